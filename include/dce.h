@@ -1,0 +1,133 @@
+/*
+ * dce.h -- C ABI of libdce.so: the MI355X (gfx950) sliding-window contact-state
+ * inference path.
+ *
+ * The reference (UMich-CURLY/deep-contact-estimator) has no FFI layer: its hot path
+ * is reached through three Python-level contracts.  Each entry point below names the
+ * reference call it stands in for, so that a maintainer can bind it with ctypes (see
+ * INTEGRATION.md) behind the unchanged Python surface:
+ *
+ *   contact_cnn() + load_state_dict(...)      src/contact_cnn.py:7-58,
+ *                                             src/inference_one_seq.py:153-156
+ *   model(input_data) -> (B,16) logits        src/contact_cnn.py:60-66,
+ *                                             src/inference_one_seq.py:25, src/test.py:87
+ *   contact_dataset.__getitem__ (z-score)     utils/data_handler.py:32-61
+ *   inference() loop: argmax + bit-unpack     src/inference_one_seq.py:19-30,59-62
+ *
+ * Conventions
+ *   - plain C types only; no C++/torch types cross this boundary.
+ *   - every function returns 0 (DCE_OK) or a negative dce_status; nothing throws or
+ *     aborts.  dce_last_error(ctx) gives a human-readable message for the last failure.
+ *   - a ctx is bound to ONE device and ONE stream and is not re-entrant.  Multi-GPU is
+ *     one ctx per device (one process per GPU in this repo).
+ *   - "on_device" flags say whether the caller's data pointers are device (HIP) or host
+ *     pointers.  Host pointers are staged through ctx-owned pinned/device buffers.
+ *   - any output pointer may be NULL to skip that output.
+ *   - all launches are asynchronous on the ctx stream when on_device != 0; with host
+ *     pointers the call returns after the results have landed in host memory.
+ */
+#ifndef DCE_H
+#define DCE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCE_WINDOW      150   /* config/*.yaml window_size; hard-wired in the model (4736 = 128*37) */
+#define DCE_CHANNELS    54    /* utils/mat2numpy.py:73  q12 qd12 acc3 omega3 p12 v12 */
+#define DCE_CLASSES     16    /* src/contact_cnn.py:56-57 */
+#define DCE_LEGS        4     /* src/inference_one_seq.py:59-62 */
+#define DCE_FEAT        4736  /* src/contact_cnn.py:48  128 channels * 37 */
+#define DCE_FC1         2048
+#define DCE_FC2         512
+
+typedef enum dce_status {
+    DCE_OK              =  0,
+    DCE_ERR_ARG         = -1,  /* NULL / out-of-range / wrong shape */
+    DCE_ERR_HIP         = -2,  /* a HIP runtime call failed; message has hipGetErrorString */
+    DCE_ERR_STATE       = -3,  /* called in the wrong order (e.g. forward before finalize) */
+    DCE_ERR_KEY         = -4,  /* unknown or duplicate state_dict key */
+    DCE_ERR_NOMEM       = -5
+} dce_status;
+
+typedef enum dce_precision {
+    DCE_FP32            = 0,   /* fp32 MFMA everywhere (exact fp32 fmaf chains) -- the headline path */
+    DCE_BF16_FC         = 1    /* bf16 MFMA (fp32 accumulate) on the FC layers; conv stays fp32 */
+} dce_precision;
+
+typedef struct dce_ctx dce_ctx;   /* opaque; owns device weights, scratch and (by default) a stream */
+
+/* Library/ABI version, for binding sanity checks. */
+int  dce_abi_version(void);
+
+/* Number of visible HIP devices, or a negative dce_status. */
+int  dce_device_count(void);
+
+/* contact_cnn().to(device): create a context on device_id.  max_batch bounds the
+ * windows per forward call (scratch for conv features / FC activations is sized from
+ * it: 4736+2048+512 floats per window); calls with more windows are chunked inside. */
+int  dce_create(dce_ctx** out, int device_id, int64_t max_batch);
+void dce_destroy(dce_ctx* ctx);
+
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the
+ * ctx-owned one.  stream == NULL restores the ctx-owned stream. */
+int  dce_set_stream(dce_ctx* ctx, void* hip_stream);
+
+/* load_state_dict: one call per state_dict key of contact_cnn (src/contact_cnn.py:8-58):
+ *   block1.0.weight (64,54,3)   block1.0.bias (64)    block1.2.weight (64,64,3)    block1.2.bias (64)
+ *   block2.0.weight (128,64,3)  block2.0.bias (128)   block2.2.weight (128,128,3)  block2.2.bias (128)
+ *   fc.0.weight (2048,4736)     fc.0.bias (2048)      fc.3.weight (512,2048)       fc.3.bias (512)
+ *   fc.6.weight (16,512)        fc.6.bias (16)
+ * host is a contiguous fp32 HOST array in PyTorch layout; it is copied. */
+int  dce_load_weight(dce_ctx* ctx, const char* key, const float* host,
+                     const int64_t* shape, int ndim);
+
+/* model.eval(): check all 14 keys are present, repack into kernel layouts, upload. */
+int  dce_finalize_weights(dce_ctx* ctx, int precision /* dce_precision */);
+
+/* model(input_data) + torch.max(output,1) + decimal2binary:
+ * windows (n,150,54) fp32, ALREADY z-scored (what DataLoader yields) ->
+ * logits (n,16) f32, pred (n) i32 argmax (ties -> lowest index), contacts (n,4) u8
+ * (MSB first: class 9 -> 1,0,0,1). */
+int  dce_forward_windows(dce_ctx* ctx, const float* windows, int64_t n, int on_device,
+                         float* logits, int32_t* pred, uint8_t* contacts);
+
+/* contact_dataset + DataLoader + inference(): raw sequence (T,54) fp32 -> results for
+ * the T-149 sliding windows; output row j belongs to data row j+149.  Each window is
+ * z-scored per channel over time (mean, unbiased std, no epsilon) inside the kernel.
+ * window must be 150. */
+int  dce_infer_sequence(dce_ctx* ctx, const float* seq, int64_t T, int window, int on_device,
+                        float* logits, int32_t* pred, uint8_t* contacts);
+
+/* contact_dataset.__getitem__ for windows [first, first+n): materialise the z-scored
+ * windows (n,150,54) from a raw (T,54) sequence (utils/data_handler.py:55-56). */
+int  dce_zscore_windows(dce_ctx* ctx, const float* seq, int64_t T, int64_t first, int64_t n,
+                        int on_device, float* windows_out);
+
+/* Per-layer taps for parity tests: run ONE batch of pre-normalised windows and copy out
+ * intermediate activations (device or host pointers per on_device; any may be NULL):
+ *   feat (n,4736) = block2 output flattened channel-major (src/contact_cnn.py:64)
+ *   h1   (n,2048) = ReLU(fc.0)      h2 (n,512) = ReLU(fc.3) */
+int  dce_forward_taps(dce_ctx* ctx, const float* windows, int64_t n, int on_device,
+                      float* feat, float* h1, float* h2, float* logits);
+
+/* Kernel timing with HIP events on the ctx's stream, for bench.py's roofline block.
+ * Enables per-kernel event recording for subsequent forward calls; dce_profile_read
+ * synchronises and returns the accumulated milliseconds and launch counts since the
+ * last reset:  slot 0 = conv stack, 1 = fc1 GEMM, 2 = fc2 GEMM, 3 = fc3+argmax tail. */
+#define DCE_PROFILE_SLOTS 4
+int  dce_profile_enable(dce_ctx* ctx, int on);
+int  dce_profile_read(dce_ctx* ctx, double ms[DCE_PROFILE_SLOTS], int64_t launches[DCE_PROFILE_SLOTS], int reset);
+
+/* Block until everything queued on the ctx stream has finished. */
+int  dce_sync(dce_ctx* ctx);
+
+/* Message for the last failing call on this ctx (or on creation when ctx == NULL). */
+const char* dce_last_error(dce_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCE_H */

@@ -1,0 +1,143 @@
+"""ctypes binding of oracle/libdce_oracle.so (dce_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Parity status: pinned by tests/test_oracle.py against tests/golden/*.npz (generated from the
+imported reference by tests/golden/make_golden.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdce_oracle.so")
+
+_KEYS = (
+    ("block1.0.weight", "block1.0.bias"), ("block1.2.weight", "block1.2.bias"),
+    ("block2.0.weight", "block2.0.bias"), ("block2.2.weight", "block2.2.bias"),
+    ("fc.0.weight", "fc.0.bias"), ("fc.3.weight", "fc.3.bias"), ("fc.6.weight", "fc.6.bias"),
+)
+
+
+class _Weights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "c1w", "c1b", "c2w", "c2b", "c3w", "c3b", "c4w", "c4b",
+        "f1w", "f1b", "f2w", "f2b", "f3w", "f3b")]
+
+
+def build(force: bool = False) -> str:
+    """Compile dce_oracle.c with gcc if the .so is missing or stale."""
+    src = os.path.join(_HERE, "dce_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_argmax16.restype = C.c_int32
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Holds a state_dict (numpy fp32, PyTorch layouts) and evaluates the reference path."""
+
+    def __init__(self, state_dict):
+        self._keep = []
+        w = _Weights()
+        names = [f[0] for f in _Weights._fields_]
+        i = 0
+        for wk, bk in _KEYS:
+            for k in (wk, bk):
+                a = np.ascontiguousarray(np.asarray(state_dict[k]), dtype=np.float32)
+                self._keep.append(a)
+                setattr(w, names[i], a.ctypes.data)
+                i += 1
+        self._w = w
+
+    def forward_windows(self, windows, taps: bool = False):
+        """windows (n,150,54) pre-normalised -> dict(logits, pred, contacts[, feat, h1, h2])."""
+        x = np.ascontiguousarray(windows, dtype=np.float32)
+        n = x.shape[0]
+        assert x.shape[1:] == (150, 54)
+        out = {
+            "logits": np.empty((n, 16), np.float32),
+            "pred": np.empty((n,), np.int32),
+            "contacts": np.empty((n, 4), np.uint8),
+        }
+        if taps:
+            out["feat"] = np.empty((n, 4736), np.float32)
+            out["h1"] = np.empty((n, 2048), np.float32)
+            out["h2"] = np.empty((n, 512), np.float32)
+        rc = lib().oracle_forward_windows(
+            C.byref(self._w), _p(x), C.c_int64(n), _p(out.get("feat")), _p(out.get("h1")),
+            _p(out.get("h2")), _p(out["logits"]), _p(out["pred"]), _p(out["contacts"]))
+        assert rc == 0
+        return out
+
+    def infer_sequence(self, seq, want_windows: bool = False):
+        """seq (T,54) raw -> dict(logits (N,16), pred (N,), contacts (N,4)[, windows])."""
+        s = np.ascontiguousarray(seq, dtype=np.float32)
+        T = s.shape[0]
+        n = max(T - 149, 0)
+        out = {
+            "logits": np.empty((n, 16), np.float32),
+            "pred": np.empty((n,), np.int32),
+            "contacts": np.empty((n, 4), np.uint8),
+        }
+        if want_windows:
+            out["windows"] = np.empty((n, 150, 54), np.float32)
+        rc = lib().oracle_infer_sequence(
+            C.byref(self._w), _p(s), C.c_int64(T), _p(out.get("windows")),
+            _p(out["logits"]), _p(out["pred"]), _p(out["contacts"]))
+        assert rc == 0
+        return out
+
+    def layer_taps(self, window):
+        """One pre-normalised window (150,54) -> per-layer activations in [C][T] layout."""
+        x = np.ascontiguousarray(window, dtype=np.float32)
+        assert x.shape == (150, 54)
+        out = {
+            "conv1": np.empty((64, 150), np.float32), "conv2": np.empty((64, 150), np.float32),
+            "pool1": np.empty((64, 75), np.float32), "conv3": np.empty((128, 75), np.float32),
+            "conv4": np.empty((128, 75), np.float32), "pool2": np.empty((128, 37), np.float32),
+        }
+        rc = lib().oracle_layer_taps(C.byref(self._w), _p(x), *[_p(out[k]) for k in (
+            "conv1", "conv2", "pool1", "conv3", "conv4", "pool2")])
+        assert rc == 0
+        return out
+
+
+def zscore_windows(seq):
+    """(T,54) raw -> (T-149,150,54) z-scored windows (utils/data_handler.py:55-56)."""
+    s = np.ascontiguousarray(seq, dtype=np.float32)
+    T = s.shape[0]
+    n = max(T - 149, 0)
+    w = np.empty((n, 150, 54), np.float32)
+    rc = lib().oracle_infer_sequence(None, _p(s), C.c_int64(T), _p(w), None, None, None)
+    assert rc == 0
+    return w
+
+
+def argmax16(logits):
+    lg = np.ascontiguousarray(logits, dtype=np.float32).reshape(-1, 16)
+    return np.array([lib().oracle_argmax16(_p(lg[i:i + 1])) for i in range(lg.shape[0])], np.int32)
+
+
+def decimal2binary(cls):
+    """numpy restatement of reference src/inference_one_seq.py:59-62."""
+    c = np.asarray(cls).astype(np.int64)
+    return ((c[..., None] & np.array([8, 4, 2, 1])) != 0).astype(np.uint8)

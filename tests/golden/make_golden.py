@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container, where /root/reference exists; the outputs (small .npz
+files of inputs' checksums and expected outputs -- data, not code) are committed and travel
+to the GPU box; the reference does not.
+
+What is imported from the reference (read-only, no bytecode written):
+    src/contact_cnn.py        contact_cnn                       (the model)
+    utils/data_handler.py     contact_dataset                   (windowing + z-score)
+    src/test.py               compute_accuracy, decimal2binary  (loop, argmax, bit unpack)
+src/inference_one_seq.py cannot be imported (it needs the `lcm` module, absent offline); its
+10-line inference() loop (src/inference_one_seq.py:19-30) is the same loop as
+test.compute_accuracy minus the labels, and is exercised through the latter.
+
+Weights/inputs come from deep_contact_estimator_amd.synth (seeded numpy streams), so tests
+regenerate them bit-identically without torch; the fixtures store checksums to prove it.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import tempfile
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("DCE_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(REF, "src"), REF, ROOT]
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from contact_cnn import contact_cnn                     # reference
+from utils.data_handler import contact_dataset          # reference
+import test as ref_test                                  # reference src/test.py
+
+from deep_contact_estimator_amd import synth
+
+torch.manual_seed(0)
+torch.set_num_threads(1)     # fixed summation order for the committed values
+
+
+def build_model(sd_np):
+    model = contact_cnn()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    return model.eval()
+
+
+def checksum(a):
+    a = np.ascontiguousarray(a)
+    return np.array([float(a.astype(np.float64).sum()), float(np.abs(a.astype(np.float64)).sum())])
+
+
+def run_case(name, wseed, bias, T, sseed, kind, batch, label_2d):
+    sd = synth.make_state_dict(wseed, bias)
+    seq = synth.make_sequence(T, sseed, kind)            # float64, like mat2numpy output
+    lab = synth.make_labels(T, sseed, two_d=label_2d)
+    model = build_model(sd)
+    with tempfile.TemporaryDirectory() as d:
+        dp, lp = os.path.join(d, "data.npy"), os.path.join(d, "label.npy")
+        np.save(dp, seq)
+        np.save(lp, lab)
+        ds = contact_dataset(data_path=dp, label_path=lp, window_size=150, device="cpu")
+        n = len(ds)
+        # --- the reference loop, verbatim call: test.compute_accuracy (src/test.py:72-107)
+        if not label_2d:
+            acc, acc_leg, bin_pred, bin_gt, pred_arr, gt_arr = ref_test.compute_accuracy(
+                DataLoader(dataset=ds, batch_size=batch), model)
+        # --- logits + the inference() loop shape (src/inference_one_seq.py:19-30)
+        logits, preds, contacts, labels = [], [], [], []
+        infer_results = torch.empty(0, 4, dtype=torch.uint8)
+        with torch.no_grad():
+            for sample in DataLoader(dataset=ds, batch_size=batch):
+                out = model(sample["data"])
+                _, p = torch.max(out, 1)
+                b = ref_test.decimal2binary(p)
+                infer_results = torch.cat((infer_results, b), 0)
+                logits.append(out.numpy().copy())
+                preds.append(p.numpy().copy())
+                labels.append(sample["label"].numpy().reshape(-1).copy())
+        logits = np.concatenate(logits)
+        preds = np.concatenate(preds)
+        labels = np.concatenate(labels)
+        contacts = infer_results.numpy()
+        assert contacts.shape == (n, 4) and contacts.dtype == np.uint8
+        if not label_2d:
+            assert np.array_equal(bin_pred.astype(np.uint8), contacts)
+            assert np.array_equal(pred_arr.astype(np.int64), preds)
+        # --- z-scored windows straight from contact_dataset.__getitem__
+        idx = [0, 1, n // 2, n - 1]
+        zwin = np.stack([ds[i]["data"].numpy() for i in idx])
+        # --- per-layer activations of window 0 via forward hooks on the reference modules
+        taps = {}
+        hooks = [
+            (model.block1[1], "conv1"), (model.block1[3], "conv2"), (model.block1[5], "pool1"),
+            (model.block2[1], "conv3"), (model.block2[3], "conv4"), (model.block2[5], "pool2"),
+            (model.fc[1], "fc1"), (model.fc[4], "fc2"),
+        ]
+        hs = [m.register_forward_hook(lambda _m, _i, o, k=k: taps.__setitem__(k, o[0].numpy().copy()))
+              for m, k in hooks]
+        with torch.no_grad():
+            model(ds[0]["data"].unsqueeze(0))
+        for h in hs:
+            h.remove()
+    srt = np.sort(logits, axis=1)
+    margin = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+    out = dict(
+        wseed=wseed, bias=bias, T=T, sseed=sseed, kind=kind, batch=batch,
+        seq_checksum=checksum(seq.astype(np.float32)),
+        w_checksum=np.stack([checksum(sd[k]) for k, _ in synth.STATE_DICT_SHAPES]),
+        logits=logits.astype(np.float32), pred=preds.astype(np.int32), contacts=contacts,
+        margin=margin, labels=labels.astype(np.int64),
+        zwin_idx=np.array(idx), zwin=zwin.astype(np.float32),
+        **{"tap_" + k: v.astype(np.float32) for k, v in taps.items()},
+    )
+    if not label_2d:
+        out.update(acc=np.float64(acc), acc_per_leg=np.asarray(acc_leg, np.float64))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: n={n} classes={np.unique(preds).size} min_margin={margin.min():.3e} "
+          f"median_margin={np.median(margin):.3f} max|logit|={np.abs(logits).max():.2f}")
+
+
+def edge_cases():
+    """Pinned edge semantics: tie -> lowest index; constant channel -> NaN
+    logits -> class 0; decimal2binary table."""
+    sd = synth.make_state_dict(1, "uniform")
+    model = build_model(sd)
+    seq = synth.make_sequence(150 + 3, 11, "normal")
+    seq[:, 7] = 3.25                                  # constant channel -> std 0 -> NaN
+    with tempfile.TemporaryDirectory() as d:
+        dp, lp = os.path.join(d, "data.npy"), os.path.join(d, "label.npy")
+        np.save(dp, seq)
+        np.save(lp, synth.make_labels(153, 11))
+        ds = contact_dataset(data_path=dp, label_path=lp, window_size=150, device="cpu")
+        with torch.no_grad():
+            x = torch.stack([ds[i]["data"] for i in range(len(ds))])
+            out = model(x)
+            _, p = torch.max(out, 1)
+    tie = torch.tensor([[0., 2., 2., 1.] + [0.] * 12, [5.] * 16])
+    _, ptie = torch.max(tie, 1)
+    d2b = ref_test.decimal2binary(torch.arange(16)).numpy()
+    np.savez_compressed(
+        os.path.join(HERE, "edge.npz"),
+        const_channel=7, const_value=3.25, const_T=153, const_sseed=11,
+        const_logits_isnan=np.isnan(out.numpy()), const_pred=p.numpy().astype(np.int32),
+        const_zwin_nan_cols=np.isnan(x.numpy()).all(axis=(0, 1)),
+        tie_logits=tie.numpy(), tie_pred=ptie.numpy().astype(np.int32),
+        decimal2binary=d2b)
+    print("edge: const-channel pred", p.numpy(), "tie pred", ptie.numpy())
+
+
+if __name__ == "__main__":
+    # case A: N(0,1) sequence, biased He weights, batch 30 (config/test_params.yaml:9), 1-D labels
+    run_case("seq_normal", wseed=1, bias="uniform", T=150 + 255, sseed=0, kind="normal",
+             batch=30, label_2d=False)
+    # case B: AR(1)+offset sequence (z-score cancellation stress), zero-bias weights, batch 1
+    # (config/inference_one_seq_params.yaml:10), (T,1) labels as mat2numpy_one_seq writes
+    run_case("seq_ar1", wseed=2, bias="zero", T=150 + 127, sseed=5, kind="ar1",
+             batch=1, label_2d=True)
+    edge_cases()

@@ -1,0 +1,96 @@
+"""CPU: pin the oracle (C restatement + torch functional restatement) against the golden
+vectors captured from the imported reference (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import tol_ok
+from oracle import oracle as orc
+
+CASES = ["seq_normal", "seq_ar1"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_zscore_matches_contact_dataset(name, golden, case_inputs):
+    g = golden(name)
+    _, seq = case_inputs(g)
+    w = orc.zscore_windows(seq)
+    assert w.shape == (seq.shape[0] - 149, 150, 54)
+    # reference: utils/data_handler.py:55-56 on fp32 data; fp32 round-off of mean/std only
+    np.testing.assert_allclose(w[g["zwin_idx"]], g["zwin"], rtol=0, atol=2e-5 * np.abs(g["zwin"]).max())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sequence_logits_argmax_contacts(name, golden, case_inputs):
+    g = golden(name)
+    sd, seq = case_inputs(g)
+    out = orc.Oracle(sd).infer_sequence(seq)
+    tol_ok(out["logits"], g["logits"], "logits")
+    # argmax must be exact wherever the reference's own top-2 margin clears the fp32 noise floor
+    tau = 1e-3 * np.abs(g["logits"]).max()
+    safe = g["margin"] > tau
+    assert safe.sum() >= 0.95 * safe.size
+    assert np.array_equal(out["pred"][safe], g["pred"][safe])
+    assert np.array_equal(out["contacts"][safe], g["contacts"][safe])
+    # in these fixtures nothing sits below the floor either: whole arrays bit-identical
+    assert np.array_equal(out["pred"], g["pred"])
+    assert np.array_equal(out["contacts"], g["contacts"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_layer_taps_window0(name, golden, case_inputs):
+    g = golden(name)
+    sd, seq = case_inputs(g)
+    o = orc.Oracle(sd)
+    win0 = g["zwin"][0]                       # the reference's own z-scored window 0
+    taps = o.layer_taps(win0)
+    for k in ("conv1", "conv2", "pool1", "conv3", "conv4", "pool2"):
+        tol_ok(taps[k], g["tap_" + k], k)
+    fw = o.forward_windows(win0[None], taps=True)
+    # flatten is channel-major c*37+t (src/contact_cnn.py:64)
+    tol_ok(fw["feat"][0], g["tap_pool2"].reshape(-1), "feat")
+    tol_ok(fw["h1"][0], g["tap_fc1"], "fc1")
+    tol_ok(fw["h2"][0], g["tap_fc2"], "fc2")
+    tol_ok(fw["logits"][0], g["logits"][0], "logits0")
+
+
+def test_edge_semantics(golden):
+    from deep_contact_estimator_amd import synth
+    e = golden("edge")
+    # decimal2binary table, MSB = leg 0 (src/inference_one_seq.py:59-62)
+    assert np.array_equal(orc.decimal2binary(np.arange(16)), e["decimal2binary"])
+    assert np.array_equal(orc.decimal2binary(np.array([9]))[0], [1, 0, 0, 1])
+    # ties -> lowest index
+    assert np.array_equal(orc.argmax16(e["tie_logits"]), e["tie_pred"])
+    # constant channel -> NaN column -> NaN logits -> class 0
+    seq = synth.make_sequence(int(e["const_T"]), int(e["const_sseed"]), "normal")
+    seq[:, int(e["const_channel"])] = float(e["const_value"])
+    sd = synth.make_state_dict(1, "uniform")
+    out = orc.Oracle(sd).infer_sequence(seq.astype(np.float32), want_windows=True)
+    assert np.array_equal(np.isnan(out["windows"]).all(axis=(0, 1)), e["const_zwin_nan_cols"])
+    assert np.array_equal(np.isnan(out["logits"]), e["const_logits_isnan"])
+    assert np.array_equal(out["pred"], e["const_pred"])
+
+
+def test_empty_and_short_sequences():
+    from deep_contact_estimator_amd import synth
+    o = orc.Oracle(synth.make_state_dict(1))
+    for T in (0, 1, 149):
+        out = o.infer_sequence(np.zeros((T, 54), np.float32))
+        assert out["logits"].shape == (0, 16) and out["contacts"].shape == (0, 4)
+    out = o.infer_sequence(synth.make_sequence(150, 3).astype(np.float32))
+    assert out["logits"].shape == (1, 16)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_torch_restatement_matches_reference(name, golden, case_inputs):
+    """oracle/torch_ref.py is what bench.py times as cpu_baseline; it must BE the reference path."""
+    torch = pytest.importorskip("torch")
+    from oracle import torch_ref
+    g = golden(name)
+    sd, seq = case_inputs(g)
+    torch.set_num_threads(1)
+    tsd = torch_ref.to_torch(sd)
+    contacts = torch_ref.reference_loop(tsd, torch.from_numpy(seq), int(g["batch"])).numpy()
+    assert np.array_equal(contacts, g["contacts"])
+    logits = torch_ref.forward(tsd, torch.from_numpy(orc.zscore_windows(seq))).numpy()
+    tol_ok(logits, g["logits"], "torch_ref logits")
