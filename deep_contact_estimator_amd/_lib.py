@@ -1,0 +1,62 @@
+"""ctypes binding of libdce.so -- the only way the Python host reaches the GPU.
+
+There is deliberately NO fallback: if the HIP library is missing or no MI355X is visible the
+product fails loudly (RuntimeError), it never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdce.so")
+
+# every symbol include/dce.h declares: (name, restype, argtypes)
+_i64p = C.POINTER(C.c_int64)
+SYMBOLS = {
+    "dce_abi_version": (C.c_int, []),
+    "dce_device_count": (C.c_int, []),
+    "dce_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64]),
+    "dce_destroy": (None, [C.c_void_p]),
+    "dce_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dce_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, _i64p, C.c_int]),
+    "dce_finalize_weights": (C.c_int, [C.c_void_p, C.c_int]),
+    "dce_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dce_infer_sequence": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dce_zscore_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "dce_forward_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dce_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "dce_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), _i64p, C.c_int]),
+    "dce_sync": (C.c_int, [C.c_void_p]),
+    "dce_last_error": (C.c_char_p, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libdce.so and bind every declared symbol.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m deep_contact_estimator_amd.build` "
+            "(there is no CPU fallback for the inference path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class DceError(RuntimeError):
+    pass
+
+
+def check(rc: int, ctx=None):
+    if rc != 0:
+        msg = load().dce_last_error(ctx)
+        raise DceError(f"libdce error {rc}: {msg.decode() if msg else '?'}")

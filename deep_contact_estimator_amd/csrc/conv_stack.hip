@@ -1,0 +1,370 @@
+// conv_stack.hip -- fused z-score + Conv1d x4 + ReLU + MaxPool1d x2 for gfx950 (MI355X).
+//
+// Replaces, for the inference path, what PyTorch dispatches for
+//   utils/data_handler.py:55-56      per-window z-score (mean, unbiased std over time)
+//   src/contact_cnn.py:61            permute (B,150,54) -> (B,54,150)
+//   src/contact_cnn.py:10-26,28-44   block1 / block2 (Dropout = identity in eval)
+//   src/contact_cnn.py:64            view(B,-1): feat index = c*37 + t
+//
+// Design (see DESIGN.md "conv stack"):
+//  * One workgroup = 4 waves = NW(2) windows; two workgroups are co-resident per CU
+//    (<= 80 KiB LDS and <= 256 VGPRs each), so one group's load/z-score/store phases hide
+//    under the other's MFMA phases.
+//  * Every activation of the two windows lives in ONE LDS buffer in [channel][position]
+//    layout; a layer's whole output is held in MFMA accumulators (80 VGPRs/lane) until all
+//    waves have finished reading its input, then written back IN PLACE.  HBM sees only the
+//    raw sensor rows and the 4736 pooled features per window.
+//  * Each conv is an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains at the
+//    fp32 peak rate): M = Cout, N = positions of both windows laid side by side with their
+//    zero pads as ordinary columns, K = (tap, cin).  The B operand is read straight from the
+//    activation rows (lane = position -> conflict-free ds_read_b32, the +-1 tap shift is an
+//    address immediate); the A operand (weights, pre-packed per lane on the host) streams
+//    from L2 as one float4 per lane per 4 K-steps.
+//  * Bias is the accumulator's initial value; ReLU, zero-padding and MaxPool (adjacent
+//    positions = adjacent lanes -> one DPP quad_perm) are fused in the write-back.
+//
+// Position layouts (p = column index of the implicit GEMM; LDS address = row*S + p + 1):
+//   stage 1 (T=150): p = 2 + 152*w + t      pads p = 1,152,153,304      row stride S1 = 307
+//   stage 2 (T=75):  q = 2 +  76*w + t      pads q = 1,77,153           row stride S2 = 155
+// t = 0 sits on an even column in both, so pooling pairs (2j,2j+1) are lanes (2m,2m+1), and
+// pooling maps stage 1 to stage 2 by q = p/2 + 1 for both windows and for the pads alike.
+#include "dce_kernels.h"
+
+namespace dce {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NW  = 2;            // windows per workgroup
+constexpr int S1  = 307;          // odd strides: transposing stores hit 32 distinct banks
+constexpr int S2  = 155;
+constexpr int ACT_FLOATS = 128 * S2 + 16;             // 19,856 floats = 79,424 B (>= 64*S1+16)
+constexpr int NT  = 5;            // 32-column tiles per wave (stage 1: 10 tiles / 2, stage 2: 5)
+constexpr int RED_ROW = 56;       // stage-1 rows 56.. are free until conv1 writes back
+static_assert(64 * S1 + 16 <= ACT_FLOATS, "stage-1 image must fit");
+static_assert(ACT_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+
+// ------------------------------------------------------------------------------------------
+// Host-side weight packing
+// ------------------------------------------------------------------------------------------
+static const int kCin[4]  = {54, 64, 64, 128};
+static const int kCinP[4] = {56, 64, 64, 128};
+static const int kCout[4] = {64, 64, 128, 128};
+
+size_t conv_pack_floats(int l) { return (size_t)kCout[l] * 3 * kCinP[l]; }
+
+void conv_pack_host(int l, const float* w, float* out)
+{
+    const int cin = kCin[l], G = kCinP[l] / 8, cout = kCout[l];
+    size_t o = 0;
+    for (int mt = 0; mt < cout / 32; ++mt)
+        for (int g = 0; g < G; ++g)
+            for (int tap = 0; tap < 3; ++tap)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int u = 0; u < 4; ++u) {
+                        const int co = 32 * mt + (lane & 31);
+                        const int ci = 8 * g + 2 * u + (lane >> 5);
+                        out[o++] = ci < cin ? w[((size_t)co * cin + ci) * 3 + tap] : 0.f;
+                    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }   // keeps NaN like torch
+
+__device__ __forceinline__ float swap_adjacent(float v)
+{   // lane 2m <-> 2m+1 : DPP quad_perm [1,0,3,2]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+
+// Implicit-GEMM main loop of one conv layer for one wave: 5 column tiles x one 32-row tile.
+//   bsrc = act + (lane>>5)*S + (lane&31) + 32*first_tile       (this lane's B element, tap 0, cin pair 0)
+//   ap   = packed weights of this wave's row tile, + lane
+template <int CINP, int S>
+__device__ __forceinline__ void conv_mfma(const float* __restrict__ bsrc,
+                                          const float4* __restrict__ ap, f32x16 (&acc)[NT])
+{
+    constexpr int G = CINP / 8;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        const float* bp = bsrc + g * 8 * S;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const float4 a4 = ap[(g * 3 + tap) * 64];
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bp[2 * u * S + 32 * t + tap],
+                                                                  acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, int m0, int h,
+                                              f32x16 (&acc)[NT])
+{
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = bias[m0 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = bv[r];
+}
+
+// column validity: is column p a real sample (not a pad / filler) in a layout with window
+// stride WS and TLEN samples per window?
+template <int WS, int TLEN>
+__device__ __forceinline__ bool col_valid(int p)
+{
+    const int r = p - 2;
+    const int t = r >= WS ? r - WS : r;
+    return r >= 0 && r < NW * WS && t < TLEN;
+}
+
+// ReLU + write back a layer's accumulators in place (no pooling).
+template <int S, int WS, int TLEN>
+__device__ __forceinline__ void store_plain(float* __restrict__ act, const f32x16 (&acc)[NT],
+                                            int m0, int nt0, int lane)
+{
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int p = 32 * (nt0 + t) + j;
+        const bool valid = col_valid<WS, TLEN>(p);
+        if (p <= S - 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                act[co * S + p + 1] = valid ? relu_nan(acc[t][r]) : 0.f;
+            }
+        }
+    }
+}
+
+// ReLU + MaxPool1d(2,2) + write back into the stage-2 layout (q = p/2 + 1).
+__device__ __forceinline__ void store_pool_stage2(float* __restrict__ act, const f32x16 (&acc)[NT],
+                                                  int m0, int nt0, int lane)
+{
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int p = 32 * (nt0 + t) + j;
+        const bool valid = col_valid<152, 150>(p);
+        const bool writer = ((j & 1) == 0) && p <= 304;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = relu_nan(acc[t][r]);
+            const float o = fmaxf(v, swap_adjacent(v));      // a NaN window is NaN everywhere
+            if (writer) act[co * S2 + (p >> 1) + 2] = valid ? o : 0.f;
+        }
+    }
+}
+
+// ReLU + MaxPool1d(2,2) (floor: t = 74 dropped) + flatten (c*37 + j) to HBM.
+__device__ __forceinline__ void store_pool_feat(float* __restrict__ feat, int64_t win0, int nvalid,
+                                                const f32x16 (&acc)[NT], int m0, int lane)
+{
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = 32 * t + j;
+        const int r_ = q - 2;
+        const int w = r_ >= 76 ? 1 : 0;
+        const int tt = r_ - 76 * w;
+        const bool writer = ((j & 1) == 0) && r_ >= 0 && r_ < 152 && tt < 74 && w < nvalid;
+        float* dst = feat + (win0 + w) * FEAT + (tt >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = relu_nan(acc[t][r]);
+            const float o = fmaxf(v, swap_adjacent(v));
+            if (writer) dst[co * 37] = o;
+        }
+    }
+}
+
+// Load NWIN windows (rows t = 4m + g of channel c per thread, tid = g*54 + c < 216) and, if ZS,
+// z-score them per channel over time: mean = sum/150, std = sqrt(sum((x-mean)^2)/149), no eps
+// (utils/data_handler.py:55-56).  red: >= NWIN*2*216 floats of LDS scratch.
+template <bool ZS, int NWIN>
+__device__ __forceinline__ void load_windows(const float* __restrict__ src, int64_t win_stride,
+                                             int nvalid, float* __restrict__ red,
+                                             float (&x)[NWIN][38], int tid)
+{
+    const int c = tid % CH, g = tid / CH;
+    const bool loader = tid < 4 * CH;
+#pragma unroll
+    for (int w = 0; w < NWIN; ++w)
+#pragma unroll
+        for (int m = 0; m < 38; ++m) {
+            const int t = 4 * m + g;
+            x[w][m] = (loader && t < WIN && w < nvalid) ? src[w * win_stride + t * CH + c] : 0.f;
+        }
+    if (ZS) {
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 38; ++m) s += x[w][m];
+            if (loader) red[w * 216 + tid] = s;
+        }
+        __syncthreads();
+        float mean[NWIN];
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            const float* r = red + w * 216 + c;
+            mean[w] = loader ? ((r[0] + r[54]) + (r[108] + r[162])) / 150.f : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int m = 0; m < 38; ++m) {
+                const float d = x[w][m] - mean[w];
+                x[w][m] = d;
+                q += (4 * m + g < WIN) ? d * d : 0.f;
+            }
+            if (loader) red[(NWIN + w) * 216 + tid] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            const float* r = red + (NWIN + w) * 216 + c;
+            const float sd = loader ? sqrtf(((r[0] + r[54]) + (r[108] + r[162])) / 149.f) : 1.f;
+#pragma unroll
+            for (int m = 0; m < 38; ++m) x[w][m] = (w < nvalid) ? x[w][m] / sd : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The fused kernel
+// ------------------------------------------------------------------------------------------
+template <bool ZS>
+__global__ __launch_bounds__(256, 2)
+void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat)
+{
+    extern __shared__ __attribute__((aligned(16))) float act[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t win0 = (int64_t)blockIdx.x * NW;
+    const int nvalid = (n - win0) < NW ? (int)(n - win0) : NW;
+
+    // ---- prologue: HBM -> registers -> (z-score) -> LDS, transposed to [channel][position]
+    {
+        float x[NW][38];
+        const int64_t wstride = ZS ? CH : (int64_t)WIN * CH;
+        load_windows<ZS, NW>(src + win0 * wstride, wstride, nvalid, act + RED_ROW * S1, x, tid);
+        if (tid < 4 * CH) {
+            const int c = tid % CH, g = tid / CH;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int m = 0; m < 38; ++m) {
+                    const int t = 4 * m + g;
+                    if (t < WIN) act[c * S1 + 3 + 152 * w + t] = x[w][m];
+                }
+        }
+        // zero pads of rows 0..53 (addresses p+1 for p in {-1,0,1,152,153,304,305}) and the two
+        // filler channels 54,55 (conv1 runs K over 56 input rows with zero weights there)
+        for (int i = tid; i < CH * 7; i += 256) {
+            const int c = i / 7, k = i % 7;
+            const int a = k < 3 ? k : (k < 5 ? 150 + k : 300 + k);      // 0,1,2,153,154,305,306
+            act[c * S1 + a] = 0.f;
+        }
+        for (int i = tid; i < 2 * S1; i += 256) act[CH * S1 + i] = 0.f;
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+
+    // ---- conv1: 54(56) -> 64, stage 1
+    {
+        const int mt = wv & 1, nt0 = NT * (wv >> 1);
+        acc_init_bias(pk.b[0], 32 * mt, h, acc);
+        conv_mfma<56, S1>(act + h * S1 + j + 32 * nt0,
+                          reinterpret_cast<const float4*>(pk.w[0]) + mt * (3 * 7 * 64) + lane, acc);
+        __syncthreads();
+        store_plain<S1, 152, 150>(act, acc, 32 * mt, nt0, lane);
+        __syncthreads();
+        // ---- conv2: 64 -> 64, ReLU, pool -> stage 2
+        acc_init_bias(pk.b[1], 32 * mt, h, acc);
+        conv_mfma<64, S1>(act + h * S1 + j + 32 * nt0,
+                          reinterpret_cast<const float4*>(pk.w[1]) + mt * (3 * 8 * 64) + lane, acc);
+        __syncthreads();
+        store_pool_stage2(act, acc, 32 * mt, nt0, lane);
+        __syncthreads();
+    }
+    // ---- conv3: 64 -> 128, stage 2
+    {
+        const int mt = wv;
+        acc_init_bias(pk.b[2], 32 * mt, h, acc);
+        conv_mfma<64, S2>(act + h * S2 + j,
+                          reinterpret_cast<const float4*>(pk.w[2]) + mt * (3 * 8 * 64) + lane, acc);
+        __syncthreads();
+        store_plain<S2, 76, 75>(act, acc, 32 * mt, 0, lane);
+        __syncthreads();
+        // ---- conv4: 128 -> 128, ReLU, pool, flatten -> HBM
+        acc_init_bias(pk.b[3], 32 * mt, h, acc);
+        conv_mfma<128, S2>(act + h * S2 + j,
+                           reinterpret_cast<const float4*>(pk.w[3]) + mt * (3 * 16 * 64) + lane, acc);
+        store_pool_feat(feat, win0, nvalid, acc, 32 * mt, lane);
+    }
+}
+
+hipError_t init_conv_stack()
+{   // > 64 KiB of dynamic LDS has to be granted per function, per device
+    const int lds = ACT_FLOATS * (int)sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
+hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const ConvPack& pk,
+                             float* feat, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t lds = ACT_FLOATS * sizeof(float);
+    const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
+    if (zscore)
+        hipLaunchKernelGGL(conv_stack_kernel<true>, grid, block, lds, st, src, n, pk, feat);
+    else
+        hipLaunchKernelGGL(conv_stack_kernel<false>, grid, block, lds, st, src, n, pk, feat);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// contact_dataset.__getitem__ alone: materialise z-scored windows (n,150,54)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void zscore_windows_kernel(const float* __restrict__ seq, int64_t n, float* __restrict__ out)
+{
+    __shared__ float red[2 * 216];
+    const int tid = threadIdx.x;
+    const int64_t i = blockIdx.x;
+    float x[1][38];
+    load_windows<true, 1>(seq + i * CH, CH, 1, red, x, tid);
+    if (tid < 4 * CH) {
+        const int c = tid % CH, g = tid / CH;
+#pragma unroll
+        for (int m = 0; m < 38; ++m) {
+            const int t = 4 * m + g;
+            if (t < WIN) out[i * (WIN * CH) + t * CH + c] = x[0][m];
+        }
+    }
+    (void)n;
+}
+
+hipError_t launch_zscore_windows(const float* seq_first_row, int64_t n, float* out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(zscore_windows_kernel, dim3((unsigned)n), dim3(256), 0, st, seq_first_row, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace dce

@@ -1,0 +1,423 @@
+// dce_api.hip -- implementation of the C ABI declared in include/dce.h.
+// Owns device weights/scratch, repacks PyTorch-layout weights into kernel layouts, chunks
+// arbitrarily long inputs over the scratch, and sequences the four kernels of the path:
+//   conv_stack (z-score+conv1..4)  ->  fc_gemm (fc.0)  ->  fc_gemm (fc.3)  ->  fc3_tail (fc.6+argmax+bits)
+// No exception or abort crosses the boundary; every failure is a negative dce_status plus a message.
+#include "../../include/dce.h"
+#include "dce_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace dce;
+
+namespace {
+
+struct KeyInfo { const char* name; int ndim; int64_t shape[3]; };
+const KeyInfo kKeys[14] = {
+    {"block1.0.weight", 3, {64, 54, 3}},   {"block1.0.bias", 1, {64, 0, 0}},
+    {"block1.2.weight", 3, {64, 64, 3}},   {"block1.2.bias", 1, {64, 0, 0}},
+    {"block2.0.weight", 3, {128, 64, 3}},  {"block2.0.bias", 1, {128, 0, 0}},
+    {"block2.2.weight", 3, {128, 128, 3}}, {"block2.2.bias", 1, {128, 0, 0}},
+    {"fc.0.weight", 2, {2048, 4736, 0}},   {"fc.0.bias", 1, {2048, 0, 0}},
+    {"fc.3.weight", 2, {512, 2048, 0}},    {"fc.3.bias", 1, {512, 0, 0}},
+    {"fc.6.weight", 2, {16, 512, 0}},      {"fc.6.bias", 1, {16, 0, 0}},
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct dce_ctx {
+    int device = 0;
+    int64_t max_batch = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    std::vector<float> host_w[14];         // staged state_dict (host, PyTorch layout)
+    bool have[14] = {};
+    bool finalized = false;
+    int precision = DCE_FP32;
+
+    float* d_weights = nullptr;            // one allocation: conv packs, biases, fc weights
+    ConvPack pk{};
+    const float *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr,
+                *fc3w = nullptr, *fc3b = nullptr;
+
+    float *feat = nullptr, *h1 = nullptr, *h2 = nullptr;   // scratch, max_batch rows each
+
+    // staging for host-pointer callers
+    float* d_in = nullptr;   size_t d_in_bytes = 0;
+    float* d_logits = nullptr; int32_t* d_pred = nullptr; uint8_t* d_contacts = nullptr;
+    size_t d_out_rows = 0;
+
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct Span { int slot; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    double prof_ms[DCE_PROFILE_SLOTS] = {};
+    int64_t prof_n[DCE_PROFILE_SLOTS] = {};
+};
+
+namespace {
+
+int fail(dce_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((c), DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+struct Timer {   // records a [begin,end] event pair around one launch when profiling is on
+    dce_ctx* c; int slot; hipEvent_t a = nullptr, b = nullptr;
+    Timer(dce_ctx* c_, int slot_) : c(c_), slot(slot_)
+    {
+        if (!c->prof) return;
+        for (hipEvent_t* e : {&a, &b}) {
+            if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) { *e = nullptr; }
+        }
+        if (a && b) hipEventRecord(a, c->stream);
+    }
+    ~Timer()
+    {
+        if (!c->prof || !a || !b) return;
+        hipEventRecord(b, c->stream);
+        c->spans.push_back({slot, a, b});
+    }
+};
+
+int drain_spans(dce_ctx* c)
+{
+    for (auto& s : c->spans) {
+        HIP_TRY(c, hipEventSynchronize(s.b));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, s.a, s.b));
+        c->prof_ms[s.slot] += ms;
+        c->prof_n[s.slot] += 1;
+        c->ev_pool.push_back(s.a);
+        c->ev_pool.push_back(s.b);
+    }
+    c->spans.clear();
+    return DCE_OK;
+}
+
+// One chunk (n <= max_batch) of the path, everything on device.
+//   src: raw sequence rows (zscore=1) or pre-normalised windows (zscore=0)
+int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
+              float* logits, int32_t* pred, uint8_t* contacts)
+{
+    { Timer t(c, 0); HIP_TRY(c, launch_conv_stack(src, zscore, n, c->pk, c->feat, c->stream)); }
+    { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
+    { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
+    { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream)); }
+    if (c->prof && c->spans.size() > 4096) return drain_spans(c);
+    return DCE_OK;
+}
+
+int ensure_in(dce_ctx* c, size_t bytes)
+{
+    if (c->d_in_bytes >= bytes) return DCE_OK;
+    if (c->d_in) { HIP_TRY(c, hipFree(c->d_in)); c->d_in = nullptr; c->d_in_bytes = 0; }
+    HIP_TRY(c, hipMalloc(&c->d_in, bytes));
+    c->d_in_bytes = bytes;
+    return DCE_OK;
+}
+
+int ensure_out(dce_ctx* c, size_t rows)
+{
+    if (c->d_out_rows >= rows) return DCE_OK;
+    if (c->d_logits) { hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); }
+    c->d_logits = nullptr; c->d_pred = nullptr; c->d_contacts = nullptr; c->d_out_rows = 0;
+    HIP_TRY(c, hipMalloc(&c->d_logits, rows * NCLS * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->d_pred, rows * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_contacts, rows * 4));
+    c->d_out_rows = rows;
+    return DCE_OK;
+}
+
+int check_ready(dce_ctx* c)
+{
+    if (!c) return DCE_ERR_ARG;
+    if (!c->finalized) return fail(c, DCE_ERR_STATE, "weights not finalized: call dce_finalize_weights first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return DCE_OK;
+}
+
+// Shared driver for forward_windows / infer_sequence: chunk over max_batch, stage host buffers.
+int run_all(dce_ctx* c, const float* src, int zscore, int64_t n, int64_t src_floats, int on_device,
+            float* logits, int32_t* pred, uint8_t* contacts)
+{
+    const float* dsrc = src;
+    float* dl = logits; int32_t* dp = pred; uint8_t* dc = contacts;
+    if (!on_device) {
+        int rc = ensure_in(c, (size_t)src_floats * sizeof(float));
+        if (rc) return rc;
+        rc = ensure_out(c, (size_t)n);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_in, src, (size_t)src_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        dsrc = c->d_in; dl = c->d_logits; dp = c->d_pred; dc = c->d_contacts;
+    }
+    const int64_t row_floats = zscore ? CH : (int64_t)WIN * CH;
+    for (int64_t i0 = 0; i0 < n; i0 += c->max_batch) {
+        const int64_t nb = (n - i0) < c->max_batch ? (n - i0) : c->max_batch;
+        int rc = run_chunk(c, dsrc + i0 * row_floats, zscore, nb,
+                           dl ? dl + i0 * NCLS : nullptr, dp ? dp + i0 : nullptr, dc ? dc + i0 * 4 : nullptr);
+        if (rc) return rc;
+    }
+    if (!on_device) {
+        if (logits)   HIP_TRY(c, hipMemcpyAsync(logits, dl, (size_t)n * NCLS * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (pred)     HIP_TRY(c, hipMemcpyAsync(pred, dp, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (contacts) HIP_TRY(c, hipMemcpyAsync(contacts, dc, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return DCE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dce_abi_version(void) { return 1; }
+
+int dce_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { fail(nullptr, DCE_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); return DCE_ERR_HIP; }
+    return n;
+}
+
+int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
+{
+    if (!out || max_batch <= 0 || device_id < 0) return fail(nullptr, DCE_ERR_ARG, "dce_create: bad argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, DCE_ERR_HIP, "no HIP device available (%s): the HIP path is mandatory, there is no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id >= ndev) return fail(nullptr, DCE_ERR_ARG, "device %d out of range (%d devices)", device_id, ndev);
+    dce_ctx* c = new (std::nothrow) dce_ctx();
+    if (!c) return fail(nullptr, DCE_ERR_NOMEM, "out of host memory");
+    c->device = device_id;
+    c->max_batch = max_batch;
+#define CREATE_TRY(expr)                                                                        \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                        \
+        fail(nullptr, DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));              \
+        dce_destroy(c); return DCE_ERR_HIP; } } while (0)
+    CREATE_TRY(hipSetDevice(device_id));
+    CREATE_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CREATE_TRY(init_conv_stack());
+    CREATE_TRY(init_fc_gemm());
+    CREATE_TRY(hipMalloc(&c->feat, (size_t)max_batch * FEAT * sizeof(float)));
+    CREATE_TRY(hipMalloc(&c->h1, (size_t)max_batch * FC1 * sizeof(float)));
+    CREATE_TRY(hipMalloc(&c->h2, (size_t)max_batch * FC2 * sizeof(float)));
+#undef CREATE_TRY
+    *out = c;
+    return DCE_OK;
+}
+
+void dce_destroy(dce_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2);
+    hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int dce_set_stream(dce_ctx* c, void* hip_stream)
+{
+    if (!c) return DCE_ERR_ARG;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return DCE_OK;
+}
+
+int dce_load_weight(dce_ctx* c, const char* key, const float* host, const int64_t* shape, int ndim)
+{
+    if (!c) return DCE_ERR_ARG;
+    if (!key || !host || !shape) return fail(c, DCE_ERR_ARG, "dce_load_weight: NULL argument");
+    for (int k = 0; k < 14; ++k) {
+        if (strcmp(key, kKeys[k].name) != 0) continue;
+        if (ndim != kKeys[k].ndim) return fail(c, DCE_ERR_ARG, "%s: expected %d dims, got %d", key, kKeys[k].ndim, ndim);
+        size_t count = 1;
+        for (int d = 0; d < ndim; ++d) {
+            if (shape[d] != kKeys[k].shape[d])
+                return fail(c, DCE_ERR_ARG, "%s: dim %d is %lld, expected %lld", key, d, (long long)shape[d], (long long)kKeys[k].shape[d]);
+            count *= (size_t)shape[d];
+        }
+        c->host_w[k].assign(host, host + count);
+        c->have[k] = true;
+        c->finalized = false;
+        return DCE_OK;
+    }
+    return fail(c, DCE_ERR_KEY, "unexpected state_dict key '%s'", key);
+}
+
+int dce_finalize_weights(dce_ctx* c, int precision)
+{
+    if (!c) return DCE_ERR_ARG;
+    if (precision != DCE_FP32)
+        return fail(c, DCE_ERR_ARG, "precision %d not available in this build (fp32 only)", precision);
+    for (int k = 0; k < 14; ++k)
+        if (!c->have[k]) return fail(c, DCE_ERR_STATE, "missing state_dict key '%s'", kKeys[k].name);
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    // one host image -> one upload.  Offsets kept 256-B aligned.
+    std::vector<float> img;
+    auto reserve = [&](size_t floats) { size_t off = (img.size() + 63) & ~size_t(63); img.resize(off + floats); return off; };
+    size_t off_w[4], off_b[4];
+    for (int l = 0; l < 4; ++l) {
+        off_w[l] = reserve(conv_pack_floats(l));
+        conv_pack_host(l, c->host_w[2 * l].data(), img.data() + off_w[l]);
+        off_b[l] = reserve(c->host_w[2 * l + 1].size());
+        memcpy(img.data() + off_b[l], c->host_w[2 * l + 1].data(), c->host_w[2 * l + 1].size() * sizeof(float));
+    }
+    size_t off_fc[6];
+    for (int k = 0; k < 6; ++k) {
+        const auto& v = c->host_w[8 + k];
+        off_fc[k] = reserve(v.size());
+        memcpy(img.data() + off_fc[k], v.data(), v.size() * sizeof(float));
+    }
+    if (c->d_weights) { HIP_TRY(c, hipFree(c->d_weights)); c->d_weights = nullptr; }
+    HIP_TRY(c, hipMalloc(&c->d_weights, img.size() * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(c->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    for (int l = 0; l < 4; ++l) { c->pk.w[l] = c->d_weights + off_w[l]; c->pk.b[l] = c->d_weights + off_b[l]; }
+    c->fc1w = c->d_weights + off_fc[0]; c->fc1b = c->d_weights + off_fc[1];
+    c->fc2w = c->d_weights + off_fc[2]; c->fc2b = c->d_weights + off_fc[3];
+    c->fc3w = c->d_weights + off_fc[4]; c->fc3b = c->d_weights + off_fc[5];
+    c->precision = precision;
+    c->finalized = true;
+    return DCE_OK;
+}
+
+int dce_forward_windows(dce_ctx* c, const float* windows, int64_t n, int on_device,
+                        float* logits, int32_t* pred, uint8_t* contacts)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !windows)) return fail(c, DCE_ERR_ARG, "dce_forward_windows: bad argument");
+    if (n == 0) return DCE_OK;
+    return run_all(c, windows, 0, n, n * WIN * CH, on_device, logits, pred, contacts);
+}
+
+int dce_infer_sequence(dce_ctx* c, const float* seq, int64_t T, int window, int on_device,
+                       float* logits, int32_t* pred, uint8_t* contacts)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (window != WIN) return fail(c, DCE_ERR_ARG, "window_size must be %d (the model hard-codes 4736 = 128*37), got %d", WIN, window);
+    if (T < 0 || (T > 0 && !seq)) return fail(c, DCE_ERR_ARG, "dce_infer_sequence: bad argument");
+    const int64_t n = T - WIN + 1;
+    if (n <= 0) return DCE_OK;        // contact_dataset.__len__ <= 0: nothing to do
+    return run_all(c, seq, 1, n, T * CH, on_device, logits, pred, contacts);
+}
+
+int dce_zscore_windows(dce_ctx* c, const float* seq, int64_t T, int64_t first, int64_t n,
+                       int on_device, float* windows_out)
+{
+    if (!c) return DCE_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (first < 0 || n < 0 || first + n + WIN - 1 > T || !seq || !windows_out)
+        return fail(c, DCE_ERR_ARG, "dce_zscore_windows: windows [%lld,%lld) out of range for T=%lld",
+                    (long long)first, (long long)(first + n), (long long)T);
+    if (n == 0) return DCE_OK;
+    if (on_device) {
+        HIP_TRY(c, launch_zscore_windows(seq + first * CH, n, windows_out, c->stream));
+        return DCE_OK;
+    }
+    const size_t in_floats = (size_t)(n + WIN - 1) * CH, out_floats = (size_t)n * WIN * CH;
+    int rc = ensure_in(c, (in_floats + out_floats) * sizeof(float));
+    if (rc) return rc;
+    float* dout = c->d_in + in_floats;
+    HIP_TRY(c, hipMemcpyAsync(c->d_in, seq + first * CH, in_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, launch_zscore_windows(c->d_in, n, dout, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(windows_out, dout, out_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DCE_OK;
+}
+
+int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
+                     float* feat, float* h1, float* h2, float* logits)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (n <= 0 || n > c->max_batch || !windows)
+        return fail(c, DCE_ERR_ARG, "dce_forward_taps: need 0 < n <= max_batch (%lld)", (long long)c->max_batch);
+    const float* dsrc = windows;
+    float* dl = logits;
+    if (!on_device) {
+        rc = ensure_in(c, (size_t)n * WIN * CH * sizeof(float));
+        if (rc) return rc;
+        rc = ensure_out(c, (size_t)n);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_in, windows, (size_t)n * WIN * CH * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        dsrc = c->d_in; dl = c->d_logits;
+    }
+    rc = run_chunk(c, dsrc, 0, n, dl, nullptr, nullptr);
+    if (rc) return rc;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (feat) HIP_TRY(c, hipMemcpyAsync(feat, c->feat, (size_t)n * FEAT * sizeof(float), kind, c->stream));
+    if (h1)   HIP_TRY(c, hipMemcpyAsync(h1, c->h1, (size_t)n * FC1 * sizeof(float), kind, c->stream));
+    if (h2)   HIP_TRY(c, hipMemcpyAsync(h2, c->h2, (size_t)n * FC2 * sizeof(float), kind, c->stream));
+    if (!on_device) {
+        if (logits) HIP_TRY(c, hipMemcpyAsync(logits, dl, (size_t)n * NCLS * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return DCE_OK;
+}
+
+int dce_profile_enable(dce_ctx* c, int on)
+{
+    if (!c) return DCE_ERR_ARG;
+    c->prof = on != 0;
+    return DCE_OK;
+}
+
+int dce_profile_read(dce_ctx* c, double ms[DCE_PROFILE_SLOTS], int64_t launches[DCE_PROFILE_SLOTS], int reset)
+{
+    if (!c) return DCE_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = drain_spans(c);
+    if (rc) return rc;
+    for (int s = 0; s < DCE_PROFILE_SLOTS; ++s) {
+        if (ms) ms[s] = c->prof_ms[s];
+        if (launches) launches[s] = c->prof_n[s];
+        if (reset) { c->prof_ms[s] = 0; c->prof_n[s] = 0; }
+    }
+    return DCE_OK;
+}
+
+int dce_sync(dce_ctx* c)
+{
+    if (!c) return DCE_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DCE_OK;
+}
+
+const char* dce_last_error(dce_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"

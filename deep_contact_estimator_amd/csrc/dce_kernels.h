@@ -1,0 +1,45 @@
+// dce_kernels.h -- launch interface between the C ABI (dce_api.hip) and the gfx950 kernels.
+// Internal to libdce.so; the public boundary is include/dce.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dce {
+
+// ---- geometry of contact_cnn (reference src/contact_cnn.py:8-58) ------------------------
+constexpr int WIN = 150, CH = 54, NCLS = 16, FEAT = 4736, FC1 = 2048, FC2 = 512;
+
+// ---- packed conv weights (built once in dce_finalize_weights) ---------------------------
+// Layer l has CinPad (multiple of 8) input rows and Cout output channels.  The implicit
+// GEMM runs K in the order (channel group of 8, tap, channel); a K-step is 2 channels (MFMA 32x32x2), a group is
+// 4 steps = 8 channels = one float4 per lane.  Element [mtile][g][tap][lane][u] holds
+//   w[cout = 32*mtile + (lane&31)][cin = 8*g + 2*u + (lane>>5)][tap]     (0 if cin >= Cin)
+struct ConvPack {
+    const float* w[4];   // packed weights per layer (device)
+    const float* b[4];   // bias per layer (device), PyTorch order
+};
+size_t conv_pack_floats(int layer);                                  // floats in layer's pack
+void   conv_pack_host(int layer, const float* w_torch, float* out);  // [Cout][Cin][3] -> pack
+
+// Per-device one-time setup (dynamic-LDS grants); call after hipSetDevice.
+hipError_t init_conv_stack();
+hipError_t init_fc_gemm();
+
+// Fused z-score + conv1..conv4 + ReLU + 2x MaxPool for n windows -> feat (n,4736).
+//   zscore != 0: src is a raw (T,54) sequence; window i = rows [first+i, first+i+150)
+//   zscore == 0: src is (n,150,54) pre-normalised windows, window i at src + i*8100
+hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const ConvPack& pk,
+                             float* feat, hipStream_t st);
+
+// z-scored windows only: out (n,150,54) from seq rows [first, first+n+149)
+hipError_t launch_zscore_windows(const float* seq_first_row, int64_t n, float* out, hipStream_t st);
+
+// C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]); fp32 MFMA, N % 128 == 0, K % 32 == 0.
+hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, float* C,
+                          int64_t M, int N, int K, int relu, hipStream_t st);
+
+// logits = h2 * W3^T + b3 ; argmax (first max, NaN-first) ; 4-bit unpack (MSB = leg 0)
+hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,
+                           float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st);
+
+}  // namespace dce

@@ -1,0 +1,244 @@
+// fc_gemm.hip -- the three nn.Linear layers of contact_cnn on gfx950 (MI355X).
+//
+// Replaces what PyTorch dispatches for  src/contact_cnn.py:47-58  (fc.0 + ReLU, fc.3 + ReLU,
+// fc.6; Dropout = identity in eval) and for the loop epilogue  src/inference_one_seq.py:26-27
+// (torch.max(output,1) + decimal2binary, :59-62).
+//
+//  * fc_gemm_kernel: C[M,N] = act(A[M,K] W[N,K]^T + b) on v_mfma_f32_32x32x2_f32 -- exact fp32
+//    (k-ordered fmaf chain, deterministic) at the fp32 peak rate.  128x128x32 block tile,
+//    4 waves as 2x2, each 64x64 (2x2 MFMA tiles, 64 accumulator VGPRs), double-buffered LDS
+//    with register staging (global_load_dwordx4 of tile t+1 issued before the MFMAs of tile t,
+//    ds_write_b128 after), rows padded to 36 floats so the ds_read_b128 fragment reads are
+//    bank-conflict free.  Both operands are K-contiguous (PyTorch's [out][in] layout needs no
+//    repack): a lane reads 4 consecutive k of its row and feeds 4 MFMAs; lanes 0-31 / 32-63
+//    take k-quads 0 / 1 of each 8-wide K slice for A and B alike.
+//  * blockIdx -> tile map is XCD-aware: the 64 blocks co-resident on one XCD (32 CUs x 2) form
+//    an 8x8 (or 16x4) super-tile, so each A row-panel and W column-panel is fetched into that
+//    XCD's L2 once per 8 (4) consumers.
+//  * fc3_tail_kernel: 16 lanes per window, one class each (K=512 sequential fmaf from LDS-resident
+//    W3^T), then argmax with torch.max semantics (first maximum; a NaN wins, first NaN first)
+//    and the 4-bit unpack, MSB = leg 0.
+#include "dce_kernels.h"
+
+namespace dce {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LDK = 36;      // LDK: padded row length in floats
+constexpr int TILE_FLOATS = BM * LDK;                     // one operand tile in LDS
+constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;   // {A,B} x double buffer = 73,728 B
+
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
+__global__ __launch_bounds__(256, 2)
+void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                    const float* __restrict__ bias, float* __restrict__ C,
+                    int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][BM][LDK]
+    float* Bs = smem + 2 * TILE_FLOATS;     // [2][BN][LDK]
+
+    // ---- XCD-aware tile assignment (speed only; any placement is correct)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, li = bid >> 3;
+    const int sid = (li >> 6) * 8 + xcd;                 // super-tile id
+    const int within = li & 63;
+    const int sn = 1 << sn_log2, sm = 64 >> sn_log2;     // super-tile = sm x sn tiles
+    const int nsn = ntiles >> sn_log2;                   // super-tiles along N
+    const int tm = (sid / nsn) * sm + (within >> sn_log2);
+    const int tn = (sid % nsn) * sn + (within & (sn - 1));
+    if (tm >= mtiles) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const int i = lane & 31, h = lane >> 5;
+
+    // staging: thread -> (row = tid/8 + 32*s, k4 = tid%8), s = 0..3, for A and for B
+    const int srow = tid >> 3, sk4 = tid & 7;
+    const float* ag[4];
+    const float* bg[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        int ra = m0 + srow + 32 * s;
+        ra = ra < M ? ra : M - 1;                        // clamp: rows >= M are computed, never stored
+        ag[s] = A + (size_t)ra * K + 4 * sk4;
+        bg[s] = W + (size_t)(n0 + srow + 32 * s) * K + 4 * sk4;
+    }
+    const int sdst = srow * LDK + 4 * sk4;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra4[4], rb4[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        ra4[s] = *reinterpret_cast<const float4*>(ag[s]);
+        rb4[s] = *reinterpret_cast<const float4*>(bg[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        *reinterpret_cast<float4*>(As + sdst + 32 * s * LDK) = ra4[s];
+        *reinterpret_cast<float4*>(Bs + sdst + 32 * s * LDK) = rb4[s];
+    }
+    __syncthreads();
+
+    const int KT = K / BK;
+    const int fa = (wm + i) * LDK + 4 * h;               // this lane's A fragment row, k-quad h
+    const int fb = (wn + i) * LDK + 4 * h;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                ra4[s] = *reinterpret_cast<const float4*>(ag[s] + (size_t)(kt + 1) * BK);
+                rb4[s] = *reinterpret_cast<const float4*>(bg[s] + (size_t)(kt + 1) * BK);
+            }
+        }
+        const float* as = As + cur * TILE_FLOATS + fa;
+        const float* bs = Bs + cur * TILE_FLOATS + fb;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const float4 a0 = *reinterpret_cast<const float4*>(as + 8 * kq);
+            const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * LDK + 8 * kq);
+            const float4 b0 = *reinterpret_cast<const float4*>(bs + 8 * kq);
+            const float4 b1 = *reinterpret_cast<const float4*>(bs + 32 * LDK + 8 * kq);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[u], bv0[u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[u], bv1[u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[u], bv0[u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[u], bv1[u], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < KT) {
+            float* ad = As + (cur ^ 1) * TILE_FLOATS + sdst;
+            float* bd = Bs + (cur ^ 1) * TILE_FLOATS + sdst;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                *reinterpret_cast<float4*>(ad + 32 * s * LDK) = ra4[s];
+                *reinterpret_cast<float4*>(bd + 32 * s * LDK) = rb4[s];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + (ReLU) ; D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = n0 + wn + 32 * b + i;
+        const float bv = bias[col];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[a][b][r] + bv;
+                if (relu) v = relu_nan(v);
+                if (row < M) C[(size_t)row * N + col] = v;
+            }
+        }
+    }
+}
+
+hipError_t init_fc_gemm()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+}
+
+hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, float* C,
+                          int64_t M, int N, int K, int relu, hipStream_t st)
+{
+    if (M <= 0) return hipSuccess;
+    if (N % BN || K % BK || M > (1 << 30)) return hipErrorInvalidValue;
+    const int mtiles = (int)((M + BM - 1) / BM), ntiles = N / BN;
+    int sn_log2 = 3;                                   // super-tile 8 x 8 ...
+    while ((1 << sn_log2) > ntiles) --sn_log2;         // ... or (64/ntiles) x ntiles when N is narrow
+    const int sm = 64 >> sn_log2, nsn = ntiles >> sn_log2;
+    const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
+    const int grid = ((nsuper + 7) / 8) * 8 * 64;
+    hipLaunchKernelGGL(fc_gemm_kernel, dim3(grid), dim3(256), GEMM_LDS_BYTES, st,
+                       A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// fc.6 (512 -> 16) + torch.max(output,1) + decimal2binary
+// ------------------------------------------------------------------------------------------
+constexpr int TAIL_WINDOWS = 16;       // windows per 256-thread block (16 lanes per window)
+
+__global__ __launch_bounds__(256)
+void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
+                     const float* __restrict__ b3, int64_t n, float* __restrict__ logits,
+                     int32_t* __restrict__ pred, uint8_t* __restrict__ contacts)
+{
+    __shared__ float w3t[FC2 * NCLS];                    // [k][class], 32 KB
+    __shared__ float lg[TAIL_WINDOWS][NCLS];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < FC2 * NCLS; e += 256) {
+        const int cls = e / FC2, k = e % FC2;            // coalesced read of W3[cls][k]
+        w3t[k * NCLS + cls] = W3[e];
+    }
+    const int cls = tid & 15, wl = tid >> 4;
+    const float bv = b3[cls];
+    for (int64_t base = (int64_t)blockIdx.x * TAIL_WINDOWS; base < n;
+         base += (int64_t)gridDim.x * TAIL_WINDOWS) {
+        __syncthreads();                                 // w3t ready / lg free again
+        const int64_t win = base + wl;
+        // the 16 lanes of a window read the same h2 row (one broadcast 16-B load per 4 k)
+        const float4* hp = reinterpret_cast<const float4*>(h2 + (win < n ? win : n - 1) * FC2);
+        float acc = 0.f;
+#pragma unroll 4
+        for (int k4 = 0; k4 < FC2 / 4; ++k4) {
+            const float4 hv = hp[k4];
+            const float* wp = w3t + (4 * k4) * NCLS + cls;
+            acc = fmaf(hv.x, wp[0], acc);
+            acc = fmaf(hv.y, wp[NCLS], acc);
+            acc = fmaf(hv.z, wp[2 * NCLS], acc);
+            acc = fmaf(hv.w, wp[3 * NCLS], acc);
+        }
+        acc += bv;
+        lg[wl][cls] = acc;
+        if (win < n && logits) logits[win * NCLS + cls] = acc;
+        __syncthreads();
+        if (tid < TAIL_WINDOWS && base + tid < n) {
+            const float* l = lg[tid];
+            int best = 0;
+            bool nan_seen = false;
+            for (int k = 0; k < NCLS; ++k)               // torch.max: a NaN wins, the first one first
+                if (!nan_seen && l[k] != l[k]) { best = k; nan_seen = true; }
+            if (!nan_seen)
+                for (int k = 1; k < NCLS; ++k)
+                    if (l[k] > l[best]) best = k;        // strict >: ties -> lowest index
+            if (pred) pred[base + tid] = best;
+            if (contacts) {
+                uchar4 c;
+                c.x = (best >> 3) & 1; c.y = (best >> 2) & 1; c.z = (best >> 1) & 1; c.w = best & 1;
+                *reinterpret_cast<uchar4*>(contacts + (base + tid) * 4) = c;
+            }
+        }
+    }
+}
+
+hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,
+                           float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + TAIL_WINDOWS - 1) / TAIL_WINDOWS;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(fc3_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                       h2, W3, b3, n, logits, pred, contacts);
+    return hipGetLastError();
+}
+
+}  // namespace dce

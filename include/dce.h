@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DCE_WINDOW      150   /* config/*.yaml window_size; hard-wired in the model (4736 = 128*37) */
+#define DCE_WINDOW      150   /* window_size in the YAML configs; hard-wired in the model (4736 = 128*37) */
 #define DCE_CHANNELS    54    /* utils/mat2numpy.py:73  q12 qd12 acc3 omega3 p12 v12 */
 #define DCE_CLASSES     16    /* src/contact_cnn.py:56-57 */
 #define DCE_LEGS        4     /* src/inference_one_seq.py:59-62 */

@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports exactly what include/dce.h
+declares; host-side logic that needs no GPU."""
+import os
+import re
+import ctypes as C
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from deep_contact_estimator_amd import build, _lib
+    build.build()                      # hipcc cross-compiles without a GPU
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from deep_contact_estimator_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "dce.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dce_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.dce_abi_version() == 1
+
+
+def test_no_gpu_fails_loudly(lib):
+    """Without a device the product must refuse to run -- never fall back to the CPU."""
+    if lib.dce_device_count() > 0:
+        pytest.skip("GPU present")
+    from deep_contact_estimator_amd import contact_cnn, synth
+    from deep_contact_estimator_amd._lib import DceError
+    ctx = C.c_void_p()
+    assert lib.dce_create(C.byref(ctx), 0, 16) < 0 and not ctx
+    assert b"no CPU fallback" in lib.dce_last_error(None)
+    m = contact_cnn(device=0, max_batch=4).load_state_dict(synth.make_state_dict(1))
+    with pytest.raises(DceError):
+        m(np.zeros((1, 150, 54), np.float32))
+
+
+def test_null_ctx_is_an_error_not_a_crash(lib):
+    assert lib.dce_finalize_weights(None, 0) < 0
+    assert lib.dce_forward_windows(None, None, 0, 0, None, None, None) < 0
+    assert lib.dce_sync(None) < 0
+    lib.dce_destroy(None)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the package may reference it."""
+    pkg = os.path.join(ROOT, "deep_contact_estimator_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower() or f == "__init__.py" and "oracle" not in src, (dirpath, f)
+
+
+def test_synth_is_deterministic_and_shaped():
+    from deep_contact_estimator_amd import synth
+    a, b = synth.make_state_dict(1), synth.make_state_dict(1)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert [k for k, _ in synth.STATE_DICT_SHAPES] == list(a)
+    assert sum(v.size for v in a.values()) == 10_855_440
+    s = synth.make_sequence(200, 0)
+    assert s.shape == (200, 54) and s.dtype == np.float64
+    assert synth.make_labels(10, 0, two_d=True).shape == (10, 1)
+
+
+def test_state_dict_validation_and_decimal2binary():
+    from deep_contact_estimator_amd import contact_cnn, synth
+    from deep_contact_estimator_amd.inference import decimal2binary
+    m = contact_cnn(max_batch=4)
+    sd = synth.make_state_dict(1)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        m.load_state_dict({**sd, "block3.0.weight": np.zeros(3, np.float32)})
+    m.load_state_dict(sd)
+    assert set(m.state_dict()) == set(sd)
+    assert np.array_equal(decimal2binary(np.array([9]))[0], [1, 0, 0, 1])
+    torch = pytest.importorskip("torch")
+    t = decimal2binary(torch.arange(16))
+    assert t.dtype == torch.uint8 and np.array_equal(t.numpy(), decimal2binary(np.arange(16)))
