@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- inference windows/sec of the MI355X contact-estimator path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: BASELINE.json configs[1], i.e. B=4096
+pre-normalised windows (B,150,54) fp32 already resident in HBM -> conv stack -> 3 FC ->
+logits (B,16) + argmax + 4 contact bits, all through the C ABI (dce_forward_windows, device
+pointers, torch's current stream).  With N>1 every rank (one process per GPU) runs its own B
+windows (weak scaling, no data-path collective inside the model) and the (B,16) logits are
+gathered to rank 0 over RCCL each step, asynchronously behind the next step's kernels.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, from HIP events
+recorded on the launch stream inside the timed region (dce_profile_*); `cpu_baseline` is the
+PyTorch-CPU restatement of the reference path (oracle/torch_ref.py, checked against the
+reference's golden vectors) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per window (SURVEY.md 8(d) / BASELINE.md 3): 2*MAC of each layer
+FLOP = {
+    "conv_stack": 3_110_400 + 3_686_400 + 3_686_400 + 7_372_800,   # 17,856,000
+    "fc1_gemm": 2 * 4736 * 2048,                                     # 19,398,656
+    "fc2_gemm": 2 * 2048 * 512,                                      #  2,097,152
+    "fc3_tail": 2 * 512 * 16,                                        #     16,384
+}
+# algorithmic HBM bytes per window per kernel (inputs read once + outputs written once)
+BYTES = {
+    "conv_stack": 150 * 54 * 4 + 4736 * 4,
+    "fc1_gemm": 4736 * 4 + 2048 * 4,
+    "fc2_gemm": 2048 * 4 + 512 * 4,
+    "fc3_tail": 512 * 4 + 16 * 4 + 4 + 4,
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(sd, windows_np, gpu_logits, gpu_pred, budget_s=12.0):
+    """The reference path on the host cores: oracle/torch_ref.forward (the op sequence the
+    reference dispatches on CPU) on a bounded sample of the same windows."""
+    import torch
+    from oracle import torch_ref
+    tsd = torch_ref.to_torch(sd)
+    bs = 512
+    x = torch.from_numpy(windows_np[:bs])
+    # PyTorch's default (one thread per logical CPU) oversubscribes these small convs badly on
+    # a many-core host; give the baseline its best thread count from a short sweep.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    best_t, best_rate = 1, 0.0
+    for nt in sorted({t for t in (8, 16, 32, 64, 128, avail) if t <= avail}):
+        torch.set_num_threads(nt)
+        torch_ref.forward(tsd, x[:64])
+        t0 = time.perf_counter()
+        out = torch_ref.forward(tsd, x)
+        rate = bs / (time.perf_counter() - t0)
+        if rate > best_rate:
+            best_t, best_rate = nt, rate
+    torch.set_num_threads(best_t)
+    out = torch_ref.forward(tsd, x)                     # parity sample
+    t0 = time.perf_counter()
+    done = 0
+    reps = 0
+    while True:
+        i0 = (reps * bs) % max(windows_np.shape[0] - bs + 1, 1)
+        torch_ref.forward(tsd, torch.from_numpy(windows_np[i0:i0 + bs]))
+        done += bs
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 2000:
+            break
+    ref = out.numpy()
+    diff = float(np.abs(ref - gpu_logits[:bs]).max())
+    agree = int((ref.argmax(1) == gpu_pred[:bs]).sum())
+    return {
+        "value": done / el, "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{reps} x {bs}-window batches of the bench input through oracle/torch_ref.forward "
+                  f"(PyTorch {torch.__version__} CPU, model only, {el:.1f} s; best of a thread sweep, "
+                  f"{avail} logical CPUs available)",
+        "gpu_vs_cpu_max_abs_logit_diff": diff, "gpu_vs_cpu_argmax_agree": f"{agree}/{bs}",
+        "max_abs_logit": float(np.abs(ref).max()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from deep_contact_estimator_amd import contact_cnn, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch
+    sd = synth.make_state_dict(1, "uniform")
+    model = contact_cnn(device=local_rank, max_batch=B)
+    model.load_state_dict(sd).eval()
+
+    # synthetic input: a per-rank N(0,1) sequence, z-scored per window by the library
+    # (contact_dataset.__getitem__), materialised as (B,150,54) in HBM before the timed region
+    seq = torch.from_numpy(synth.make_sequence(B + 149, seed=2 + rank).astype(np.float32)).to(dev)
+    windows = model.zscore_windows(seq, 0, B)
+    torch.cuda.synchronize()
+
+    gather_bufs = [None, None]
+    logits_keep = [None, None]
+    handles = [None, None]
+    if world > 1 and rank == 0:
+        gather_bufs = [[torch.empty((B, 16), dtype=torch.float32, device=dev) for _ in range(world)]
+                       for _ in range(2)]
+
+    def step(i):
+        out = model.predict(windows)
+        if world > 1:
+            s = i & 1
+            if handles[s] is not None:
+                handles[s].wait()
+            logits_keep[s] = out["logits"]
+            handles[s] = dist.gather(out["logits"], gather_bufs[s] if rank == 0 else None, dst=0, async_op=True)
+        return out
+
+    def drain():
+        for s in (0, 1):
+            if handles[s] is not None:
+                handles[s].wait()
+                handles[s] = None
+
+    for i in range(args.warmup):
+        out = step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    model.profile(True)
+    model.profile_read(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    prof = model.profile_read(reset=True)
+    model.profile(False)
+
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        wps = world * B * args.steps / elapsed
+        kernels = {}
+        for k, v in prof.items():
+            if v["launches"] == 0:
+                continue
+            avg_ms = v["ms"] / v["launches"]
+            kernels[k] = {
+                "avg_ms": avg_ms, "launches": v["launches"],
+                "tflops": FLOP[k] * B / (avg_ms * 1e-3) / 1e12,
+                "frac_fp32_mfma_peak": FLOP[k] * B / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                "algorithmic_GBs": BYTES[k] * B / (avg_ms * 1e-3) / 1e9,
+            }
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "inference windows/sec (54-ch, win=150)",
+            "value": wps, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: {B} pre-normalised windows (B,150,54) fp32 per GPU per step, "
+                            "HBM-resident -> fused conv stack + fc1/fc2/fc3 -> logits+argmax+contact bits "
+                            "(dce_forward_windows, fp32 MFMA); synthetic He-init checkpoint seed 1",
+                "batch_per_gpu": B, "global_batch": B * world, "window": 150, "channels": 54,
+                "sharding": "independent windows per rank" + ("; async RCCL gather of (B,16) logits to rank 0 per step" if world > 1 else ""),
+            },
+            "roofline": {
+                "kernel": dom, "bound": "mfma",
+                "achieved": kernels[dom]["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": kernels[dom]["frac_fp32_mfma_peak"], "traffic": traffic,
+                "flops_per_launch": FLOP[dom] * B, "avg_launch_ms": kernels[dom]["avg_ms"],
+                "hbm_informational": {"algorithmic_GBs": kernels[dom]["algorithmic_GBs"],
+                                      "frac_of_8TBs": kernels[dom]["algorithmic_GBs"] / PEAK_HBM_GBS},
+            },
+            "kernels": kernels,
+            "path_flops_frac_of_peak": wps / world * sum(FLOP.values()) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd, windows.cpu().numpy(), out["logits"].cpu().numpy(),
+                                               out["pred"].cpu().numpy())
+            res["speedup_vs_cpu_baseline"] = wps / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

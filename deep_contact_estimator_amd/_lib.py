@@ -18,7 +18,7 @@ SYMBOLS = {
     "dce_device_count": (C.c_int, []),
     "dce_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64]),
     "dce_destroy": (None, [C.c_void_p]),
-    "dce_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dce_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "dce_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, _i64p, C.c_int]),
     "dce_finalize_weights": (C.c_int, [C.c_void_p, C.c_int]),
     "dce_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -34,6 +34,32 @@ SYMBOLS = {
 _lib = None
 
 
+def _load_hip_runtime():
+    """Put exactly one HIP runtime into the global symbol scope before libdce.so is opened.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so + libhsa-runtime64.so; device pointers
+    and streams handed over from torch tensors belong to THAT runtime, and a second runtime
+    (e.g. /opt/rocm's) in the same process cannot even open the device.  So: torch's copy when
+    torch is installed, the system ROCm one otherwise."""
+    cands = []
+    try:
+        import torch                                  # noqa: F401  (loads its bundled runtime)
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cands += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so.7", "libamdhip64.so"]
+    last = None
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError as e:                          # try the next candidate
+            last = e
+    raise RuntimeError(f"no HIP runtime (libamdhip64) could be loaded: {last}")
+
+
 def load():
     """dlopen libdce.so and bind every declared symbol.  Raises if it has not been built."""
     global _lib
@@ -43,6 +69,7 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m deep_contact_estimator_amd.build` "
             "(there is no CPU fallback for the inference path)")
+    _load_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it

@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdce.so")
 SOURCES = ["conv_stack.hip", "fc_gemm.hip", "dce_api.hip"]
 HEADERS = ["dce_kernels.h", os.path.join("..", "..", "include", "dce.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+OBJDIR = os.path.join(HERE, "build")
 
 
 def _hipcc() -> str:
@@ -36,15 +37,33 @@ def stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc -c each translation unit for gfx950, then link WITHOUT naming a HIP runtime:
+    libdce.so leaves hip* undefined so that it binds to the ONE runtime already in the process
+    (PyTorch wheels bundle their own libamdhip64/libhsa-runtime64; a second copy from
+    /opt/rocm in the same process cannot open the device).  _lib.load() puts the right runtime
+    in the global symbol scope first."""
     if not force and not stale():
         return LIB
-    cmd = [_hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    procs = []
+    for s in SOURCES:
+        obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        cmd = [hipcc, *CFLAGS, "-c", os.path.join(CSRC, s), "-o", obj]
+        procs.append((cmd, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    objs = []
+    for cmd, obj, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
+        if verbose and out:
+            print(out, file=sys.stderr)
+        objs.append(obj)
+    link = [shutil.which("g++") or "g++", "-shared", "-fPIC", *objs, "-o", LIB + ".tmp"]
+    r = subprocess.run(link, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError("link failed:\n" + " ".join(link) + "\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
-    if verbose:
-        print(r.stderr, file=sys.stderr)
     return LIB
 
 

@@ -163,7 +163,7 @@ class contact_cnn:
             if "pred" in want: out["pred"] = torch.empty((n,), dtype=torch.int32, device=x.device)
             if "contacts" in want: out["contacts"] = torch.empty((n, 4), dtype=torch.uint8, device=x.device)
             ptr = lambda k: C.c_void_p(out[k].data_ptr()) if k in out and n > 0 else None
-            _lib.check(lib.dce_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), ctx)
+            _lib.check(lib.dce_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), 0), ctx)
             if raw_sequence:
                 rc = lib.dce_infer_sequence(ctx, C.c_void_p(x.data_ptr()), x.shape[0], WINDOW, 1,
                                             ptr("logits"), ptr("pred"), ptr("contacts"))
@@ -182,7 +182,7 @@ class contact_cnn:
         if "pred" in want: out["pred"] = np.empty((n,), np.int32)
         if "contacts" in want: out["contacts"] = np.empty((n, 4), np.uint8)
         ptr = lambda k: out[k].ctypes.data_as(C.c_void_p) if k in out and n > 0 else None
-        _lib.check(lib.dce_set_stream(ctx, None), ctx)
+        _lib.check(lib.dce_set_stream(ctx, None, 1), ctx)
         if raw_sequence:
             rc = lib.dce_infer_sequence(ctx, a.ctypes.data_as(C.c_void_p), a.shape[0], WINDOW, 0,
                                         ptr("logits"), ptr("pred"), ptr("contacts"))
@@ -230,7 +230,7 @@ class contact_cnn:
         out = {"feat": np.empty((n, 4736), np.float32), "h1": np.empty((n, 2048), np.float32),
                "h2": np.empty((n, 512), np.float32), "logits": np.empty((n, CLASSES), np.float32)}
         p = lambda k: out[k].ctypes.data_as(C.c_void_p)
-        _lib.check(self._lib.dce_set_stream(self._ctx, None), self._ctx)
+        _lib.check(self._lib.dce_set_stream(self._ctx, None, 1), self._ctx)
         _lib.check(self._lib.dce_forward_taps(self._ctx, a.ctypes.data_as(C.c_void_p), n, 0,
                                               p("feat"), p("h1"), p("h2"), p("logits")), self._ctx)
         return out
@@ -245,13 +245,13 @@ class contact_cnn:
             import torch
             seq = seq.contiguous()
             out = torch.empty((n, WINDOW, CHANNELS), dtype=torch.float32, device=seq.device)
-            _lib.check(self._lib.dce_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(seq.device).cuda_stream)), ctx)
+            _lib.check(self._lib.dce_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(seq.device).cuda_stream), 0), ctx)
             _lib.check(self._lib.dce_zscore_windows(ctx, C.c_void_p(seq.data_ptr()), T, first, n, 1,
                                                     C.c_void_p(out.data_ptr()) if n > 0 else None), ctx)
             return out
         a = np.ascontiguousarray(seq.numpy() if _is_torch(seq) else np.asarray(seq), dtype=np.float32)
         out = np.empty((n, WINDOW, CHANNELS), np.float32)
-        _lib.check(self._lib.dce_set_stream(ctx, None), ctx)
+        _lib.check(self._lib.dce_set_stream(ctx, None, 1), ctx)
         _lib.check(self._lib.dce_zscore_windows(ctx, a.ctypes.data_as(C.c_void_p), T, first, n, 0,
                                                 out.ctypes.data_as(C.c_void_p)), ctx)
         return out

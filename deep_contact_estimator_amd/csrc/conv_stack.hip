@@ -40,6 +40,7 @@ constexpr int S2  = 155;
 constexpr int ACT_FLOATS = 128 * S2 + 16;             // 19,856 floats = 79,424 B (>= 64*S1+16)
 constexpr int NT  = 5;            // 32-column tiles per wave (stage 1: 10 tiles / 2, stage 2: 5)
 constexpr int RED_ROW = 56;       // stage-1 rows 56.. are free until conv1 writes back
+static_assert((RED_ROW * S1) % 2 == 0 && NW * 4 * 216 <= 8 * S1, "fp64 reduction scratch fits rows 56..63, 8-B aligned");
 static_assert(64 * S1 + 16 <= ACT_FLOATS, "stage-1 image must fit");
 static_assert(ACT_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
 
@@ -189,8 +190,13 @@ __device__ __forceinline__ void store_pool_feat(float* __restrict__ feat, int64_
 }
 
 // Load NWIN windows (rows t = 4m + g of channel c per thread, tid = g*54 + c < 216) and, if ZS,
-// z-score them per channel over time: mean = sum/150, std = sqrt(sum((x-mean)^2)/149), no eps
-// (utils/data_handler.py:55-56).  red: >= NWIN*2*216 floats of LDS scratch.
+// z-score them per channel over time exactly as utils/data_handler.py:55-56 does on fp32 data:
+//   (x - mean) / std,  mean = sum/150 rounded to fp32,  std = sqrt(sum((x-mean)^2)/149) (unbiased,
+//   no epsilon) rounded to fp32.
+// Both reductions run in fp64 (full-rate on CDNA4, ~300 ops per thread): with sensor offsets
+// of O(1-10) and spreads of O(0.01) one fp32 ulp of the mean is already 5e-5 standard
+// deviations, so the mean must be the correctly rounded one, not an fp32 running sum.
+// red: >= NWIN*4*216 floats of LDS scratch (two sets of 216 doubles per window).
 template <bool ZS, int NWIN>
 __device__ __forceinline__ void load_windows(const float* __restrict__ src, int64_t win_stride,
                                              int nvalid, float* __restrict__ red,
@@ -206,35 +212,36 @@ __device__ __forceinline__ void load_windows(const float* __restrict__ src, int6
             x[w][m] = (loader && t < WIN && w < nvalid) ? src[w * win_stride + t * CH + c] : 0.f;
         }
     if (ZS) {
+        double* dred = reinterpret_cast<double*>(red);
 #pragma unroll
         for (int w = 0; w < NWIN; ++w) {
-            float s = 0.f;
+            double s = 0.0;
 #pragma unroll
-            for (int m = 0; m < 38; ++m) s += x[w][m];
-            if (loader) red[w * 216 + tid] = s;
+            for (int m = 0; m < 38; ++m) s += (double)x[w][m];       // rows t >= 150 were loaded as 0
+            if (loader) dred[w * 216 + tid] = s;
         }
         __syncthreads();
         float mean[NWIN];
 #pragma unroll
         for (int w = 0; w < NWIN; ++w) {
-            const float* r = red + w * 216 + c;
-            mean[w] = loader ? ((r[0] + r[54]) + (r[108] + r[162])) / 150.f : 0.f;
-            float q = 0.f;
+            const double* r = dred + w * 216 + c;
+            const double mu = loader ? ((r[0] + r[54]) + (r[108] + r[162])) / 150.0 : 0.0;
+            mean[w] = (float)mu;
+            double q = 0.0;
 #pragma unroll
             for (int m = 0; m < 38; ++m) {
-                const float d = x[w][m] - mean[w];
-                x[w][m] = d;
-                q += (4 * m + g < WIN) ? d * d : 0.f;
+                const double d = (double)x[w][m] - mu;
+                q += (4 * m + g < WIN) ? d * d : 0.0;
             }
-            if (loader) red[(NWIN + w) * 216 + tid] = q;
+            if (loader) dred[(NWIN + w) * 216 + tid] = q;
         }
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < NWIN; ++w) {
-            const float* r = red + (NWIN + w) * 216 + c;
-            const float sd = loader ? sqrtf(((r[0] + r[54]) + (r[108] + r[162])) / 149.f) : 1.f;
+            const double* r = dred + (NWIN + w) * 216 + c;
+            const float sd = loader ? (float)sqrt(((r[0] + r[54]) + (r[108] + r[162])) / 149.0) : 1.f;
 #pragma unroll
-            for (int m = 0; m < 38; ++m) x[w][m] = (w < nvalid) ? x[w][m] / sd : 0.f;
+            for (int m = 0; m < 38; ++m) x[w][m] = (w < nvalid) ? (x[w][m] - mean[w]) / sd : 0.f;
         }
     }
 }
@@ -344,7 +351,7 @@ hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const Conv
 __global__ __launch_bounds__(256)
 void zscore_windows_kernel(const float* __restrict__ seq, int64_t n, float* __restrict__ out)
 {
-    __shared__ float red[2 * 216];
+    __shared__ __attribute__((aligned(16))) float red[4 * 216];
     const int tid = threadIdx.x;
     const int64_t i = blockIdx.x;
     float x[1][38];

@@ -36,6 +36,7 @@ struct dce_ctx {
     int64_t max_batch = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t xstream_ev = nullptr;
     std::string err;
 
     std::vector<float> host_w[14];         // staged state_dict (host, PyTorch layout)
@@ -242,16 +243,26 @@ void dce_destroy(dce_ctx* c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->xstream_ev) hipEventDestroy(c->xstream_ev);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2);
     hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
 
-int dce_set_stream(dce_ctx* c, void* hip_stream)
+int dce_set_stream(dce_ctx* c, void* hip_stream, int use_own)
 {
     if (!c) return DCE_ERR_ARG;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    hipStream_t next = use_own ? c->own_stream : (hipStream_t)hip_stream;
+    if (next != c->stream) {
+        // the scratch buffers are shared by every call on this ctx: work queued on the new
+        // stream must not overtake what is still in flight on the old one
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (!c->xstream_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->xstream_ev, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->xstream_ev, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(next, c->xstream_ev, 0));
+        c->stream = next;
+    }
     return DCE_OK;
 }
 

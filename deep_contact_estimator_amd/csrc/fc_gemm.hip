@@ -24,20 +24,29 @@ namespace dce {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDK = 36;      // LDK: padded row length in floats
-constexpr int TILE_FLOATS = BM * LDK;                     // one operand tile in LDS
-constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;   // {A,B} x double buffer = 73,728 B
+constexpr int BK = 32, LDK = 36;          // K-tile; LDK = padded LDS row length in floats
 
 __device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
 
+template <int TM, int TN> struct GemmCfg {
+    static constexpr int BM = 64 * TM, BN = 64 * TN;              // block tile (2x2 waves)
+    static constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK;
+    static constexpr int LDS_BYTES = 2 * (A_FLOATS + B_FLOATS) * 4;
+};
+
+// TM x TN MFMA 32x32 tiles per wave; block = 2x2 waves = (64 TM) x (64 TN) outputs.
+template <int TM, int TN>
 __global__ __launch_bounds__(256, 2)
 void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
                     const float* __restrict__ bias, float* __restrict__ C,
                     int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
 {
+    using Cfg = GemmCfg<TM, TN>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN;
+    constexpr int SA = BM / 32, SB = BN / 32;            // float4 staged per thread per K-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BM][LDK]
-    float* Bs = smem + 2 * TILE_FLOATS;     // [2][BN][LDK]
+    float* As = smem;                                    // [2][BM][LDK]
+    float* Bs = smem + 2 * Cfg::A_FLOATS;                // [2][BN][LDK]
 
     // ---- XCD-aware tile assignment (speed only; any placement is correct)
     const int bid = blockIdx.x;
@@ -53,41 +62,40 @@ void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    const int wm = (wv >> 1) * 32 * TM, wn = (wv & 1) * 32 * TN;
     const int i = lane & 31, h = lane >> 5;
 
-    // staging: thread -> (row = tid/8 + 32*s, k4 = tid%8), s = 0..3, for A and for B
+    // staging: thread -> (row = tid/8 + 32*s, 16-byte column tid%8)
     const int srow = tid >> 3, sk4 = tid & 7;
-    const float* ag[4];
-    const float* bg[4];
+    const float* ag[SA];
+    const float* bg[SB];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < SA; ++s) {
         int ra = m0 + srow + 32 * s;
         ra = ra < M ? ra : M - 1;                        // clamp: rows >= M are computed, never stored
         ag[s] = A + (size_t)ra * K + 4 * sk4;
-        bg[s] = W + (size_t)(n0 + srow + 32 * s) * K + 4 * sk4;
     }
+#pragma unroll
+    for (int s = 0; s < SB; ++s) bg[s] = W + (size_t)(n0 + srow + 32 * s) * K + 4 * sk4;
     const int sdst = srow * LDK + 4 * sk4;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra4[4], rb4[4];
+    float4 ra4[SA], rb4[SB];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        ra4[s] = *reinterpret_cast<const float4*>(ag[s]);
-        rb4[s] = *reinterpret_cast<const float4*>(bg[s]);
-    }
+    for (int s = 0; s < SA; ++s) ra4[s] = *reinterpret_cast<const float4*>(ag[s]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        *reinterpret_cast<float4*>(As + sdst + 32 * s * LDK) = ra4[s];
-        *reinterpret_cast<float4*>(Bs + sdst + 32 * s * LDK) = rb4[s];
-    }
+    for (int s = 0; s < SB; ++s) rb4[s] = *reinterpret_cast<const float4*>(bg[s]);
+#pragma unroll
+    for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(As + sdst + 32 * s * LDK) = ra4[s];
+#pragma unroll
+    for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(Bs + sdst + 32 * s * LDK) = rb4[s];
     __syncthreads();
 
     const int KT = K / BK;
@@ -95,50 +103,50 @@ void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
     const int fb = (wn + i) * LDK + 4 * h;
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) {
+        // prefetch the next K-tile into registers (the last iteration re-reads its own tile:
+        // unconditional loads keep the staging registers out of scratch and the loop branch-free)
+        const size_t koff = (size_t)(kt + 1 < KT ? kt + 1 : kt) * BK;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                ra4[s] = *reinterpret_cast<const float4*>(ag[s] + (size_t)(kt + 1) * BK);
-                rb4[s] = *reinterpret_cast<const float4*>(bg[s] + (size_t)(kt + 1) * BK);
-            }
-        }
-        const float* as = As + cur * TILE_FLOATS + fa;
-        const float* bs = Bs + cur * TILE_FLOATS + fb;
+        for (int s = 0; s < SA; ++s) ra4[s] = *reinterpret_cast<const float4*>(ag[s] + koff);
+#pragma unroll
+        for (int s = 0; s < SB; ++s) rb4[s] = *reinterpret_cast<const float4*>(bg[s] + koff);
+
+        const float* as = As + cur * Cfg::A_FLOATS + fa;
+        const float* bs = Bs + cur * Cfg::B_FLOATS + fb;
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
-            const float4 a0 = *reinterpret_cast<const float4*>(as + 8 * kq);
-            const float4 a1 = *reinterpret_cast<const float4*>(as + 32 * LDK + 8 * kq);
-            const float4 b0 = *reinterpret_cast<const float4*>(bs + 8 * kq);
-            const float4 b1 = *reinterpret_cast<const float4*>(bs + 32 * LDK + 8 * kq);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+            float4 af[TM], bf[TN];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[u], bv0[u], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[u], bv1[u], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[u], bv0[u], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[u], bv1[u], acc[1][1], 0, 0, 0);
-            }
-        }
-        if (kt + 1 < KT) {
-            float* ad = As + (cur ^ 1) * TILE_FLOATS + sdst;
-            float* bd = Bs + (cur ^ 1) * TILE_FLOATS + sdst;
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(as + 32 * a * LDK + 8 * kq);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                *reinterpret_cast<float4*>(ad + 32 * s * LDK) = ra4[s];
-                *reinterpret_cast<float4*>(bd + 32 * s * LDK) = rb4[s];
-            }
+            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(bs + 32 * b * LDK + 8 * kq);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const float av = u == 0 ? af[a].x : u == 1 ? af[a].y : u == 2 ? af[a].z : af[a].w;
+                        const float bv = u == 0 ? bf[b].x : u == 1 ? bf[b].y : u == 2 ? bf[b].z : bf[b].w;
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                    }
         }
+        float* ad = As + (cur ^ 1) * Cfg::A_FLOATS + sdst;
+        float* bd = Bs + (cur ^ 1) * Cfg::B_FLOATS + sdst;
+#pragma unroll
+        for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(ad + 32 * s * LDK) = ra4[s];
+#pragma unroll
+        for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(bd + 32 * s * LDK) = rb4[s];
         __syncthreads();
     }
 
     // ---- epilogue: bias + (ReLU) ; D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < TN; ++b) {
         const int col = n0 + wn + 32 * b + i;
         const float bv = bias[col];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < TM; ++a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -152,24 +160,38 @@ void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
 
 hipError_t init_fc_gemm()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel<2, 2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<2, 2>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel<1, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<1, 1>::LDS_BYTES);
+}
+
+template <int TM, int TN>
+static hipError_t launch_gemm_cfg(const float* A, const float* W, const float* bias, float* C,
+                                  int64_t M, int N, int K, int relu, hipStream_t st)
+{
+    using Cfg = GemmCfg<TM, TN>;
+    const int mtiles = (int)((M + Cfg::BM - 1) / Cfg::BM), ntiles = N / Cfg::BN;
+    int sn_log2 = 3;                                   // super-tile 8 x 8 ...
+    while ((1 << sn_log2) > ntiles) --sn_log2;         // ... or (64/ntiles) x ntiles when N is narrow
+    const int sm = 64 >> sn_log2, nsn = ntiles >> sn_log2;
+    const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
+    const int grid = ((nsuper + 7) / 8) * 8 * 64;
+    hipLaunchKernelGGL((fc_gemm_kernel<TM, TN>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st,
+                       A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+    return hipGetLastError();
 }
 
 hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, float* C,
                           int64_t M, int N, int K, int relu, hipStream_t st)
 {
     if (M <= 0) return hipSuccess;
-    if (N % BN || K % BK || M > (1 << 30)) return hipErrorInvalidValue;
-    const int mtiles = (int)((M + BM - 1) / BM), ntiles = N / BN;
-    int sn_log2 = 3;                                   // super-tile 8 x 8 ...
-    while ((1 << sn_log2) > ntiles) --sn_log2;         // ... or (64/ntiles) x ntiles when N is narrow
-    const int sm = 64 >> sn_log2, nsn = ntiles >> sn_log2;
-    const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
-    const int grid = ((nsuper + 7) / 8) * 8 * 64;
-    hipLaunchKernelGGL(fc_gemm_kernel, dim3(grid), dim3(256), GEMM_LDS_BYTES, st,
-                       A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
-    return hipGetLastError();
+    if (N % 128 || K % BK || M > (1 << 30)) return hipErrorInvalidValue;
+    // 128x128 tiles when they alone fill the chip (512 resident blocks), else 64x64
+    const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
+    if (big_blocks >= 384) return launch_gemm_cfg<2, 2>(A, W, bias, C, M, N, K, relu, st);
+    return launch_gemm_cfg<1, 1>(A, W, bias, C, M, N, K, relu, st);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -72,8 +72,10 @@ int  dce_create(dce_ctx** out, int device_id, int64_t max_batch);
 void dce_destroy(dce_ctx* ctx);
 
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the
- * ctx-owned one.  stream == NULL restores the ctx-owned stream. */
-int  dce_set_stream(dce_ctx* ctx, void* hip_stream);
+ * ctx-owned one.  use_own != 0 restores the ctx-owned (non-blocking) stream and ignores
+ * hip_stream; otherwise hip_stream is used as given -- NULL means HIP's null stream, which
+ * is what torch.cuda.current_stream().cuda_stream is for torch's default stream. */
+int  dce_set_stream(dce_ctx* ctx, void* hip_stream, int use_own);
 
 /* load_state_dict: one call per state_dict key of contact_cnn (src/contact_cnn.py:8-58):
  *   block1.0.weight (64,54,3)   block1.0.bias (64)    block1.2.weight (64,64,3)    block1.2.bias (64)
