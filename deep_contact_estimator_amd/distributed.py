@@ -1,0 +1,68 @@
+"""Sharding the sliding windows of one sequence over the GPUs of a node.
+
+Windows are independent (no BatchNorm, Dropout off in eval: reference utils/data_handler.py:55-57
+uses only rows [i, i+150)), so rank g of G takes a contiguous range of windows and therefore the
+sequence rows of that range plus a 149-row halo; weights are replicated.  There is no collective
+inside the model.  The one exchange the path has is collecting the results: an RCCL gather of the
+(n_g,16) fp32 logits (and the (n_g,4) u8 contacts) to rank 0 -- point-to-point over xGMI, each
+peer on its own link.  One process per GPU; ``torch.distributed`` backend "nccl" (= RCCL) on the
+GPUs, "gloo" in the CPU tests of this logic.
+"""
+from __future__ import annotations
+
+WINDOW = 150
+
+
+def shard_range(n_windows: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, balanced window range [lo, hi) of `rank` (first n%world ranks get one extra)."""
+    if n_windows <= 0:
+        return 0, 0
+    base, extra = divmod(n_windows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_rows(T: int, rank: int, world: int) -> tuple[int, int, int, int]:
+    """-> (row_lo, row_hi, win_lo, win_hi): rows [row_lo,row_hi) of the (T,54) sequence hold
+    exactly the windows [win_lo,win_hi) of this rank (149-row halo included)."""
+    lo, hi = shard_range(T - WINDOW + 1, rank, world)
+    if hi <= lo:
+        return 0, 0, lo, hi
+    return lo, hi + WINDOW - 1, lo, hi
+
+
+def gather_rows(t, group=None, dst: int = 0):
+    """Gather per-rank row blocks of unequal length to `dst`, concatenated in rank order.
+    One size exchange (all_gather of a scalar) + one gather of the padded blocks."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    nmax = max(sizes)
+    pad = t
+    if t.shape[0] < nmax:
+        pad = torch.cat([t, t.new_zeros((nmax - t.shape[0],) + tuple(t.shape[1:]))], 0)
+    pad = pad.contiguous()
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+
+
+def infer_sequence_sharded(run, seq, group=None, dst: int = 0):
+    """Run `run(seq_rows) -> {'logits','pred','contacts'}` (e.g. contact_cnn.infer_sequence) on
+    this rank's shard of `seq` ((T,54), identical on every rank or at least valid on its own row
+    range) and gather the results to rank `dst` in window order.  Returns the full dict on `dst`,
+    None elsewhere."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    r0, r1, _, _ = shard_rows(seq.shape[0], rank, world)
+    out = run(seq[r0:r1])
+    res = {k: gather_rows(v, group, dst) for k, v in out.items()}
+    return res if rank == dst else None

@@ -1,0 +1,70 @@
+"""Entry script mirroring the reference's src/inference_one_seq.py:137-179.
+
+    python -m deep_contact_estimator_amd.inference_one_seq --config_name config/inference_one_seq_params.yaml
+
+Reads the same YAML keys (data_path, label_path, model_load_path, window_size, batch_size,
+calculate_accuracy, save_mat, mat_save_path, save_lcm, lcm_save_path), builds
+contact_dataset / loader / contact_cnn the same way and prints the same accuracy lines.
+``--fused`` runs the whole sequence through one dce_infer_sequence call instead of the
+per-batch loop (identical results).  .mat / LCM export is out of scope: with
+save_mat the (N,4) estimates go to <mat_save_path minus .mat>.npy; save_lcm is reported and skipped.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import yaml
+
+from .contact_cnn import contact_cnn, load_checkpoint
+from .data_handler import contact_dataset, WindowLoader
+from .inference import inference, inference_and_compute_acc, inference_sequence
+
+
+def main(argv=None):
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("deep_contact_estimator_amd needs an MI355X (no CPU path)")
+    device = torch.device("cuda")
+    print("Using ", device)
+
+    parser = argparse.ArgumentParser(description="Run the contact network on one sequence")
+    parser.add_argument("--config_name", type=str,
+                        default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "config",
+                                             "inference_one_seq_params.yaml"))
+    parser.add_argument("--fused", action="store_true", help="one fused pass instead of the batch loop")
+    args = parser.parse_args(argv)
+    config = yaml.safe_load(open(args.config_name))
+
+    dataset = contact_dataset(data_path=config["data_path"], label_path=config["label_path"],
+                              window_size=config["window_size"], device=device)
+    dataloader = WindowLoader(dataset, batch_size=config["batch_size"])
+
+    model = contact_cnn(max_batch=max(int(config["batch_size"]), 8192))
+    model.load_state_dict(load_checkpoint(config["model_load_path"]))
+    model = model.eval().to(device)
+
+    if config["calculate_accuracy"]:
+        pred, acc, acc_per_leg = inference_and_compute_acc(dataloader, model, device)
+        print("Accuracy in terms of class: %.4f" % acc)
+        for leg in range(4):
+            print("Accuracy of leg %d is: %.4f" % (leg, acc_per_leg[leg]))
+        print("Accuracy is: %.4f" % (np.sum(acc_per_leg) / 4.0))
+    elif args.fused:
+        pred = inference_sequence(dataset, model)
+    else:
+        pred = inference(dataloader, model, device)
+
+    if config.get("save_mat"):
+        out = os.path.splitext(config["mat_save_path"])[0] + ".npy"
+        np.save(out, pred.cpu().numpy())
+        print("Saved contact estimates to", out, "(.mat export is out of scope)")
+    if config.get("save_lcm"):
+        print("save_lcm requested: LCM export is out of scope here, skipped")
+    return pred
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""Entry script mirroring the hot-path part of the reference's src/test.py:113-147.
+
+    python -m deep_contact_estimator_amd.test --config_name config/test_params.yaml
+
+Same YAML keys (data_folder, model_load_path, window_size, batch_size); runs compute_accuracy
+over <data_folder>/test.npy + test_label.npy and prints the accuracy block.  The sklearn
+precision / Jaccard / confusion-matrix post-processing (src/test.py:19-70,137-220) is CPU
+analysis on the returned arrays and out of scope; the arrays are returned unchanged so the
+reference's own functions can consume them.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import yaml
+
+from .contact_cnn import contact_cnn, load_checkpoint
+from .data_handler import contact_dataset, WindowLoader
+from .inference import compute_accuracy
+
+
+def main(argv=None):
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("deep_contact_estimator_amd needs an MI355X (no CPU path)")
+    device = torch.device("cuda")
+    print("Using ", device)
+    parser = argparse.ArgumentParser(description="Test the contact network")
+    parser.add_argument("--config_name", type=str,
+                        default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "config",
+                                             "test_params.yaml"))
+    args = parser.parse_args(argv)
+    config = yaml.safe_load(open(args.config_name))
+
+    test_data = contact_dataset(data_path=config["data_folder"] + "test.npy",
+                                label_path=config["data_folder"] + "test_label.npy",
+                                window_size=config["window_size"], device=device)
+    test_dataloader = WindowLoader(test_data, batch_size=config["batch_size"])
+    model = contact_cnn(max_batch=max(int(config["batch_size"]), 8192))
+    model.load_state_dict(load_checkpoint(config["model_load_path"]))
+    model = model.eval().to(device)
+
+    test_acc, acc_per_leg, bin_pred_arr, bin_gt_arr, pred_arr, gt_arr = compute_accuracy(test_dataloader, model)
+    print("Test accuracy in terms of class is: %.4f" % test_acc)
+    for leg in range(4):
+        print("Accuracy of leg %d is: %.4f" % (leg, acc_per_leg[leg]))
+    print("Accuracy is: %.4f" % (np.sum(acc_per_leg) / 4.0))
+    return test_acc, acc_per_leg, bin_pred_arr, bin_gt_arr, pred_arr, gt_arr
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel-trace stats + PMC passes for the bench workload.
+# Usage: tools/profile_gpu.sh <tag>      outputs under gpurun_out/<tag>_*
+set -u
+TAG=${1:-r1}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out
+B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o ${TAG} -- $B > $OUT/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- $B > $OUT/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- $B > $OUT/${TAG}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/${TAG}_pmc_sq -o ${TAG} -- $B > $OUT/${TAG}_pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_lds -o ${TAG} -- $B > $OUT/${TAG}_pmc_lds.log 2>&1
+find $OUT -name "${TAG}*" -type f | head -40
+for f in $OUT/${TAG}_*.log; do echo "== $f"; grep -E '"metric"|rror' $f | cut -c1-300; done
