@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdce.so")
+LIB_PATH = os.environ.get("DCE_LIB") or os.path.join(_HERE, "libdce.so")   # DCE_LIB: A/B builds
 
 # every symbol include/dce.h declares: (name, restype, argtypes)
 _i64p = C.POINTER(C.c_int64)

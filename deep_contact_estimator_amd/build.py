@@ -36,6 +36,21 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, defines: list[str]) -> str:
+    """Experimental A/B build: libdce_<name>.so with extra -D flags (select with DCE_LIB=...)."""
+    out = os.path.join(HERE, f"libdce_{name}.so")
+    hipcc = _hipcc()
+    od = os.path.join(OBJDIR, name)
+    os.makedirs(od, exist_ok=True)
+    objs = []
+    for s in SOURCES:
+        obj = os.path.join(od, s.replace(".hip", ".o"))
+        subprocess.run([hipcc, *CFLAGS, *defines, "-c", os.path.join(CSRC, s), "-o", obj], check=True)
+        objs.append(obj)
+    subprocess.run([shutil.which("g++") or "g++", "-shared", "-fPIC", *objs, "-o", out], check=True)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc -c each translation unit for gfx950, then link WITHOUT naming a HIP runtime:
     libdce.so leaves hip* undefined so that it binds to the ONE runtime already in the process

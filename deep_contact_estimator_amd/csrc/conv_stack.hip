@@ -29,6 +29,7 @@
 // t = 0 sits on an even column in both, so pooling pairs (2j,2j+1) are lanes (2m,2m+1), and
 // pooling maps stage 1 to stage 2 by q = p/2 + 1 for both windows and for the pads alike.
 #include "dce_kernels.h"
+#include <cstdlib>
 
 namespace dce {
 
@@ -42,7 +43,26 @@ constexpr int NT  = 5;            // 32-column tiles per wave (stage 1: 10 tiles
 constexpr int RED_ROW = 56;       // stage-1 rows 56.. are free until conv1 writes back
 static_assert((RED_ROW * S1) % 2 == 0 && NW * 4 * 216 <= 8 * S1, "fp64 reduction scratch fits rows 56..63, 8-B aligned");
 static_assert(64 * S1 + 16 <= ACT_FLOATS, "stage-1 image must fit");
-static_assert(ACT_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+constexpr int LDS_FLOATS = ACT_FLOATS + 384;          // + the four bias vectors
+static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+#ifndef DCE_STAGGER
+#define DCE_STAGGER 0
+#endif
+#ifndef DCE_TRACE
+#define DCE_TRACE 0
+#endif
+#ifndef DCE_SLOT_PRIO
+#define DCE_SLOT_PRIO 0      // measured: s_setprio by wave slot makes the kernel 11 % SLOWER (r1 notes)
+#endif
+#if DCE_TRACE
+// debug build only (python -m ... build_variant('trace', ['-DDCE_TRACE=1'])): per-block phase
+// timestamps (s_memtime) + HW_ID, read back with dce_debug_trace_read().
+__device__ unsigned long long g_trace[4096 * 16];
+#define TRACE_MARK(k) do { if (tid == 0 && blockIdx.x < 4096) \
+        g_trace[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE_MARK(k) do {} while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Host-side weight packing
@@ -81,35 +101,89 @@ __device__ __forceinline__ float swap_adjacent(float v)
 // Implicit-GEMM main loop of one conv layer for one wave: 5 column tiles x one 32-row tile.
 //   bsrc = act + (lane>>5)*S + (lane&31) + 32*first_tile       (this lane's B element, tap 0, cin pair 0)
 //   ap   = packed weights of this wave's row tile, + lane
-template <int CINP, int S>
-__device__ __forceinline__ void conv_mfma(const float* __restrict__ bsrc,
-                                          const float4* __restrict__ ap, f32x16 (&acc)[NT])
+//   a0   = weights of channel group 0 (3 taps), loaded by the caller BEFORE the barrier that
+//          precedes this layer, so their L2 latency hides under the previous layer's write-back.
+// Weights of group g+1 are fetched while group g's 60 MFMAs run (register double buffer).
+struct A3 { float4 t0, t1, t2; };                      // one channel group's weights, 3 taps
+__device__ __forceinline__ A3 load_a(const float4* __restrict__ ap, int g)
 {
-    constexpr int G = CINP / 8;
-#pragma unroll 1
-    for (int g = 0; g < G; ++g) {
-        const float* bp = bsrc + g * 8 * S;
+    A3 a;
+    a.t0 = ap[(g * 3 + 0) * 64]; a.t1 = ap[(g * 3 + 1) * 64]; a.t2 = ap[(g * 3 + 2) * 64];
+    return a;
+}
+
+// B operand of one (channel group, tap) stage: 4 K-steps x 5 column tiles = 20 values per lane.
+template <int S>
+__device__ __forceinline__ void load_b(const float* __restrict__ bp, int tap, float (&b)[4 * NT])
+{
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            const float4 a4 = ap[(g * 3 + tap) * 64];
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+        for (int t = 0; t < NT; ++t) b[u * NT + t] = bp[2 * u * S + 32 * t + tap];
+}
+
+__device__ __forceinline__ void mfma_stage(const float4 a4, const float (&b)[4 * NT], f32x16 (&acc)[NT])
+{
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bp[2 * u * S + 32 * t + tap],
-                                                                  acc[t], 0, 0, 0);
-            }
-        }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b[u * NT + t], acc[t], 0, 0, 0);
+}
+
+// ask the scheduler for a 1:1 MFMA / LDS-read interleave over one stage (20 MFMAs)
+__device__ __forceinline__ void interleave_stage()
+{
+#pragma unroll
+    for (int i = 0; i < 4 * NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
     }
 }
 
-__device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, int m0, int h,
-                                              f32x16 (&acc)[NT])
+// Software-pipelined main loop.  A stage = (8-channel group g, tap) = 20 MFMAs.  Three B
+// register sets (one per tap) rotate so that every LDS read is issued a full stage (1280 MFMA
+// cycles) before its first use:
+//     MFMA tap0(g) || read B2(g)      MFMA tap1(g) || read B0(g+1)      MFMA tap2(g) || read B1(g+1)
+// Weights of group g+1 (A operand, L2) are fetched during group g as well.
+template <int CINP, int S>
+__device__ __forceinline__ void conv_mfma(const float* __restrict__ bsrc,
+                                          const float4* __restrict__ ap, A3 acur,
+                                          f32x16 (&acc)[NT])
 {
+    constexpr int G = CINP / 8;
+    float b0[4 * NT], b1[4 * NT], b2[4 * NT];
+    load_b<S>(bsrc, 0, b0);
+    load_b<S>(bsrc, 1, b1);
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        const int gn = g + 1 < G ? g + 1 : g;                // last iteration: harmless re-read
+        const A3 anxt = load_a(ap, gn);
+        // keep the three weight loads HERE: left alone, the scheduler sinks them to the end of
+        // the iteration and the next iteration stalls on their full L2 latency (measured: +12 %)
+        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);   // 3 VMEM reads first
+        const float* bp = bsrc + g * 8 * S;
+        const float* bn = bsrc + gn * 8 * S;
+        load_b<S>(bp, 2, b2);
+        mfma_stage(acur.t0, b0, acc);
+        interleave_stage();
+        load_b<S>(bn, 0, b0);
+        mfma_stage(acur.t1, b1, acc);
+        interleave_stage();
+        load_b<S>(bn, 1, b1);
+        mfma_stage(acur.t2, b2, acc);
+        interleave_stage();
+        acur = anxt;
+    }
+}
+
+__device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias_lds, int m0, int h,
+                                              f32x16 (&acc)[NT])
+{   // bias_lds: this layer's bias vector, staged in LDS at kernel start
     float bv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = bias[m0 + (r & 3) + 8 * (r >> 2) + 4 * h];
+    for (int r = 0; r < 16; ++r) bv[r] = bias_lds[m0 + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -146,45 +220,50 @@ __device__ __forceinline__ void store_plain(float* __restrict__ act, const f32x1
     }
 }
 
-// ReLU + MaxPool1d(2,2) + write back into the stage-2 layout (q = p/2 + 1).
+// ReLU + MaxPool1d(2,2) + write back into the stage-2 layout (q = p/2 + 1).  After the
+// adjacent-lane max both lanes of a pair hold the pooled value, so the even lane stores
+// accumulator row r and the odd lane row r+1: every lane stores, no per-store predication.
 __device__ __forceinline__ void store_pool_stage2(float* __restrict__ act, const f32x16 (&acc)[NT],
                                                   int m0, int nt0, int lane)
 {
-    const int j = lane & 31, h = lane >> 5;
+    const int j = lane & 31, h = lane >> 5, odd = j & 1;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int p = 32 * (nt0 + t) + j;
+        const int p = 32 * (nt0 + t) + (j & ~1);                 // even column of this lane's pair
         const bool valid = col_valid<152, 150>(p);
-        const bool writer = ((j & 1) == 0) && p <= 304;
+        if (p <= 304) {
+            float* dst = act + (m0 + 4 * h + odd) * S2 + (p >> 1) + 2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = relu_nan(acc[t][r]);
-            const float o = fmaxf(v, swap_adjacent(v));      // a NaN window is NaN everywhere
-            if (writer) act[co * S2 + (p >> 1) + 2] = valid ? o : 0.f;
+            for (int r = 0; r < 16; r += 2) {
+                const float v0 = relu_nan(acc[t][r]), v1 = relu_nan(acc[t][r + 1]);
+                const float o0 = fmaxf(v0, swap_adjacent(v0));   // a NaN window is NaN everywhere
+                const float o1 = fmaxf(v1, swap_adjacent(v1));
+                dst[((r & 3) + 8 * (r >> 2)) * S2] = valid ? (odd ? o1 : o0) : 0.f;
+            }
         }
     }
 }
 
-// ReLU + MaxPool1d(2,2) (floor: t = 74 dropped) + flatten (c*37 + j) to HBM.
+// ReLU + MaxPool1d(2,2) (floor: t = 74 dropped) + flatten (c*37 + j) to HBM; same lane pairing.
 __device__ __forceinline__ void store_pool_feat(float* __restrict__ feat, int64_t win0, int nvalid,
                                                 const f32x16 (&acc)[NT], int m0, int lane)
 {
-    const int j = lane & 31, h = lane >> 5;
+    const int j = lane & 31, h = lane >> 5, odd = j & 1;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int q = 32 * t + j;
+        const int q = 32 * t + (j & ~1);
         const int r_ = q - 2;
         const int w = r_ >= 76 ? 1 : 0;
         const int tt = r_ - 76 * w;
-        const bool writer = ((j & 1) == 0) && r_ >= 0 && r_ < 152 && tt < 74 && w < nvalid;
-        float* dst = feat + (win0 + w) * FEAT + (tt >> 1);
+        if (r_ >= 0 && r_ < 152 && tt < 74 && w < nvalid) {
+            float* dst = feat + (win0 + w) * FEAT + (m0 + 4 * h + odd) * 37 + (tt >> 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = relu_nan(acc[t][r]);
-            const float o = fmaxf(v, swap_adjacent(v));
-            if (writer) dst[co * 37] = o;
+            for (int r = 0; r < 16; r += 2) {
+                const float v0 = relu_nan(acc[t][r]), v1 = relu_nan(acc[t][r + 1]);
+                const float o0 = fmaxf(v0, swap_adjacent(v0));
+                const float o1 = fmaxf(v1, swap_adjacent(v1));
+                dst[((r & 3) + 8 * (r >> 2)) * 37] = odd ? o1 : o0;
+            }
         }
     }
 }
@@ -260,6 +339,32 @@ void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
     const int64_t win0 = (int64_t)blockIdx.x * NW;
     const int nvalid = (n - win0) < NW ? (int)(n - win0) : NW;
 
+    TRACE_MARK(0);
+#if DCE_TRACE
+    if (tid == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+#endif
+#if DCE_SLOT_PRIO
+    // Two workgroups share every SIMD (one wave each, wave slots 0 and 1).  With equal priority
+    // they split the matrix pipe 50/50, their waves drift apart SIMD by SIMD, and each block's
+    // barriers then wait for its slowest wave while the pipe idles (measured: 26 % of a block's
+    // life in load / write-back phases).  Strict priority by wave slot makes the slot-1 block run
+    // as if alone, in lockstep across its 4 SIMDs, while the slot-0 block soaks up every gap.
+    if (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1) __builtin_amdgcn_s_setprio(3);
+#endif
+#if DCE_STAGGER
+    // Two workgroups share each CU and would otherwise run their load / write-back phases in
+    // lockstep (both idle the matrix pipe at the same moments).  Offset the one whose waves sit
+    // in an odd wave slot of their SIMD (HW_ID.wave_id bit 0); first residency round only.
+    if (blockIdx.x < 2 * 256 && (__builtin_amdgcn_s_getreg((1 - 1) << 11 | 0 << 6 | 4) & 1))
+        __builtin_amdgcn_s_sleep(127);
+#endif
+    // biases of the four layers -> LDS once (read back as accumulator init values)
+    for (int i = tid; i < 384; i += 256) {
+        const int l = i < 64 ? 0 : (i < 128 ? 1 : (i < 256 ? 2 : 3));
+        const int o = i < 64 ? i : (i < 128 ? i - 64 : (i < 256 ? i - 128 : i - 256));
+        act[ACT_FLOATS + i] = pk.b[l][o];
+    }
+
     // ---- prologue: HBM -> registers -> (z-score) -> LDS, transposed to [channel][position]
     {
         float x[NW][38];
@@ -285,46 +390,70 @@ void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
         for (int i = tid; i < 2 * S1; i += 256) act[CH * S1 + i] = 0.f;
     }
     __syncthreads();
+    TRACE_MARK(1);
 
     f32x16 acc[NT];
+    A3 a0;
+    const float* bias_lds = act + ACT_FLOATS;            // [64 | 64 | 128 | 128]
 
     // ---- conv1: 54(56) -> 64, stage 1
     {
         const int mt = wv & 1, nt0 = NT * (wv >> 1);
-        acc_init_bias(pk.b[0], 32 * mt, h, acc);
-        conv_mfma<56, S1>(act + h * S1 + j + 32 * nt0,
-                          reinterpret_cast<const float4*>(pk.w[0]) + mt * (3 * 7 * 64) + lane, acc);
-        __syncthreads();
+        const float4* ap1 = reinterpret_cast<const float4*>(pk.w[0]) + mt * (3 * 7 * 64) + lane;
+        const float4* ap2 = reinterpret_cast<const float4*>(pk.w[1]) + mt * (3 * 8 * 64) + lane;
+        a0 = load_a(ap1, 0);
+        acc_init_bias(bias_lds, 32 * mt, h, acc);
+        conv_mfma<56, S1>(act + h * S1 + j + 32 * nt0, ap1, a0, acc);
+        TRACE_MARK(2);
+        a0 = load_a(ap2, 0);                             // next layer's first weights: in flight
+        __syncthreads();                                 // across the write-back
         store_plain<S1, 152, 150>(act, acc, 32 * mt, nt0, lane);
+        acc_init_bias(bias_lds + 64, 32 * mt, h, acc);
         __syncthreads();
+        TRACE_MARK(3);
         // ---- conv2: 64 -> 64, ReLU, pool -> stage 2
-        acc_init_bias(pk.b[1], 32 * mt, h, acc);
-        conv_mfma<64, S1>(act + h * S1 + j + 32 * nt0,
-                          reinterpret_cast<const float4*>(pk.w[1]) + mt * (3 * 8 * 64) + lane, acc);
-        __syncthreads();
-        store_pool_stage2(act, acc, 32 * mt, nt0, lane);
-        __syncthreads();
+        conv_mfma<64, S1>(act + h * S1 + j + 32 * nt0, ap2, a0, acc);
+        TRACE_MARK(4);
     }
-    // ---- conv3: 64 -> 128, stage 2
     {
-        const int mt = wv;
-        acc_init_bias(pk.b[2], 32 * mt, h, acc);
-        conv_mfma<64, S2>(act + h * S2 + j,
-                          reinterpret_cast<const float4*>(pk.w[2]) + mt * (3 * 8 * 64) + lane, acc);
+        const int mt12 = wv & 1, nt0 = NT * (wv >> 1), mt = wv;
+        const float4* ap3 = reinterpret_cast<const float4*>(pk.w[2]) + mt * (3 * 8 * 64) + lane;
+        const float4* ap4 = reinterpret_cast<const float4*>(pk.w[3]) + mt * (3 * 16 * 64) + lane;
+        a0 = load_a(ap3, 0);
+        __syncthreads();
+        store_pool_stage2(act, acc, 32 * mt12, nt0, lane);
+        acc_init_bias(bias_lds + 128, 32 * mt, h, acc);
+        __syncthreads();
+        TRACE_MARK(5);
+        // ---- conv3: 64 -> 128, stage 2
+        conv_mfma<64, S2>(act + h * S2 + j, ap3, a0, acc);
+        TRACE_MARK(6);
+        a0 = load_a(ap4, 0);
         __syncthreads();
         store_plain<S2, 76, 75>(act, acc, 32 * mt, 0, lane);
+        acc_init_bias(bias_lds + 256, 32 * mt, h, acc);
         __syncthreads();
+        TRACE_MARK(7);
         // ---- conv4: 128 -> 128, ReLU, pool, flatten -> HBM
-        acc_init_bias(pk.b[3], 32 * mt, h, acc);
-        conv_mfma<128, S2>(act + h * S2 + j,
-                           reinterpret_cast<const float4*>(pk.w[3]) + mt * (3 * 16 * 64) + lane, acc);
+        conv_mfma<128, S2>(act + h * S2 + j, ap4, a0, acc);
+        TRACE_MARK(8);
         store_pool_feat(feat, win0, nvalid, acc, 32 * mt, lane);
+        TRACE_MARK(9);
     }
 }
 
+#if DCE_TRACE
+}  // namespace dce
+extern "C" int dce_debug_trace_read(unsigned long long* out, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dce::g_trace), sizeof(unsigned long long) * 16 * nblocks);
+}
+namespace dce {
+#endif
+
 hipError_t init_conv_stack()
 {   // > 64 KiB of dynamic LDS has to be granted per function, per device
-    const int lds = ACT_FLOATS * (int)sizeof(float);
+    const int lds = DCE_TRACE ? 100 * 1024 : LDS_FLOATS * (int)sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
@@ -336,7 +465,10 @@ hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const Conv
                              float* feat, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    const size_t lds = ACT_FLOATS * sizeof(float);
+    size_t lds = LDS_FLOATS * sizeof(float);
+#if DCE_TRACE
+    if (getenv("DCE_ONE_PER_CU")) lds = 100 * 1024;      // debug: force one workgroup per CU
+#endif
     const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
     if (zscore)
         hipLaunchKernelGGL(conv_stack_kernel<true>, grid, block, lds, st, src, n, pk, feat);

@@ -24,6 +24,9 @@ namespace dce {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef DCE_SLOT_PRIO
+#define DCE_SLOT_PRIO 0      // no effect on the GEMM, harmful on the conv kernel (r1 notes)
+#endif
 constexpr int BK = 32, LDK = 36;          // K-tile; LDK = padded LDS row length in floats
 
 __device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
@@ -62,6 +65,11 @@ void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if DCE_SLOT_PRIO
+    // strict priority between the co-resident blocks of a SIMD (see conv_stack.hip): the odd
+    // wave slot runs as if alone, the even one fills its barrier / staging gaps
+    if (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1) __builtin_amdgcn_s_setprio(3);
+#endif
     const int wm = (wv >> 1) * 32 * TM, wn = (wv & 1) * 32 * TN;
     const int i = lane & 31, h = lane >> 5;
 
