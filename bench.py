@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc"],
+                    help="fp32 = the headline (exact fp32 MFMA); bf16_fc = BASELINE configs[4]")
     args = ap.parse_args()
 
     import torch
@@ -123,7 +125,7 @@ def main():
 
     B = args.batch
     sd = synth.make_state_dict(1, "uniform")
-    model = contact_cnn(device=local_rank, max_batch=B)
+    model = contact_cnn(device=local_rank, max_batch=B, precision=args.precision)
     model.load_state_dict(sd).eval()
 
     # synthetic input: a per-rank N(0,1) sequence, z-scored per window by the library
@@ -207,7 +209,7 @@ def main():
             "value": wps, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "f32 conv + bf16 FC (f32 accumulate)", "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: {B} pre-normalised windows (B,150,54) fp32 per GPU per step, "
                             "HBM-resident -> fused conv stack + fc1/fc2/fc3 -> logits+argmax+contact bits "

@@ -227,9 +227,11 @@ class contact_cnn:
         a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
         self._check_windows(a)
         n = a.shape[0]
-        out = {"feat": np.empty((n, 4736), np.float32), "h1": np.empty((n, 2048), np.float32),
-               "h2": np.empty((n, 512), np.float32), "logits": np.empty((n, CLASSES), np.float32)}
-        p = lambda k: out[k].ctypes.data_as(C.c_void_p)
+        out = {"h2": np.empty((n, 512), np.float32), "logits": np.empty((n, CLASSES), np.float32)}
+        if self._precision == "fp32":          # feat / h1 are bf16 scratch in the bf16-FC mode
+            out["feat"] = np.empty((n, 4736), np.float32)
+            out["h1"] = np.empty((n, 2048), np.float32)
+        p = lambda k: out[k].ctypes.data_as(C.c_void_p) if k in out else None
         _lib.check(self._lib.dce_set_stream(self._ctx, None, 1), self._ctx)
         _lib.check(self._lib.dce_forward_taps(self._ctx, a.ctypes.data_as(C.c_void_p), n, 0,
                                               p("feat"), p("h1"), p("h2"), p("logits")), self._ctx)

@@ -245,7 +245,17 @@ __device__ __forceinline__ void store_pool_stage2(float* __restrict__ act, const
 }
 
 // ReLU + MaxPool1d(2,2) (floor: t = 74 dropped) + flatten (c*37 + j) to HBM; same lane pairing.
-__device__ __forceinline__ void store_pool_feat(float* __restrict__ feat, int64_t win0, int nvalid,
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
+{   // round-to-nearest-even; NaN stays NaN
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void put_feat(float* p, float v) { *p = v; }
+__device__ __forceinline__ void put_feat(unsigned short* p, float v) { *p = f32_to_bf16_rne(v); }
+
+template <typename FT>   // FT = float (headline) or unsigned short (bf16 features for DCE_BF16_FC)
+__device__ __forceinline__ void store_pool_feat(FT* __restrict__ feat, int64_t win0, int nvalid,
                                                 const f32x16 (&acc)[NT], int m0, int lane)
 {
     const int j = lane & 31, h = lane >> 5, odd = j & 1;
@@ -256,13 +266,13 @@ __device__ __forceinline__ void store_pool_feat(float* __restrict__ feat, int64_
         const int w = r_ >= 76 ? 1 : 0;
         const int tt = r_ - 76 * w;
         if (r_ >= 0 && r_ < 152 && tt < 74 && w < nvalid) {
-            float* dst = feat + (win0 + w) * FEAT + (m0 + 4 * h + odd) * 37 + (tt >> 1);
+            FT* dst = feat + (win0 + w) * FEAT + (m0 + 4 * h + odd) * 37 + (tt >> 1);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const float v0 = relu_nan(acc[t][r]), v1 = relu_nan(acc[t][r + 1]);
                 const float o0 = fmaxf(v0, swap_adjacent(v0));
                 const float o1 = fmaxf(v1, swap_adjacent(v1));
-                dst[((r & 3) + 8 * (r >> 2)) * 37] = odd ? o1 : o0;
+                put_feat(dst + ((r & 3) + 8 * (r >> 2)) * 37, odd ? o1 : o0);
             }
         }
     }
@@ -328,9 +338,9 @@ __device__ __forceinline__ void load_windows(const float* __restrict__ src, int6
 // ------------------------------------------------------------------------------------------
 // The fused kernel
 // ------------------------------------------------------------------------------------------
-template <bool ZS>
+template <bool ZS, typename FT>
 __global__ __launch_bounds__(256, 2)
-void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat)
+void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT* __restrict__ feat)
 {
     extern __shared__ __attribute__((aligned(16))) float act[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -451,18 +461,24 @@ extern "C" int dce_debug_trace_read(unsigned long long* out, int nblocks)
 namespace dce {
 #endif
 
-hipError_t init_conv_stack()
+template <bool ZS, typename FT> static hipError_t grant_conv_lds()
 {   // > 64 KiB of dynamic LDS has to be granted per function, per device
     const int lds = DCE_TRACE ? 100 * 1024 : LDS_FLOATS * (int)sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_kernel<false>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_kernel<ZS, FT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
+hipError_t init_conv_stack()
+{
+    hipError_t e;
+    if ((e = grant_conv_lds<true, float>()) != hipSuccess) return e;
+    if ((e = grant_conv_lds<false, float>()) != hipSuccess) return e;
+    if ((e = grant_conv_lds<true, unsigned short>()) != hipSuccess) return e;
+    return grant_conv_lds<false, unsigned short>();
+}
+
 hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const ConvPack& pk,
-                             float* feat, hipStream_t st)
+                             void* feat, int feat_bf16, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     size_t lds = LDS_FLOATS * sizeof(float);
@@ -470,10 +486,15 @@ hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const Conv
     if (getenv("DCE_ONE_PER_CU")) lds = 100 * 1024;      // debug: force one workgroup per CU
 #endif
     const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
-    if (zscore)
-        hipLaunchKernelGGL(conv_stack_kernel<true>, grid, block, lds, st, src, n, pk, feat);
-    else
-        hipLaunchKernelGGL(conv_stack_kernel<false>, grid, block, lds, st, src, n, pk, feat);
+    if (feat_bf16) {
+        unsigned short* f = static_cast<unsigned short*>(feat);
+        if (zscore) hipLaunchKernelGGL((conv_stack_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f);
+        else        hipLaunchKernelGGL((conv_stack_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f);
+    } else {
+        float* f = static_cast<float*>(feat);
+        if (zscore) hipLaunchKernelGGL((conv_stack_kernel<true, float>), grid, block, lds, st, src, n, pk, f);
+        else        hipLaunchKernelGGL((conv_stack_kernel<false, float>), grid, block, lds, st, src, n, pk, f);
+    }
     return hipGetLastError();
 }
 

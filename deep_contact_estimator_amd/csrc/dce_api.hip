@@ -48,6 +48,7 @@ struct dce_ctx {
     ConvPack pk{};
     const float *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr,
                 *fc3w = nullptr, *fc3b = nullptr;
+    const void *fc1w_bf16 = nullptr, *fc2w_bf16 = nullptr;   // DCE_BF16_FC only
 
     float *feat = nullptr, *h1 = nullptr, *h2 = nullptr;   // scratch, max_batch rows each
 
@@ -124,9 +125,17 @@ int drain_spans(dce_ctx* c)
 int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
               float* logits, int32_t* pred, uint8_t* contacts)
 {
-    { Timer t(c, 0); HIP_TRY(c, launch_conv_stack(src, zscore, n, c->pk, c->feat, c->stream)); }
-    { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
-    { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
+    if (c->precision == DCE_BF16_FC) {
+        // conv stack in fp32 -> bf16 features; fc.0 / fc.3 on bf16 MFMA with fp32 accumulate
+        // (feat and h1 scratch hold bf16 here); fc.6 + argmax stay fp32
+        { Timer t(c, 0); HIP_TRY(c, launch_conv_stack(src, zscore, n, c->pk, c->feat, 1, c->stream)); }
+        { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
+        { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, c->stream)); }
+    } else {
+        { Timer t(c, 0); HIP_TRY(c, launch_conv_stack(src, zscore, n, c->pk, c->feat, 0, c->stream)); }
+        { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
+        { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
+    }
     { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream)); }
     if (c->prof && c->spans.size() > 4096) return drain_spans(c);
     return DCE_OK;
@@ -290,8 +299,8 @@ int dce_load_weight(dce_ctx* c, const char* key, const float* host, const int64_
 int dce_finalize_weights(dce_ctx* c, int precision)
 {
     if (!c) return DCE_ERR_ARG;
-    if (precision != DCE_FP32)
-        return fail(c, DCE_ERR_ARG, "precision %d not available in this build (fp32 only)", precision);
+    if (precision != DCE_FP32 && precision != DCE_BF16_FC)
+        return fail(c, DCE_ERR_ARG, "unknown precision %d (0 = fp32, 1 = bf16 FC)", precision);
     for (int k = 0; k < 14; ++k)
         if (!c->have[k]) return fail(c, DCE_ERR_STATE, "missing state_dict key '%s'", kKeys[k].name);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -312,6 +321,20 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         off_fc[k] = reserve(v.size());
         memcpy(img.data() + off_fc[k], v.data(), v.size() * sizeof(float));
     }
+    size_t off_bf[2] = {0, 0};
+    if (precision == DCE_BF16_FC) {
+        // bf16 copies of fc.0 / fc.3 weights (round-to-nearest-even), same [out][in] layout
+        for (int k = 0; k < 2; ++k) {
+            const auto& v = c->host_w[8 + 2 * k];
+            off_bf[k] = reserve((v.size() + 1) / 2);
+            unsigned short* d = reinterpret_cast<unsigned short*>(img.data() + off_bf[k]);
+            for (size_t i = 0; i < v.size(); ++i) {
+                unsigned u; memcpy(&u, &v[i], 4);
+                d[i] = ((u & 0x7fffffffu) > 0x7f800000u) ? (unsigned short)((u >> 16) | 0x40)
+                                                         : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            }
+        }
+    }
     if (c->d_weights) { HIP_TRY(c, hipFree(c->d_weights)); c->d_weights = nullptr; }
     HIP_TRY(c, hipMalloc(&c->d_weights, img.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -319,6 +342,8 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     c->fc1w = c->d_weights + off_fc[0]; c->fc1b = c->d_weights + off_fc[1];
     c->fc2w = c->d_weights + off_fc[2]; c->fc2b = c->d_weights + off_fc[3];
     c->fc3w = c->d_weights + off_fc[4]; c->fc3b = c->d_weights + off_fc[5];
+    c->fc1w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[0] : nullptr;
+    c->fc2w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[1] : nullptr;
     c->precision = precision;
     c->finalized = true;
     return DCE_OK;
@@ -377,6 +402,8 @@ int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
     if (rc) return rc;
     if (n <= 0 || n > c->max_batch || !windows)
         return fail(c, DCE_ERR_ARG, "dce_forward_taps: need 0 < n <= max_batch (%lld)", (long long)c->max_batch);
+    if (c->precision != DCE_FP32 && (feat || h1))
+        return fail(c, DCE_ERR_ARG, "dce_forward_taps: feat/h1 taps are fp32-only (they are bf16 scratch in DCE_BF16_FC mode)");
     const float* dsrc = windows;
     float* dl = logits;
     if (!on_device) {

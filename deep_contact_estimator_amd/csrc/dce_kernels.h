@@ -28,8 +28,9 @@ hipError_t init_fc_gemm();
 // Fused z-score + conv1..conv4 + ReLU + 2x MaxPool for n windows -> feat (n,4736).
 //   zscore != 0: src is a raw (T,54) sequence; window i = rows [first+i, first+i+150)
 //   zscore == 0: src is (n,150,54) pre-normalised windows, window i at src + i*8100
+//   feat_bf16 != 0: feat is (n,4736) bf16 (round-to-nearest-even) for the bf16 FC path
 hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const ConvPack& pk,
-                             float* feat, hipStream_t st);
+                             void* feat, int feat_bf16, hipStream_t st);
 
 // z-scored windows only: out (n,150,54) from seq rows [first, first+n+149)
 hipError_t launch_zscore_windows(const float* seq_first_row, int64_t n, float* out, hipStream_t st);
@@ -37,6 +38,11 @@ hipError_t launch_zscore_windows(const float* seq_first_row, int64_t n, float* o
 // C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]); fp32 MFMA, N % 128 == 0, K % 32 == 0.
 hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, float* C,
                           int64_t M, int N, int K, int relu, hipStream_t st);
+
+// Same GEMM on bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate): A[M,K], W[N,K] bf16,
+// C fp32 or bf16 (out_bf16).  N % 128 == 0, K % 64 == 0.  DCE_BF16_FC precision only.
+hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int out_bf16,
+                               int64_t M, int N, int K, int relu, hipStream_t st);
 
 // logits = h2 * W3^T + b3 ; argmax (first max, NaN-first) ; 4-bit unpack (MSB = leg 0)
 hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,

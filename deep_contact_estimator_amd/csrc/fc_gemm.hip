@@ -27,29 +27,46 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef DCE_SLOT_PRIO
 #define DCE_SLOT_PRIO 0      // no effect on the GEMM, harmful on the conv kernel (r1 notes)
 #endif
-constexpr int BK = 32, LDK = 36;          // K-tile; LDK = padded LDS row length in floats
+// One K-tile is 128 BYTES of K per row in either precision (32 floats / 64 bf16); LDS rows are
+// padded to 144 B so the 16-B fragment reads of 16 consecutive rows hit 16 distinct slots.
+constexpr int KT_BYTES = 128, LDR = 144;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
 
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
+{   // round-to-nearest-even; NaN stays NaN (quiet)
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
 template <int TM, int TN> struct GemmCfg {
     static constexpr int BM = 64 * TM, BN = 64 * TN;              // block tile (2x2 waves)
-    static constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK;
-    static constexpr int LDS_BYTES = 2 * (A_FLOATS + B_FLOATS) * 4;
+    static constexpr int A_BYTES = BM * LDR, B_BYTES = BN * LDR;
+    static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
 };
 
-// TM x TN MFMA 32x32 tiles per wave; block = 2x2 waves = (64 TM) x (64 TN) outputs.
-template <int TM, int TN>
+// C[M,N] = act(A[M,K] W[N,K]^T + bias).  TM x TN MFMA 32x32 tiles per wave; block = 2x2 waves.
+//   BF16 = false: A, W fp32; v_mfma_f32_32x32x2_f32  (exact fp32)            -- the headline path
+//   BF16 = true : A, W bf16; v_mfma_f32_32x32x16_bf16, fp32 accumulate       -- DCE_BF16_FC
+//   OUT_BF16    : store C as bf16 (input of the next bf16 GEMM) instead of fp32
+template <int TM, int TN, bool BF16, bool OUT_BF16>
 __global__ __launch_bounds__(256, 2)
-void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                    const float* __restrict__ bias, float* __restrict__ C,
+void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
+                    const float* __restrict__ bias, void* __restrict__ Cv,
                     int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
 {
     using Cfg = GemmCfg<TM, TN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN;
-    constexpr int SA = BM / 32, SB = BN / 32;            // float4 staged per thread per K-tile
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                    // [2][BM][LDK]
-    float* Bs = smem + 2 * Cfg::A_FLOATS;                // [2][BN][LDK]
+    constexpr int SA = BM / 32, SB = BN / 32;            // 16-B pieces staged per thread per K-tile
+    constexpr int ES = BF16 ? 2 : 4;                     // element size
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                                     // [2][BM][LDR]
+    char* Bs = smem + 2 * Cfg::A_BYTES;                  // [2][BN][LDR]
+    const char* A = static_cast<const char*>(Av);
+    const char* W = static_cast<const char*>(Wv);
 
     // ---- XCD-aware tile assignment (speed only; any placement is correct)
     const int bid = blockIdx.x;
@@ -66,8 +83,6 @@ void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #if DCE_SLOT_PRIO
-    // strict priority between the co-resident blocks of a SIMD (see conv_stack.hip): the odd
-    // wave slot runs as if alone, the even one fills its barrier / staging gaps
     if (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1) __builtin_amdgcn_s_setprio(3);
 #endif
     const int wm = (wv >> 1) * 32 * TM, wn = (wv & 1) * 32 * TN;
@@ -75,17 +90,18 @@ void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
 
     // staging: thread -> (row = tid/8 + 32*s, 16-byte column tid%8)
     const int srow = tid >> 3, sk4 = tid & 7;
-    const float* ag[SA];
-    const float* bg[SB];
+    const size_t rowb = (size_t)K * ES;                  // bytes per operand row
+    const char* ag[SA];
+    const char* bg[SB];
 #pragma unroll
     for (int s = 0; s < SA; ++s) {
         int ra = m0 + srow + 32 * s;
         ra = ra < M ? ra : M - 1;                        // clamp: rows >= M are computed, never stored
-        ag[s] = A + (size_t)ra * K + 4 * sk4;
+        ag[s] = A + (size_t)ra * rowb + 16 * sk4;
     }
 #pragma unroll
-    for (int s = 0; s < SB; ++s) bg[s] = W + (size_t)(n0 + srow + 32 * s) * K + 4 * sk4;
-    const int sdst = srow * LDK + 4 * sk4;
+    for (int s = 0; s < SB; ++s) bg[s] = W + (size_t)(n0 + srow + 32 * s) * rowb + 16 * sk4;
+    const int sdst = srow * LDR + 16 * sk4;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -101,50 +117,61 @@ void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
 #pragma unroll
     for (int s = 0; s < SB; ++s) rb4[s] = *reinterpret_cast<const float4*>(bg[s]);
 #pragma unroll
-    for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(As + sdst + 32 * s * LDK) = ra4[s];
+    for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(As + sdst + 32 * s * LDR) = ra4[s];
 #pragma unroll
-    for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(Bs + sdst + 32 * s * LDK) = rb4[s];
+    for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(Bs + sdst + 32 * s * LDR) = rb4[s];
     __syncthreads();
 
-    const int KT = K / BK;
-    const int fa = (wm + i) * LDK + 4 * h;               // this lane's A fragment row, k-quad h
-    const int fb = (wn + i) * LDK + 4 * h;
+    const int KT = (int)(rowb / KT_BYTES);
+    const int fa = (wm + i) * LDR + 16 * h;              // this lane's fragment row, 16-B half h
+    const int fb = (wn + i) * LDR + 16 * h;
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
         // prefetch the next K-tile into registers (the last iteration re-reads its own tile:
         // unconditional loads keep the staging registers out of scratch and the loop branch-free)
-        const size_t koff = (size_t)(kt + 1 < KT ? kt + 1 : kt) * BK;
+        const size_t koff = (size_t)(kt + 1 < KT ? kt + 1 : kt) * KT_BYTES;
 #pragma unroll
         for (int s = 0; s < SA; ++s) ra4[s] = *reinterpret_cast<const float4*>(ag[s] + koff);
 #pragma unroll
         for (int s = 0; s < SB; ++s) rb4[s] = *reinterpret_cast<const float4*>(bg[s] + koff);
 
-        const float* as = As + cur * Cfg::A_FLOATS + fa;
-        const float* bs = Bs + cur * Cfg::B_FLOATS + fb;
+        const char* as = As + cur * Cfg::A_BYTES + fa;
+        const char* bs = Bs + cur * Cfg::B_BYTES + fb;
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
             float4 af[TM], bf[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(as + 32 * a * LDK + 8 * kq);
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(as + 32 * a * LDR + 32 * kq);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(bs + 32 * b * LDK + 8 * kq);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(bs + 32 * b * LDR + 32 * kq);
+            if constexpr (BF16) {
+                // lane (i,h) holds k = 16*kq + 8*h .. +7 of its row: the 32x32x16 fragment
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int b = 0; b < TN; ++b) {
-                        const float av = u == 0 ? af[a].x : u == 1 ? af[a].y : u == 2 ? af[a].z : af[a].w;
-                        const float bv = u == 0 ? bf[b].x : u == 1 ? bf[b].y : u == 2 ? bf[b].z : bf[b].w;
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
-                    }
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bf[b]), acc[a][b], 0, 0, 0);
+            } else {
+                // lanes 0-31 / 32-63 take k-quads 0 / 1 of each 8-wide K slice: 4 MFMAs of K=2
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            const float av = u == 0 ? af[a].x : u == 1 ? af[a].y : u == 2 ? af[a].z : af[a].w;
+                            const float bv = u == 0 ? bf[b].x : u == 1 ? bf[b].y : u == 2 ? bf[b].z : bf[b].w;
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                        }
+            }
         }
-        float* ad = As + (cur ^ 1) * Cfg::A_FLOATS + sdst;
-        float* bd = Bs + (cur ^ 1) * Cfg::B_FLOATS + sdst;
+        char* ad = As + (cur ^ 1) * Cfg::A_BYTES + sdst;
+        char* bd = Bs + (cur ^ 1) * Cfg::B_BYTES + sdst;
 #pragma unroll
-        for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(ad + 32 * s * LDK) = ra4[s];
+        for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(ad + 32 * s * LDR) = ra4[s];
 #pragma unroll
-        for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(bd + 32 * s * LDK) = rb4[s];
+        for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(bd + 32 * s * LDR) = rb4[s];
         __syncthreads();
     }
 
@@ -160,23 +187,35 @@ void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
                 const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = acc[a][b][r] + bv;
                 if (relu) v = relu_nan(v);
-                if (row < M) C[(size_t)row * N + col] = v;
+                if (row < M) {
+                    if constexpr (OUT_BF16) static_cast<unsigned short*>(Cv)[(size_t)row * N + col] = f32_to_bf16_rne(v);
+                    else static_cast<float*>(Cv)[(size_t)row * N + col] = v;
+                }
             }
         }
     }
 }
 
-hipError_t init_fc_gemm()
+template <int TM, int TN, bool BF16, bool OUT_BF16>
+static hipError_t grant_lds()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel<2, 2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<2, 2>::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel<1, 1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<1, 1>::LDS_BYTES);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel<TM, TN, BF16, OUT_BF16>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<TM, TN>::LDS_BYTES);
 }
 
-template <int TM, int TN>
-static hipError_t launch_gemm_cfg(const float* A, const float* W, const float* bias, float* C,
+hipError_t init_fc_gemm()
+{
+    hipError_t e;
+    if ((e = grant_lds<2, 2, false, false>()) != hipSuccess) return e;
+    if ((e = grant_lds<1, 1, false, false>()) != hipSuccess) return e;
+    if ((e = grant_lds<2, 2, true, true>()) != hipSuccess) return e;
+    if ((e = grant_lds<2, 2, true, false>()) != hipSuccess) return e;
+    if ((e = grant_lds<1, 1, true, true>()) != hipSuccess) return e;
+    return grant_lds<1, 1, true, false>();
+}
+
+template <int TM, int TN, bool BF16, bool OUT_BF16>
+static hipError_t launch_gemm_cfg(const void* A, const void* W, const float* bias, void* C,
                                   int64_t M, int N, int K, int relu, hipStream_t st)
 {
     using Cfg = GemmCfg<TM, TN>;
@@ -186,7 +225,7 @@ static hipError_t launch_gemm_cfg(const float* A, const float* W, const float* b
     const int sm = 64 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 64;
-    hipLaunchKernelGGL((fc_gemm_kernel<TM, TN>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st,
+    hipLaunchKernelGGL((fc_gemm_kernel<TM, TN, BF16, OUT_BF16>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st,
                        A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
     return hipGetLastError();
 }
@@ -195,11 +234,24 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
                           int64_t M, int N, int K, int relu, hipStream_t st)
 {
     if (M <= 0) return hipSuccess;
-    if (N % 128 || K % BK || M > (1 << 30)) return hipErrorInvalidValue;
+    if (N % 128 || K % 32 || M > (1 << 30)) return hipErrorInvalidValue;
     // 128x128 tiles when they alone fill the chip (512 resident blocks), else 64x64
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
-    if (big_blocks >= 384) return launch_gemm_cfg<2, 2>(A, W, bias, C, M, N, K, relu, st);
-    return launch_gemm_cfg<1, 1>(A, W, bias, C, M, N, K, relu, st);
+    if (big_blocks >= 384) return launch_gemm_cfg<2, 2, false, false>(A, W, bias, C, M, N, K, relu, st);
+    return launch_gemm_cfg<1, 1, false, false>(A, W, bias, C, M, N, K, relu, st);
+}
+
+hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int out_bf16,
+                               int64_t M, int N, int K, int relu, hipStream_t st)
+{
+    if (M <= 0) return hipSuccess;
+    if (N % 128 || K % 64 || M > (1 << 30)) return hipErrorInvalidValue;
+    const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
+    if (big_blocks >= 384)
+        return out_bf16 ? launch_gemm_cfg<2, 2, true, true>(A, W, bias, C, M, N, K, relu, st)
+                        : launch_gemm_cfg<2, 2, true, false>(A, W, bias, C, M, N, K, relu, st);
+    return out_bf16 ? launch_gemm_cfg<1, 1, true, true>(A, W, bias, C, M, N, K, relu, st)
+                    : launch_gemm_cfg<1, 1, true, false>(A, W, bias, C, M, N, K, relu, st);
 }
 
 // ------------------------------------------------------------------------------------------

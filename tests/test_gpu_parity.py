@@ -225,6 +225,33 @@ def test_full_size_properties(models, orc):
     _argmax_contract(pred[idx], contacts[idx], ref["logits"], ref["pred"], ref["contacts"])
 
 
+def test_bf16_fc_precision(models, orc):
+    """BASELINE.json configs[4]: bf16 MFMA (fp32 accumulate) on fc.0/fc.3, conv stack fp32.
+    Accuracy delta vs the fp32 path on identical inputs: bounded logit error, rare argmax flips,
+    and every flip sits on a small fp32 top-2 margin."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    seq = synth.make_sequence(150 + 2047, 41).astype(np.float32)
+    f32 = models().infer_sequence(seq)
+    m = contact_cnn(device=0, max_batch=2048, precision="bf16_fc")
+    m.load_state_dict(synth.make_state_dict(1, "uniform"))
+    b16 = m.infer_sequence(seq)
+    again = m.infer_sequence(seq)
+    assert np.array_equal(b16["logits"], again["logits"])                    # deterministic
+    scale = np.abs(f32["logits"]).max()
+    err = np.abs(b16["logits"] - f32["logits"]).max()
+    assert err < 2e-2 * scale, (err, scale)              # bf16 has 8 mantissa bits; K=4736 averages it down
+    flips = b16["pred"] != f32["pred"]
+    srt = np.sort(f32["logits"], axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    assert flips.mean() < 0.02, flips.mean()
+    assert (margin[flips] < 4 * err + 1e-6).all()        # only near-ties may flip
+    assert np.array_equal(b16["contacts"], ((b16["pred"][:, None] & np.array([8, 4, 2, 1])) != 0).astype(np.uint8))
+    taps = m.forward_taps(m.zscore_windows(seq, 0, 8))
+    assert "feat" not in taps and taps["h2"].shape == (8, 512)
+    print(f"bf16_fc vs fp32: max|dlogit| {err:.3e} (scale {scale:.2f}), argmax flips {int(flips.sum())}/{len(flips)}")
+    m.close()
+
+
 def test_reference_loop_api(golden, case_inputs, models, tmp_path):
     """The reference's own call sequence (src/test.py:123-136, src/inference_one_seq.py:148-168)
     on the mirrored host API reproduces the golden accuracy numbers and contacts."""
