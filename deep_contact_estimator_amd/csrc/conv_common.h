@@ -1,0 +1,90 @@
+// conv_common.h -- device helpers shared by the two conv-stack kernels (direct and Winograd).
+#pragma once
+#include "dce_kernels.h"
+
+namespace dce {
+
+#ifndef DCE_TRACE
+#define DCE_TRACE 0
+#endif
+#if DCE_TRACE
+// debug build only (build.build_variant('trace', ['-DDCE_TRACE=1'])): per-workgroup phase
+// timestamps (s_memtime) + HW_ID, read back with dce_debug_trace_read() (tools/trace_conv.py)
+static __device__ unsigned long long g_trace[4096 * 16];   // one per translation unit
+#define TRACE_MARK(k) do { if (tid == 0 && blockIdx.x < 4096) \
+        g_trace[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE_MARK(k) do {} while (0)
+#endif
+
+constexpr int NW = 2;             // windows per workgroup (two workgroups per CU)
+
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }   // keeps NaN like torch
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
+{   // round-to-nearest-even; NaN stays NaN
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void put_feat(float* p, float v) { *p = v; }
+__device__ __forceinline__ void put_feat(unsigned short* p, float v) { *p = f32_to_bf16_rne(v); }
+
+// Load NWIN windows (rows t = 4m + g of channel c per thread, tid = g*54 + c < 216) and, if ZS,
+// z-score them per channel over time exactly as utils/data_handler.py:55-56 does on fp32 data:
+//   (x - mean) / std,  mean = sum/150 rounded to fp32,  std = sqrt(sum((x-mean)^2)/149) (unbiased,
+//   no epsilon) rounded to fp32.
+// Both reductions run in fp64 (full-rate on CDNA4, ~300 ops per thread): with sensor offsets
+// of O(1-10) and spreads of O(0.01) one fp32 ulp of the mean is already 5e-5 standard
+// deviations, so the mean must be the correctly rounded one, not an fp32 running sum.
+// red: >= NWIN*4*216 floats of LDS scratch (two sets of 216 doubles per window).
+template <bool ZS, int NWIN>
+__device__ __forceinline__ void load_windows(const float* __restrict__ src, int64_t win_stride,
+                                             int nvalid, float* __restrict__ red,
+                                             float (&x)[NWIN][38], int tid)
+{
+    const int c = tid % CH, g = tid / CH;
+    const bool loader = tid < 4 * CH;
+#pragma unroll
+    for (int w = 0; w < NWIN; ++w)
+#pragma unroll
+        for (int m = 0; m < 38; ++m) {
+            const int t = 4 * m + g;
+            x[w][m] = (loader && t < WIN && w < nvalid) ? src[w * win_stride + t * CH + c] : 0.f;
+        }
+    if (ZS) {
+        double* dred = reinterpret_cast<double*>(red);
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < 38; ++m) s += (double)x[w][m];       // rows t >= 150 were loaded as 0
+            if (loader) dred[w * 216 + tid] = s;
+        }
+        __syncthreads();
+        float mean[NWIN];
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            const double* r = dred + w * 216 + c;
+            const double mu = loader ? ((r[0] + r[54]) + (r[108] + r[162])) / 150.0 : 0.0;
+            mean[w] = (float)mu;
+            double q = 0.0;
+#pragma unroll
+            for (int m = 0; m < 38; ++m) {
+                const double d = (double)x[w][m] - mu;
+                q += (4 * m + g < WIN) ? d * d : 0.0;
+            }
+            if (loader) dred[(NWIN + w) * 216 + tid] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            const double* r = dred + (NWIN + w) * 216 + c;
+            const float sd = loader ? (float)sqrt(((r[0] + r[54]) + (r[108] + r[162])) / 149.0) : 1.f;
+#pragma unroll
+            for (int m = 0; m < 38; ++m) x[w][m] = (w < nvalid) ? (x[w][m] - mean[w]) / sd : 0.f;
+        }
+    }
+}
+
+}  // namespace dce

@@ -28,14 +28,13 @@
 //   stage 2 (T=75):  q = 2 +  76*w + t      pads q = 1,77,153           row stride S2 = 155
 // t = 0 sits on an even column in both, so pooling pairs (2j,2j+1) are lanes (2m,2m+1), and
 // pooling maps stage 1 to stage 2 by q = p/2 + 1 for both windows and for the pads alike.
-#include "dce_kernels.h"
+#include "conv_common.h"
 #include <cstdlib>
 
 namespace dce {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NW  = 2;            // windows per workgroup
 constexpr int S1  = 307;          // odd strides: transposing stores hit 32 distinct banks
 constexpr int S2  = 155;
 constexpr int ACT_FLOATS = 128 * S2 + 16;             // 19,856 floats = 79,424 B (>= 64*S1+16)
@@ -48,22 +47,9 @@ static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
 #ifndef DCE_STAGGER
 #define DCE_STAGGER 0
 #endif
-#ifndef DCE_TRACE
-#define DCE_TRACE 0
-#endif
 #ifndef DCE_SLOT_PRIO
 #define DCE_SLOT_PRIO 0      // measured: s_setprio by wave slot makes the kernel 11 % SLOWER (r1 notes)
 #endif
-#if DCE_TRACE
-// debug build only (python -m ... build_variant('trace', ['-DDCE_TRACE=1'])): per-block phase
-// timestamps (s_memtime) + HW_ID, read back with dce_debug_trace_read().
-__device__ unsigned long long g_trace[4096 * 16];
-#define TRACE_MARK(k) do { if (tid == 0 && blockIdx.x < 4096) \
-        g_trace[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define TRACE_MARK(k) do {} while (0)
-#endif
-
 // ------------------------------------------------------------------------------------------
 // Host-side weight packing
 // ------------------------------------------------------------------------------------------
@@ -91,7 +77,6 @@ void conv_pack_host(int l, const float* w, float* out)
 // ------------------------------------------------------------------------------------------
 // Device helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }   // keeps NaN like torch
 
 __device__ __forceinline__ float swap_adjacent(float v)
 {   // lane 2m <-> 2m+1 : DPP quad_perm [1,0,3,2]
@@ -245,15 +230,6 @@ __device__ __forceinline__ void store_pool_stage2(float* __restrict__ act, const
 }
 
 // ReLU + MaxPool1d(2,2) (floor: t = 74 dropped) + flatten (c*37 + j) to HBM; same lane pairing.
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
-{   // round-to-nearest-even; NaN stays NaN
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ void put_feat(float* p, float v) { *p = v; }
-__device__ __forceinline__ void put_feat(unsigned short* p, float v) { *p = f32_to_bf16_rne(v); }
-
 template <typename FT>   // FT = float (headline) or unsigned short (bf16 features for DCE_BF16_FC)
 __device__ __forceinline__ void store_pool_feat(FT* __restrict__ feat, int64_t win0, int nvalid,
                                                 const f32x16 (&acc)[NT], int m0, int lane)
@@ -274,63 +250,6 @@ __device__ __forceinline__ void store_pool_feat(FT* __restrict__ feat, int64_t w
                 const float o1 = fmaxf(v1, swap_adjacent(v1));
                 put_feat(dst + ((r & 3) + 8 * (r >> 2)) * 37, odd ? o1 : o0);
             }
-        }
-    }
-}
-
-// Load NWIN windows (rows t = 4m + g of channel c per thread, tid = g*54 + c < 216) and, if ZS,
-// z-score them per channel over time exactly as utils/data_handler.py:55-56 does on fp32 data:
-//   (x - mean) / std,  mean = sum/150 rounded to fp32,  std = sqrt(sum((x-mean)^2)/149) (unbiased,
-//   no epsilon) rounded to fp32.
-// Both reductions run in fp64 (full-rate on CDNA4, ~300 ops per thread): with sensor offsets
-// of O(1-10) and spreads of O(0.01) one fp32 ulp of the mean is already 5e-5 standard
-// deviations, so the mean must be the correctly rounded one, not an fp32 running sum.
-// red: >= NWIN*4*216 floats of LDS scratch (two sets of 216 doubles per window).
-template <bool ZS, int NWIN>
-__device__ __forceinline__ void load_windows(const float* __restrict__ src, int64_t win_stride,
-                                             int nvalid, float* __restrict__ red,
-                                             float (&x)[NWIN][38], int tid)
-{
-    const int c = tid % CH, g = tid / CH;
-    const bool loader = tid < 4 * CH;
-#pragma unroll
-    for (int w = 0; w < NWIN; ++w)
-#pragma unroll
-        for (int m = 0; m < 38; ++m) {
-            const int t = 4 * m + g;
-            x[w][m] = (loader && t < WIN && w < nvalid) ? src[w * win_stride + t * CH + c] : 0.f;
-        }
-    if (ZS) {
-        double* dred = reinterpret_cast<double*>(red);
-#pragma unroll
-        for (int w = 0; w < NWIN; ++w) {
-            double s = 0.0;
-#pragma unroll
-            for (int m = 0; m < 38; ++m) s += (double)x[w][m];       // rows t >= 150 were loaded as 0
-            if (loader) dred[w * 216 + tid] = s;
-        }
-        __syncthreads();
-        float mean[NWIN];
-#pragma unroll
-        for (int w = 0; w < NWIN; ++w) {
-            const double* r = dred + w * 216 + c;
-            const double mu = loader ? ((r[0] + r[54]) + (r[108] + r[162])) / 150.0 : 0.0;
-            mean[w] = (float)mu;
-            double q = 0.0;
-#pragma unroll
-            for (int m = 0; m < 38; ++m) {
-                const double d = (double)x[w][m] - mu;
-                q += (4 * m + g < WIN) ? d * d : 0.0;
-            }
-            if (loader) dred[(NWIN + w) * 216 + tid] = q;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < NWIN; ++w) {
-            const double* r = dred + (NWIN + w) * 216 + c;
-            const float sd = loader ? (float)sqrt(((r[0] + r[54]) + (r[108] + r[162])) / 149.0) : 1.f;
-#pragma unroll
-            for (int m = 0; m < 38; ++m) x[w][m] = (w < nvalid) ? (x[w][m] - mean[w]) / sd : 0.f;
         }
     }
 }

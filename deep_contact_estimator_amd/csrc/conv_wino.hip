@@ -1,0 +1,430 @@
+// conv_wino.hip -- the conv stack with Winograd F(2,3) minimal filtering on fp32 MFMA (gfx950).
+//
+// Same contract as conv_stack.hip (z-score + 4x[Conv1d k3 p1 + ReLU] + 2x MaxPool1d(2) + flatten;
+// reference src/contact_cnn.py:10-44,61,64 and utils/data_handler.py:55-56) with 2/3 of the matrix
+// work: for an output pair (y[2m], y[2m+1]) and inputs d0..d3 = x[2m-1..2m+2] of one channel
+//     m0 = (d0-d2) g0      m1 = (d1+d2) (g0+g1+g2)/2      m2 = (d2-d1) (g0-g1+g2)/2      m3 = (d1-d3) g2
+//     y[2m] = m0+m1+m2     y[2m+1] = m1-m2-m3
+// Summed over input channels each m_k is a GEMM  M_k[Cout, pairs] = U_k[Cout,Cin] V_k[Cin,pairs]:
+// 4 GEMMs of K = Cin instead of 3 taps x K = Cin over twice the columns.  U_k is precomputed on
+// the host (fp64 -> fp32); V_k is formed on the fly from two 8-byte LDS reads (4 VALU ops per 8
+// MFMAs); the output transform, bias (initial value of M_1), ReLU, zero padding and MaxPool (the
+// two outputs of a pair live in ONE lane -> no cross-lane traffic) are fused in the write-back.
+// fp32 Winograd F(2,3) has transform constants 0, +-1, +-1/2 only; measured logit error vs an fp64
+// evaluation is the same as the direct form's.
+//
+// Structure is otherwise that of conv_stack.hip: one workgroup = 4 waves = 2 windows, two
+// workgroups per CU, all activations in one LDS buffer written back in place, weights streamed
+// from L2 as per-lane packed float4s, the layer's whole output held in accumulators.
+//
+// MFMA: v_mfma_f32_16x16x4_f32 (16-column tiles: 2 windows x 38 pairs = 76 columns fit 5 tiles
+// at 95 %, where 32-column tiles would waste 21 %).  A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+// D[row = 4*(lane>>4)+r][col = lane&15].  A K-step is 4 input channels.
+// Per wave: 2 row tiles (32 output channels) x 5 column tiles x 4 Winograd components = 40
+// accumulators of 4 VGPRs.
+//
+// LDS layout: row = channel, row stride RS; window w occupies WSEG floats: index 0 = x[-1] = 0,
+// index 1+t = x[t], index T+1 (and T+2) = 0.  Pair m reads indices 2m .. 2m+3 (8-byte aligned).
+//   stage 1 (T=150): WSEG 152, RS 304, 75 pairs/window       stage 2 (T=75): WSEG 78, RS 156, 38 pairs
+#include "conv_common.h"
+#include <cstdlib>
+
+namespace dce {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WS1 = 152, RS1 = 2 * WS1, TP1 = 75;
+constexpr int WS2 = 78,  RS2 = 2 * WS2, TP2 = 38;
+constexpr int WACT_FLOATS = 128 * RS2;                       // 19,968 floats (>= 64*RS1 = 19,456)
+constexpr int WLDS_FLOATS = WACT_FLOATS + 384;               // + biases = 81,408 B
+constexpr int WRED_ROW = 56;                                 // fp64 z-score scratch: rows 56..63 of stage 1
+static_assert(64 * RS1 <= WACT_FLOATS && WLDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+static_assert(NW * 4 * 216 <= 8 * RS1 && (WRED_ROW * RS1) % 2 == 0, "z-score scratch fits, 8-B aligned");
+constexpr int MT = 2, NTW = 5;                               // row / column tiles per wave
+#ifndef WINO_EXP
+#define WINO_EXP 0           // bit flags for tools/micro/wino_loop.hip ablations; 0 in the product
+#endif
+#ifndef WINO_PF
+#define WINO_PF 2            // LDS prefetch distance of the main loop, in column tiles (2 or 3)
+#endif
+
+// ------------------------------------------------------------------------------------------
+// Host-side weight transform + packing:  [mtile_pair][kstep][lane][mt(2) x comp(4)]
+// ------------------------------------------------------------------------------------------
+static const int wCin[4]  = {54, 64, 64, 128};
+static const int wCinP[4] = {56, 64, 64, 128};
+static const int wCout[4] = {64, 64, 128, 128};
+
+size_t conv_wino_pack_floats(int l) { return (size_t)wCout[l] * wCinP[l] * 4; }
+
+void conv_wino_pack_host(int l, const float* w, float* out)
+{
+    const int cin = wCin[l], steps = wCinP[l] / 4, cout = wCout[l];
+    size_t o = 0;
+    for (int P = 0; P < cout / 32; ++P)
+        for (int s = 0; s < steps; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int co = 32 * P + 16 * mt + (lane & 15);
+                    const int ci = 4 * s + (lane >> 4);
+                    double g0 = 0, g1 = 0, g2 = 0;
+                    if (ci < cin) {
+                        g0 = w[((size_t)co * cin + ci) * 3 + 0];
+                        g1 = w[((size_t)co * cin + ci) * 3 + 1];
+                        g2 = w[((size_t)co * cin + ci) * 3 + 2];
+                    }
+                    out[o++] = (float)g0;
+                    out[o++] = (float)((g0 + g1 + g2) * 0.5);
+                    out[o++] = (float)((g0 - g1 + g2) * 0.5);
+                    out[o++] = (float)g2;
+                }
+}
+
+// ------------------------------------------------------------------------------------------
+// Device helpers
+// ------------------------------------------------------------------------------------------
+struct A8 { float4 m0, m1; };            // this lane's weights for one K-step: [mt][comp]
+
+__device__ __forceinline__ A8 load_a8(const float4* __restrict__ ap, int s)
+{
+    A8 a; a.m0 = ap[s * 128]; a.m1 = ap[s * 128 + 1]; return a;
+}
+
+// the 4 inputs of pair m: (x[2m-1], x[2m], x[2m+1], x[2m+2]) -- two 8-byte LDS reads
+__device__ __forceinline__ float4 load_quad(const float* __restrict__ p)
+{
+    const float2 lo = *reinterpret_cast<const float2*>(p);
+    const float2 hi = *reinterpret_cast<const float2*>(p + 2);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// One layer's main loop for one wave, software-pipelined by hand at column-tile granularity
+// (a tile = 8 MFMAs = 256 matrix-pipe cycles):
+//     tile i   : 8 MFMAs on V(i), computed one tile earlier  -> no VALU->MFMA wait states
+//     tile i+1 : 4 VALU ops form V(i+1) from the raw quad loaded one tile earlier
+//     tile i+2 : its raw quad is requested from LDS now
+// and the next K-step's weights (2 x 16 B from L2) are requested at the top of each K-step.
+// sched_barrier(0) pins this order: left alone, hipcc sinks every load to just before its use
+// (measured: a lone wave then reaches only 55 % of the MFMA issue rate).
+//   xrow : act + (lane>>4)*RS               (this lane's channel within the K-step)
+//   boff : per column tile, this lane's float offset of pair m inside a row (w*WSEG + 2m)
+//   ap   : packed weights of this wave's row-tile pair, + 2*lane float4
+__device__ __forceinline__ float4 wino_v(const float4 r)
+{
+    return make_float4(r.x - r.z, r.y + r.z, r.z - r.y, r.y - r.w);
+}
+
+template <int RS, int STEPS>
+__device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const int (&boff)[NTW],
+                                          const float4* __restrict__ ap, A8 acur,
+                                          f32x4 (&acc)[MT][NTW][4])
+{
+    float4 vcur = wino_v(load_quad(xrow + boff[0]));      // V of tile (0,0)
+    float4 rawb = load_quad(xrow + boff[1]);              // raw of tile (0,1)
+#if WINO_PF >= 3
+    float4 rawc = load_quad(xrow + boff[2]);              // raw of tile (0,2)
+#endif
+#pragma unroll 1
+    for (int s = 0; s < STEPS; ++s) {
+        const int sn = s + 1 < STEPS ? s + 1 : s;         // last step: harmless re-reads
+#if WINO_EXP & 1
+        const A8 anxt = acur;                               // experiment: no weight loads
+#else
+        const A8 anxt = load_a8(ap, sn);
+#endif
+        const float* xs = xrow + s * 4 * RS;
+        const float* xn = xrow + sn * 4 * RS;
+        const float a0[4] = {acur.m0.x, acur.m0.y, acur.m0.z, acur.m0.w};
+        const float a1[4] = {acur.m1.x, acur.m1.y, acur.m1.z, acur.m1.w};
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            constexpr int D = WINO_PF;                    // LDS prefetch distance in tiles
+            const float* pc = nt + D < NTW ? xs + boff[(nt + D) % NTW] : xn + boff[(nt + D) % NTW];
+#if WINO_EXP & 2
+            const float4 rawn = rawb; (void)pc;            // experiment: no LDS reads
+#else
+            const float4 rawn = load_quad(pc);            // tile i+D
+#endif
+#if WINO_EXP & 4
+            const float4 vnxt = rawb;                      // experiment: no input transform
+#else
+            const float4 vnxt = wino_v(rawb);             // tile i+1
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            const float v[4] = {vcur.x, vcur.y, vcur.z, vcur.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[0][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], v[c], acc[0][nt][c], 0, 0, 0);
+                acc[1][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], v[c], acc[1][nt][c], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            vcur = vnxt;
+#if WINO_PF >= 3
+            rawb = rawc; rawc = rawn;
+#else
+            rawb = rawn;
+#endif
+        }
+        acur = anxt;
+    }
+}
+
+// bias -> initial value of component 1 (it enters y[2m] and y[2m+1] with +1); others start at 0
+__device__ __forceinline__ void wino_init(const float* __restrict__ bias_lds, int co0, int lane,
+                                          f32x4 (&acc)[MT][NTW][4])
+{
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = bias_lds[co0 + 16 * mt + 4 * (lane >> 4) + r];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            acc[mt][nt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[mt][nt][1] = b;
+            acc[mt][nt][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[mt][nt][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+// column n = w*TP + m of a layout with TP pairs per window -> float offset of pair m (0 for fillers)
+template <int TP, int WSEG>
+__device__ __forceinline__ void col_offsets(int nt0, int j, int (&boff)[NTW])
+{
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = 16 * (nt0 + nt) + j;
+        const int w = n >= TP ? 1 : 0;
+        const int m = n - w * TP;
+        boff[nt] = n < NW * TP ? w * WSEG + 2 * m : 0;
+    }
+}
+
+// output transform + ReLU + in-place write-back, no pooling (conv1: T=150, conv3: T=75)
+template <int RS, int WSEG, int TP, int T>
+__device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const f32x4 (&acc)[MT][NTW][4],
+                                                 int co0, int nt0, int lane)
+{
+    const int j = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = 16 * (nt0 + nt) + j;
+        const int w = n >= TP ? 1 : 0;
+        const int m = n - w * TP;
+        if (n < NW * TP) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
+                    const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
+                    float* d = act + (co0 + 16 * mt + 4 * q + r) * RS + w * WSEG + 1 + 2 * m;
+                    d[0] = relu_nan((m0 + m1) + m2);
+                    if (2 * m + 1 < T) d[1] = relu_nan((m1 - m2) - m3);
+                }
+        }
+    }
+}
+
+// output transform + ReLU + MaxPool1d(2,2) -> stage-2 layout (conv2)
+__device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, const f32x4 (&acc)[MT][NTW][4],
+                                                       int co0, int nt0, int lane)
+{
+    const int j = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = 16 * (nt0 + nt) + j;
+        const int w = n >= TP1 ? 1 : 0;
+        const int m = n - w * TP1;
+        if (n < NW * TP1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
+                    const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
+                    const float y0 = relu_nan((m0 + m1) + m2), y1 = relu_nan((m1 - m2) - m3);
+                    act[(co0 + 16 * mt + 4 * q + r) * RS2 + w * WS2 + 1 + m] = fmaxf(y0, y1);
+                }
+        }
+    }
+}
+
+// output transform + ReLU + MaxPool1d(2,2) (pairs 0..36; t = 74 dropped) + flatten c*37+j -> HBM
+template <typename FT>
+__device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t win0, int nvalid,
+                                                const f32x4 (&acc)[MT][NTW][4], int co0, int lane)
+{
+    const int j = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = 16 * nt + j;
+        const int w = n >= TP2 ? 1 : 0;
+        const int m = n - w * TP2;
+        if (n < NW * TP2 && m < 37 && w < nvalid) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
+                    const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
+                    const float y0 = relu_nan((m0 + m1) + m2), y1 = relu_nan((m1 - m2) - m3);
+                    put_feat(feat + (win0 + w) * FEAT + (co0 + 16 * mt + 4 * q + r) * 37 + m, fmaxf(y0, y1));
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The fused kernel
+// ------------------------------------------------------------------------------------------
+template <bool ZS, typename FT>
+__global__ __launch_bounds__(256, 2)
+void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT* __restrict__ feat)
+{
+    extern __shared__ __attribute__((aligned(16))) float act[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const int64_t win0 = (int64_t)blockIdx.x * NW;
+    const int nvalid = (n - win0) < NW ? (int)(n - win0) : NW;
+
+    TRACE_MARK(0);
+#if DCE_TRACE
+    if (tid == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+#endif
+    for (int i = tid; i < 384; i += 256) {
+        const int l = i < 64 ? 0 : (i < 128 ? 1 : (i < 256 ? 2 : 3));
+        const int o = i < 64 ? i : (i < 128 ? i - 64 : (i < 256 ? i - 128 : i - 256));
+        act[WACT_FLOATS + i] = pk.b[l][o];
+    }
+
+    // ---- prologue: HBM -> registers -> (z-score) -> LDS [channel][window segment]
+    {
+        float x[NW][38];
+        const int64_t wstride = ZS ? CH : (int64_t)WIN * CH;
+        load_windows<ZS, NW>(src + win0 * wstride, wstride, nvalid, act + WRED_ROW * RS1, x, tid);
+        if (ZS) __syncthreads();                 // the reduction scratch (rows 56..) is zeroed below
+        if (tid < 4 * CH) {
+            const int c = tid % CH, g = tid / CH;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int m = 0; m < 38; ++m) {
+                    const int t = 4 * m + g;
+                    if (t < WIN) act[c * RS1 + w * WS1 + 1 + t] = x[w][m];
+                }
+        }
+        // zero pads (index 0 and 151 of each window segment) of all 64 rows, and the two filler
+        // input channels 54,55 (conv1 runs K over 56 rows with zero weights there)
+        for (int i = tid; i < 64 * 4; i += 256) {
+            const int c = i >> 2, k = i & 3;
+            act[c * RS1 + (k >> 1) * WS1 + (k & 1) * (WS1 - 1)] = 0.f;
+        }
+        for (int i = tid; i < 2 * RS1; i += 256) act[CH * RS1 + i] = 0.f;
+    }
+    __syncthreads();
+    TRACE_MARK(1);
+
+    f32x4 acc[MT][NTW][4];
+    int boff[NTW];
+    const float* bias_lds = act + WACT_FLOATS;            // [64 | 64 | 128 | 128]
+    const float* xrow1 = act + q * RS1;
+    const float* xrow2 = act + q * RS2;
+
+    // ---- stage 1: conv1 (54->64) and conv2 (64->64, pooled): wave = row-tile pair (wv&1), column half (wv>>1)
+    {
+        const int P = wv & 1, nt0 = NTW * (wv >> 1), co0 = 32 * P;
+        const float4* ap1 = reinterpret_cast<const float4*>(pk.ww[0]) + P * (14 * 128) + 2 * lane;
+        const float4* ap2 = reinterpret_cast<const float4*>(pk.ww[1]) + P * (16 * 128) + 2 * lane;
+        col_offsets<TP1, WS1>(nt0, j, boff);
+        A8 a = load_a8(ap1, 0);
+        wino_init(bias_lds, co0, lane, acc);
+        wino_mfma<RS1, 14>(xrow1, boff, ap1, a, acc);
+        TRACE_MARK(2);
+        a = load_a8(ap2, 0);                              // next layer's first weights in flight
+        __syncthreads();                                  // across the write-back
+        wino_store_plain<RS1, WS1, TP1, 150>(act, acc, co0, nt0, lane);
+        wino_init(bias_lds + 64, co0, lane, acc);
+        __syncthreads();
+        TRACE_MARK(3);
+        wino_mfma<RS1, 16>(xrow1, boff, ap2, a, acc);
+        TRACE_MARK(4);
+        const float4* ap3 = reinterpret_cast<const float4*>(pk.ww[2]) + wv * (16 * 128) + 2 * lane;
+        a = load_a8(ap3, 0);
+        __syncthreads();
+        wino_store_pool_stage2(act, acc, co0, nt0, lane);
+        // stage-2 pads: index 0, 76, 77 of each window segment, all 128 rows
+        for (int i = tid; i < 128 * 6; i += 256) {
+            const int c = i / 6, k = i % 6;
+            act[c * RS2 + (k / 3) * WS2 + (k % 3 == 0 ? 0 : 75 + k % 3)] = 0.f;
+        }
+        // ---- stage 2: conv3 (64->128), conv4 (128->128, pooled -> HBM): wave = row-tile pair wv
+        const int co2 = 32 * wv;
+        const float4* ap4 = reinterpret_cast<const float4*>(pk.ww[3]) + wv * (32 * 128) + 2 * lane;
+        col_offsets<TP2, WS2>(0, j, boff);
+        wino_init(bias_lds + 128, co2, lane, acc);
+        __syncthreads();
+        TRACE_MARK(5);
+        wino_mfma<RS2, 16>(xrow2, boff, ap3, a, acc);
+        TRACE_MARK(6);
+        a = load_a8(ap4, 0);
+        __syncthreads();
+        wino_store_plain<RS2, WS2, TP2, 75>(act, acc, co2, 0, lane);
+        wino_init(bias_lds + 256, co2, lane, acc);
+        __syncthreads();
+        TRACE_MARK(7);
+        wino_mfma<RS2, 32>(xrow2, boff, ap4, a, acc);
+        TRACE_MARK(8);
+        wino_store_feat(feat, win0, nvalid, acc, co2, lane);
+        TRACE_MARK(9);
+    }
+}
+
+#if DCE_TRACE
+}  // namespace dce
+extern "C" int dce_debug_trace_read_wino(unsigned long long* out, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dce::g_trace), sizeof(unsigned long long) * 16 * nblocks);
+}
+namespace dce {
+#endif
+
+template <bool ZS, typename FT> static hipError_t grant_wino_lds()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<ZS, FT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, DCE_TRACE ? 100 * 1024 : WLDS_FLOATS * (int)sizeof(float));
+}
+
+hipError_t init_conv_wino()
+{
+    hipError_t e;
+    if ((e = grant_wino_lds<true, float>()) != hipSuccess) return e;
+    if ((e = grant_wino_lds<false, float>()) != hipSuccess) return e;
+    if ((e = grant_wino_lds<true, unsigned short>()) != hipSuccess) return e;
+    return grant_wino_lds<false, unsigned short>();
+}
+
+hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvPack& pk,
+                            void* feat, int feat_bf16, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    size_t lds = WLDS_FLOATS * sizeof(float);
+#if DCE_TRACE
+    if (getenv("DCE_ONE_PER_CU")) lds = 100 * 1024;      // debug: force one workgroup per CU
+#endif
+    const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
+    if (feat_bf16) {
+        unsigned short* f = static_cast<unsigned short*>(feat);
+        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f);
+        else        hipLaunchKernelGGL((conv_wino_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f);
+    } else {
+        float* f = static_cast<float*>(feat);
+        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, float>), grid, block, lds, st, src, n, pk, f);
+        else        hipLaunchKernelGGL((conv_wino_kernel<false, float>), grid, block, lds, st, src, n, pk, f);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace dce

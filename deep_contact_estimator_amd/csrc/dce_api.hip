@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -43,6 +44,7 @@ struct dce_ctx {
     bool have[14] = {};
     bool finalized = false;
     int precision = DCE_FP32;
+    bool winograd = true;                  // conv stack algorithm; DCE_CONV=direct selects the direct form
 
     float* d_weights = nullptr;            // one allocation: conv packs, biases, fc weights
     ConvPack pk{};
@@ -128,11 +130,11 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
     if (c->precision == DCE_BF16_FC) {
         // conv stack in fp32 -> bf16 features; fc.0 / fc.3 on bf16 MFMA with fp32 accumulate
         // (feat and h1 scratch hold bf16 here); fc.6 + argmax stay fp32
-        { Timer t(c, 0); HIP_TRY(c, launch_conv_stack(src, zscore, n, c->pk, c->feat, 1, c->stream)); }
+        { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream)); }
         { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
         { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, c->stream)); }
     } else {
-        { Timer t(c, 0); HIP_TRY(c, launch_conv_stack(src, zscore, n, c->pk, c->feat, 0, c->stream)); }
+        { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream)); }
         { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
         { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
     }
@@ -228,6 +230,7 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     if (!c) return fail(nullptr, DCE_ERR_NOMEM, "out of host memory");
     c->device = device_id;
     c->max_batch = max_batch;
+    if (const char* e = getenv("DCE_CONV")) c->winograd = strcmp(e, "direct") != 0;
 #define CREATE_TRY(expr)                                                                        \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                        \
         fail(nullptr, DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));              \
@@ -236,6 +239,7 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     CREATE_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     CREATE_TRY(init_conv_stack());
+    CREATE_TRY(init_conv_wino());
     CREATE_TRY(init_fc_gemm());
     CREATE_TRY(hipMalloc(&c->feat, (size_t)max_batch * FEAT * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h1, (size_t)max_batch * FC1 * sizeof(float)));
@@ -308,10 +312,12 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     // one host image -> one upload.  Offsets kept 256-B aligned.
     std::vector<float> img;
     auto reserve = [&](size_t floats) { size_t off = (img.size() + 63) & ~size_t(63); img.resize(off + floats); return off; };
-    size_t off_w[4], off_b[4];
+    size_t off_w[4], off_ww[4], off_b[4];
     for (int l = 0; l < 4; ++l) {
         off_w[l] = reserve(conv_pack_floats(l));
         conv_pack_host(l, c->host_w[2 * l].data(), img.data() + off_w[l]);
+        off_ww[l] = reserve(conv_wino_pack_floats(l));
+        conv_wino_pack_host(l, c->host_w[2 * l].data(), img.data() + off_ww[l]);
         off_b[l] = reserve(c->host_w[2 * l + 1].size());
         memcpy(img.data() + off_b[l], c->host_w[2 * l + 1].data(), c->host_w[2 * l + 1].size() * sizeof(float));
     }
@@ -338,7 +344,10 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     if (c->d_weights) { HIP_TRY(c, hipFree(c->d_weights)); c->d_weights = nullptr; }
     HIP_TRY(c, hipMalloc(&c->d_weights, img.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
-    for (int l = 0; l < 4; ++l) { c->pk.w[l] = c->d_weights + off_w[l]; c->pk.b[l] = c->d_weights + off_b[l]; }
+    for (int l = 0; l < 4; ++l) {
+        c->pk.w[l] = c->d_weights + off_w[l]; c->pk.ww[l] = c->d_weights + off_ww[l];
+        c->pk.b[l] = c->d_weights + off_b[l];
+    }
     c->fc1w = c->d_weights + off_fc[0]; c->fc1b = c->d_weights + off_fc[1];
     c->fc2w = c->d_weights + off_fc[2]; c->fc2b = c->d_weights + off_fc[3];
     c->fc3w = c->d_weights + off_fc[4]; c->fc3b = c->d_weights + off_fc[5];

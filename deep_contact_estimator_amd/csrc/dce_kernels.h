@@ -15,11 +15,20 @@ constexpr int WIN = 150, CH = 54, NCLS = 16, FEAT = 4736, FC1 = 2048, FC2 = 512;
 // 4 steps = 8 channels = one float4 per lane.  Element [mtile][g][tap][lane][u] holds
 //   w[cout = 32*mtile + (lane&31)][cin = 8*g + 2*u + (lane>>5)][tap]     (0 if cin >= Cin)
 struct ConvPack {
-    const float* w[4];   // packed weights per layer (device)
+    const float* w[4];   // direct-form packed weights per layer (device)
+    const float* ww[4];  // Winograd F(2,3)-transformed packed weights per layer (device)
     const float* b[4];   // bias per layer (device), PyTorch order
 };
 size_t conv_pack_floats(int layer);                                  // floats in layer's pack
 void   conv_pack_host(int layer, const float* w_torch, float* out);  // [Cout][Cin][3] -> pack
+
+// Winograd F(2,3) variant (conv_wino.hip): U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) per (cout,cin),
+// element [mtile_pair][kstep][lane][mt(2)][comp(4)] = U_comp[32*pair + 16*mt + (lane&15)][4*kstep + (lane>>4)]
+size_t conv_wino_pack_floats(int layer);
+void   conv_wino_pack_host(int layer, const float* w_torch, float* out);
+hipError_t init_conv_wino();
+hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvPack& pk,
+                            void* feat, int feat_bf16, hipStream_t st);
 
 // Per-device one-time setup (dynamic-LDS grants); call after hipSetDevice.
 hipError_t init_conv_stack();

@@ -32,6 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KT_BYTES = 128, LDR = 144;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
 
@@ -111,16 +112,20 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra4[SA], rb4[SB];
+    static_assert((SA == 4 && SB == 4) || (SA == 2 && SB == 2), "staging registers are named, 2 or 4 per operand");
+    {   // first K-tile: plain loads
+        float4 t[SA + SB];
 #pragma unroll
-    for (int s = 0; s < SA; ++s) ra4[s] = *reinterpret_cast<const float4*>(ag[s]);
+        for (int s = 0; s < SA; ++s) t[s] = *reinterpret_cast<const float4*>(ag[s]);
 #pragma unroll
-    for (int s = 0; s < SB; ++s) rb4[s] = *reinterpret_cast<const float4*>(bg[s]);
+        for (int s = 0; s < SB; ++s) t[SA + s] = *reinterpret_cast<const float4*>(bg[s]);
 #pragma unroll
-    for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(As + sdst + 32 * s * LDR) = ra4[s];
+        for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(As + sdst + 32 * s * LDR) = t[s];
 #pragma unroll
-    for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(Bs + sdst + 32 * s * LDR) = rb4[s];
+        for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(Bs + sdst + 32 * s * LDR) = t[SA + s];
+    }
     __syncthreads();
+    v4f ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;          // staging registers (native vectors: asm operands)
 
     const int KT = (int)(rowb / KT_BYTES);
     const int fa = (wm + i) * LDR + 16 * h;              // this lane's fragment row, 16-B half h
@@ -129,11 +134,20 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         const int cur = kt & 1;
         // prefetch the next K-tile into registers (the last iteration re-reads its own tile:
         // unconditional loads keep the staging registers out of scratch and the loop branch-free)
+        // Issued as inline asm: written as plain loads, LLVM sinks them (at IR level, below any
+        // sched_barrier) to just before the ds_writes at the end of the iteration, and every
+        // K-tile then waits out their full L2/HBM latency.  The asm loads are invisible to the
+        // compiler's s_waitcnt bookkeeping, so the wait before their first use is explicit below
+        // and names every destination register (cdna_hip_programming.md 5.7, form ii).
         const size_t koff = (size_t)(kt + 1 < KT ? kt + 1 : kt) * KT_BYTES;
-#pragma unroll
-        for (int s = 0; s < SA; ++s) ra4[s] = *reinterpret_cast<const float4*>(ag[s] + koff);
-#pragma unroll
-        for (int s = 0; s < SB; ++s) rb4[s] = *reinterpret_cast<const float4*>(bg[s] + koff);
+#define DCE_GLOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
+        DCE_GLOAD16(ra0, ag[0] + koff); DCE_GLOAD16(ra1, ag[1] + koff);
+        DCE_GLOAD16(rb0, bg[0] + koff); DCE_GLOAD16(rb1, bg[1] + koff);
+        if constexpr (SA == 4) {
+            DCE_GLOAD16(ra2, ag[2] + koff); DCE_GLOAD16(ra3, ag[3] + koff);
+            DCE_GLOAD16(rb2, bg[2] + koff); DCE_GLOAD16(rb3, bg[3] + koff);
+        }
+#undef DCE_GLOAD16
 
         const char* as = As + cur * Cfg::A_BYTES + fa;
         const char* bs = Bs + cur * Cfg::B_BYTES + fb;
@@ -168,10 +182,16 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         }
         char* ad = As + (cur ^ 1) * Cfg::A_BYTES + sdst;
         char* bd = Bs + (cur ^ 1) * Cfg::B_BYTES + sdst;
-#pragma unroll
-        for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(ad + 32 * s * LDR) = ra4[s];
-#pragma unroll
-        for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(bd + 32 * s * LDR) = rb4[s];
+        if constexpr (SA == 4) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(ra2), "+v"(ra3),
+                                                "+v"(rb0), "+v"(rb1), "+v"(rb2), "+v"(rb3));
+            *reinterpret_cast<v4f*>(ad + 64 * LDR) = ra2; *reinterpret_cast<v4f*>(ad + 96 * LDR) = ra3;
+            *reinterpret_cast<v4f*>(bd + 64 * LDR) = rb2; *reinterpret_cast<v4f*>(bd + 96 * LDR) = rb3;
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1));
+        }
+        *reinterpret_cast<v4f*>(ad) = ra0; *reinterpret_cast<v4f*>(ad + 32 * LDR) = ra1;
+        *reinterpret_cast<v4f*>(bd) = rb0; *reinterpret_cast<v4f*>(bd + 32 * LDR) = rb1;
         __syncthreads();
     }
 

@@ -20,7 +20,8 @@ torch.cuda.synchronize()
 lib = _lib.load()
 nb = B // 2
 buf = np.zeros((nb, 16), np.uint64)
-rc = lib.dce_debug_trace_read(buf.ctypes.data_as(C.c_void_p), nb)
+reader = lib.dce_debug_trace_read if os.environ.get('DCE_CONV') == 'direct' else lib.dce_debug_trace_read_wino
+rc = reader(buf.ctypes.data_as(C.c_void_p), nb)
 assert rc == 0
 t = buf[:, :10].astype(np.int64)
 hw = buf[:, 10].astype(np.int64)
