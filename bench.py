@@ -35,6 +35,10 @@ FLOP = {
     "fc2_gemm": 2 * 2048 * 512,                                      #  2,097,152
     "fc3_tail": 2 * 512 * 16,                                        #     16,384
 }
+# MFMA FLOPs actually executed per window by the shipped kernels (Winograd F(2,3) conv stack:
+# 4 waves x 3120 v_mfma_f32_16x16x4 x 2048 FLOP per 2 windows; GEMMs execute exactly 2*M*N*K)
+EXEC_FLOP = {"conv_stack": 4 * 3120 * 2048 // 2, "fc1_gemm": 2 * 4736 * 2048, "fc2_gemm": 2 * 2048 * 512,
+             "fc3_tail": 2 * 512 * 16}
 # algorithmic HBM bytes per window per kernel (inputs read once + outputs written once)
 BYTES = {
     "conv_stack": 150 * 54 * 4 + 4736 * 4,
@@ -195,6 +199,7 @@ def main():
                 "tflops": FLOP[k] * B / (avg_ms * 1e-3) / 1e12,
                 "frac_fp32_mfma_peak": FLOP[k] * B / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 "algorithmic_GBs": BYTES[k] * B / (avg_ms * 1e-3) / 1e9,
+                "executed_mfma_tflops": EXEC_FLOP[k] * B / (avg_ms * 1e-3) / 1e12,
             }
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
         traffic = None

@@ -25,7 +25,7 @@
 //
 // LDS layout: row = channel, row stride RS; window w occupies WSEG floats: index 0 = x[-1] = 0,
 // index 1+t = x[t], index T+1 (and T+2) = 0.  Pair m reads indices 2m .. 2m+3 (8-byte aligned).
-//   stage 1 (T=150): WSEG 152, RS 304, 75 pairs/window       stage 2 (T=75): WSEG 78, RS 156, 38 pairs
+//   stage 1 (T=150): WSEG 152, RS 306, 75 pairs/window       stage 2 (T=75): WSEG 78, RS 156, 38 pairs
 #include "conv_common.h"
 #include <cstdlib>
 
@@ -33,9 +33,10 @@ namespace dce {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WS1 = 152, RS1 = 2 * WS1, TP1 = 75;
+constexpr int WS1 = 152, RS1 = 2 * WS1 + 2, TP1 = 75;   // RS1 = 306: the transposing prologue stores
+                                                        // (lane = channel) then hit 16 banks, not 2
 constexpr int WS2 = 78,  RS2 = 2 * WS2, TP2 = 38;
-constexpr int WACT_FLOATS = 128 * RS2;                       // 19,968 floats (>= 64*RS1 = 19,456)
+constexpr int WACT_FLOATS = 128 * RS2;                       // 19,968 floats (>= 64*RS1 = 19,584)
 constexpr int WLDS_FLOATS = WACT_FLOATS + 384;               // + biases = 81,408 B
 constexpr int WRED_ROW = 56;                                 // fp64 z-score scratch: rows 56..63 of stage 1
 static_assert(64 * RS1 <= WACT_FLOATS && WLDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
@@ -43,6 +44,9 @@ static_assert(NW * 4 * 216 <= 8 * RS1 && (WRED_ROW * RS1) % 2 == 0, "z-score scr
 constexpr int MT = 2, NTW = 5;                               // row / column tiles per wave
 #ifndef WINO_EXP
 #define WINO_EXP 0           // bit flags for tools/micro/wino_loop.hip ablations; 0 in the product
+#endif
+#ifndef WINO_PK
+#define WINO_PK 1            // input transform with v_pk_add_f32 (3 instead of 4 VALU ops per tile): -2.3 % kernel time
 #endif
 #ifndef WINO_PF
 #define WINO_PF 2            // LDS prefetch distance of the main loop, in column tiles (2 or 3)
@@ -109,9 +113,18 @@ __device__ __forceinline__ float4 load_quad(const float* __restrict__ p)
 //   xrow : act + (lane>>4)*RS               (this lane's channel within the K-step)
 //   boff : per column tile, this lane's float offset of pair m inside a row (w*WSEG + 2m)
 //   ap   : packed weights of this wave's row-tile pair, + 2*lane float4
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 wino_v(const float4 r)
 {
+#if WINO_PK
+    // two packed adds: (v0,v3) = (d0,d1) - (d2,d3);  (v1,v2) = (d2,d2) + (d1,-d1)
+    const v2f p = {r.x, r.y}, q = {r.z, r.w};
+    const v2f a = p - q;
+    const v2f b = v2f{q.x, q.x} + v2f{p.y, -p.y};
+    return make_float4(a.x, b.x, b.y, a.y);
+#else
     return make_float4(r.x - r.z, r.y + r.z, r.z - r.y, r.y - r.w);
+#endif
 }
 
 template <int RS, int STEPS>
