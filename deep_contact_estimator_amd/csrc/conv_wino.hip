@@ -46,7 +46,7 @@ constexpr int MT = 2, NTW = 5;                               // row / column til
 #define WINO_EXP 0           // bit flags for tools/micro/wino_loop.hip ablations; 0 in the product
 #endif
 #ifndef WINO_PK
-#define WINO_PK 1            // input transform with v_pk_add_f32 (3 instead of 4 VALU ops per tile): -2.3 % kernel time
+#define WINO_PK 2            // 2: input transform as two hand-written v_pk_add_f32; 1: compiler-chosen packed adds
 #endif
 #ifndef WINO_PF
 #define WINO_PF 2            // LDS prefetch distance of the main loop, in column tiles (2 or 3)
@@ -114,71 +114,90 @@ __device__ __forceinline__ float4 load_quad(const float* __restrict__ p)
 //   boff : per column tile, this lane's float offset of pair m inside a row (w*WSEG + 2m)
 //   ap   : packed weights of this wave's row-tile pair, + 2*lane float4
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float4 wino_v(const float4 r)
+struct Quad { v2f p, q; };               // (d0,d1), (d2,d3) = x[2m-1..2m+2]
+struct V4 { v2f a, b; };                 // a = (v0,v3), b = (v1,v2)
+
+__device__ __forceinline__ Quad load_quad2(const float* __restrict__ ptr)
 {
-#if WINO_PK
-    // two packed adds: (v0,v3) = (d0,d1) - (d2,d3);  (v1,v2) = (d2,d2) + (d1,-d1)
-    const v2f p = {r.x, r.y}, q = {r.z, r.w};
-    const v2f a = p - q;
-    const v2f b = v2f{q.x, q.x} + v2f{p.y, -p.y};
-    return make_float4(a.x, b.x, b.y, a.y);
-#else
-    return make_float4(r.x - r.z, r.y + r.z, r.z - r.y, r.y - r.w);
-#endif
+    Quad r;
+    r.p = *reinterpret_cast<const v2f*>(ptr);
+    r.q = *reinterpret_cast<const v2f*>(ptr + 2);
+    return r;
 }
 
+// Winograd input transform in exactly two packed adds:
+//   a = (d0,d1) - (d2,d3) = (v0, v3)          b = (d1 + d2, d2 - d1) = (v1, v2)
+__device__ __forceinline__ V4 wino_v(const Quad r)
+{
+    V4 v;
+#if WINO_PK == 2
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v.a) : "v"(r.p), "v"(r.q));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(v.b) : "v"(r.p), "v"(r.q));
+#else
+    v.a = r.p - r.q;
+    v.b = v2f{r.q.x, r.q.x} + v2f{r.p.y, -r.p.y};
+#endif
+    return v;
+}
+
+// One K-step (5 column tiles x 8 MFMAs) of the pipelined main loop; see wino_mfma.
+template <int RS>
+__device__ __forceinline__ void wino_step(const float* __restrict__ xs, const float* __restrict__ xn,
+                                          const int (&boff)[NTW], const A8 a,
+                                          V4& vcur, Quad& rawb, f32x4 (&acc)[MT][NTW][4])
+{
+    const float a0[4] = {a.m0.x, a.m0.y, a.m0.z, a.m0.w};
+    const float a1[4] = {a.m1.x, a.m1.y, a.m1.z, a.m1.w};
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const float* pc = nt + 2 < NTW ? xs + boff[nt + 2] : xn + boff[nt + 2 - NTW];
+#if WINO_EXP & 2
+        const Quad rawc = rawb; (void)pc;                  // experiment: no LDS reads
+#else
+        const Quad rawc = load_quad2(pc);                  // tile i+2
+#endif
+        const V4 vnxt = wino_v(rawb);                      // tile i+1
+        __builtin_amdgcn_sched_barrier(0);
+        const float v[4] = {vcur.a.x, vcur.b.x, vcur.b.y, vcur.a.y};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[0][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], v[c], acc[0][nt][c], 0, 0, 0);
+            acc[1][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], v[c], acc[1][nt][c], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        vcur = vnxt;
+        rawb = rawc;
+    }
+}
+
+// One layer's main loop for one wave, software-pipelined by hand at column-tile granularity
+// (a tile = 8 MFMAs = 256 matrix-pipe cycles):
+//     tile i   : 8 MFMAs on V(i), computed one tile earlier  -> no VALU->MFMA wait states
+//     tile i+1 : 2 packed adds form V(i+1) from the raw quad loaded one tile earlier
+//     tile i+2 : its raw quad is requested from LDS now
+// and the weights (2 x 16 B from L2) of K-step s+1 / s+2 are requested at the top of step s / s+1.
+// sched_barrier(0) pins this order: left alone, hipcc sinks every load to just before its use
+// (measured: a lone wave then reaches only 55 % of the MFMA issue rate).  Two K-steps per loop
+// iteration, so the rotating registers (V, raw quad, weights) return to their starting names
+// and the back-edge needs no copies.
+//   xrow : act + (lane>>4)*RS               (this lane's channel within the K-step)
+//   boff : per column tile, this lane's float offset of pair m inside a row (w*WSEG + 2m)
+//   ap   : packed weights of this wave's row-tile pair, + 2*lane float4
 template <int RS, int STEPS>
 __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const int (&boff)[NTW],
-                                          const float4* __restrict__ ap, A8 acur,
+                                          const float4* __restrict__ ap, A8 a_even,
                                           f32x4 (&acc)[MT][NTW][4])
 {
-    float4 vcur = wino_v(load_quad(xrow + boff[0]));      // V of tile (0,0)
-    float4 rawb = load_quad(xrow + boff[1]);              // raw of tile (0,1)
-#if WINO_PF >= 3
-    float4 rawc = load_quad(xrow + boff[2]);              // raw of tile (0,2)
-#endif
+    static_assert(STEPS % 2 == 0, "two K-steps per iteration");
+    V4 vcur = wino_v(load_quad2(xrow + boff[0]));         // V of tile (0,0)
+    Quad rawb = load_quad2(xrow + boff[1]);               // raw of tile (0,1)
 #pragma unroll 1
-    for (int s = 0; s < STEPS; ++s) {
-        const int sn = s + 1 < STEPS ? s + 1 : s;         // last step: harmless re-reads
-#if WINO_EXP & 1
-        const A8 anxt = acur;                               // experiment: no weight loads
-#else
-        const A8 anxt = load_a8(ap, sn);
-#endif
-        const float* xs = xrow + s * 4 * RS;
-        const float* xn = xrow + sn * 4 * RS;
-        const float a0[4] = {acur.m0.x, acur.m0.y, acur.m0.z, acur.m0.w};
-        const float a1[4] = {acur.m1.x, acur.m1.y, acur.m1.z, acur.m1.w};
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            constexpr int D = WINO_PF;                    // LDS prefetch distance in tiles
-            const float* pc = nt + D < NTW ? xs + boff[(nt + D) % NTW] : xn + boff[(nt + D) % NTW];
-#if WINO_EXP & 2
-            const float4 rawn = rawb; (void)pc;            // experiment: no LDS reads
-#else
-            const float4 rawn = load_quad(pc);            // tile i+D
-#endif
-#if WINO_EXP & 4
-            const float4 vnxt = rawb;                      // experiment: no input transform
-#else
-            const float4 vnxt = wino_v(rawb);             // tile i+1
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            const float v[4] = {vcur.x, vcur.y, vcur.z, vcur.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[0][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], v[c], acc[0][nt][c], 0, 0, 0);
-                acc[1][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], v[c], acc[1][nt][c], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            vcur = vnxt;
-#if WINO_PF >= 3
-            rawb = rawc; rawc = rawn;
-#else
-            rawb = rawn;
-#endif
-        }
-        acur = anxt;
+    for (int s = 0; s < STEPS; s += 2) {
+        const int s2 = s + 2 < STEPS ? s + 2 : s;         // last iteration: harmless re-reads
+        const A8 a_odd = load_a8(ap, s + 1);
+        wino_step<RS>(xrow + s * 4 * RS, xrow + (s + 1) * 4 * RS, boff, a_even, vcur, rawb, acc);
+        a_even = load_a8(ap, s2);
+        wino_step<RS>(xrow + (s + 1) * 4 * RS, xrow + s2 * 4 * RS, boff, a_odd, vcur, rawb, acc);
     }
 }
 
