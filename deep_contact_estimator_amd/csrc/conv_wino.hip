@@ -48,6 +48,9 @@ constexpr int MT = 2, NTW = 5;                               // row / column til
 #ifndef WINO_PK
 #define WINO_PK 2            // 2: input transform as two hand-written v_pk_add_f32; 1: compiler-chosen packed adds
 #endif
+#ifndef WINO_PHASE_PRIO
+#define WINO_PHASE_PRIO 0    // s_setprio level of the non-MFMA phases (0 = leave priorities alone)
+#endif
 #ifndef WINO_PF
 #define WINO_PF 2            // LDS prefetch distance of the main loop, in column tiles (2 or 3)
 #endif
@@ -189,6 +192,9 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
                                           f32x4 (&acc)[MT][NTW][4])
 {
     static_assert(STEPS % 2 == 0, "two K-steps per iteration");
+#if WINO_PHASE_PRIO
+    __builtin_amdgcn_s_setprio(0);                        // MFMA phase: yield issue slots to a partner
+#endif                                                    // workgroup that is loading / writing back
     V4 vcur = wino_v(load_quad2(xrow + boff[0]));         // V of tile (0,0)
     Quad rawb = load_quad2(xrow + boff[1]);               // raw of tile (0,1)
 #pragma unroll 1
@@ -199,6 +205,9 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
         a_even = load_a8(ap, s2);
         wino_step<RS>(xrow + (s + 1) * 4 * RS, xrow + s2 * 4 * RS, boff, a_odd, vcur, rawb, acc);
     }
+#if WINO_PHASE_PRIO
+    __builtin_amdgcn_s_setprio(WINO_PHASE_PRIO);          // short, latency-critical phases (barrier,
+#endif                                                    // write-back, next layer's set-up) go first
 }
 
 // bias -> initial value of component 1 (it enters y[2m] and y[2m+1] with +1); others start at 0
@@ -322,6 +331,9 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
     const int64_t win0 = (int64_t)blockIdx.x * NW;
     const int nvalid = (n - win0) < NW ? (int)(n - win0) : NW;
 
+#if WINO_PHASE_PRIO
+    __builtin_amdgcn_s_setprio(WINO_PHASE_PRIO);
+#endif
     TRACE_MARK(0);
 #if DCE_TRACE
     if (tid == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
