@@ -138,28 +138,20 @@ def main():
     windows = model.zscore_windows(seq, 0, B)
     torch.cuda.synchronize()
 
-    gather_bufs = [None, None]
-    logits_keep = [None, None]
-    handles = [None, None]
-    if world > 1 and rank == 0:
-        gather_bufs = [[torch.empty((B, 16), dtype=torch.float32, device=dev) for _ in range(world)]
-                       for _ in range(2)]
+    gatherer = None
+    if world > 1:
+        from deep_contact_estimator_amd.distributed import AsyncRowGather
+        gatherer = AsyncRowGather(B, 16, torch.float32, dev, dst=0, depth=2)
 
     def step(i):
         out = model.predict(windows)
-        if world > 1:
-            s = i & 1
-            if handles[s] is not None:
-                handles[s].wait()
-            logits_keep[s] = out["logits"]
-            handles[s] = dist.gather(out["logits"], gather_bufs[s] if rank == 0 else None, dst=0, async_op=True)
+        if gatherer is not None:
+            gatherer.submit(out["logits"])
         return out
 
     def drain():
-        for s in (0, 1):
-            if handles[s] is not None:
-                handles[s].wait()
-                handles[s] = None
+        if gatherer is not None:
+            gatherer.drain()
 
     for i in range(args.warmup):
         out = step(i)

@@ -258,6 +258,30 @@ class contact_cnn:
                                                 out.ctypes.data_as(C.c_void_p)), ctx)
         return out
 
+    def confusion_counts(self, pred, labels, counts=None):
+        """Accumulate the 16x16 confusion counts C[gt][pred] on the device (dce_confusion_counts).
+        pred: (n,) int32 numpy / CUDA tensor from predict() / infer_sequence(); labels: (n,) or
+        (n,1) int64.  Returns (and, if given, updates) `counts`: (16,16) int64, same kind as pred."""
+        ctx = self._ensure_ctx()
+        if _is_torch(pred) and pred.is_cuda:
+            import torch
+            pred = pred.contiguous().to(torch.int32)
+            labels = labels.to(pred.device).contiguous().to(torch.int64).reshape(-1)
+            if counts is None:
+                counts = torch.zeros((16, 16), dtype=torch.int64, device=pred.device)
+            _lib.check(self._lib.dce_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream), 0), ctx)
+            _lib.check(self._lib.dce_confusion_counts(ctx, C.c_void_p(pred.data_ptr()), C.c_void_p(labels.data_ptr()),
+                                                      pred.shape[0], 1, C.c_void_p(counts.data_ptr())), ctx)
+            return counts
+        p = np.ascontiguousarray(pred.numpy() if _is_torch(pred) else pred, dtype=np.int32).reshape(-1)
+        g = np.ascontiguousarray(labels.numpy() if _is_torch(labels) else labels, dtype=np.int64).reshape(-1)
+        if counts is None:
+            counts = np.zeros((16, 16), np.int64)
+        _lib.check(self._lib.dce_set_stream(ctx, None, 1), ctx)
+        _lib.check(self._lib.dce_confusion_counts(ctx, p.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p),
+                                                  p.shape[0], 0, counts.ctypes.data_as(C.c_void_p)), ctx)
+        return counts
+
     # ---- profiling (bench.py) ---------------------------------------------------------------
     def profile(self, on: bool = True):
         _lib.check(self._lib.dce_profile_enable(self._ensure_ctx(), int(on)), self._ctx)

@@ -436,6 +436,32 @@ int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
     return DCE_OK;
 }
 
+int dce_confusion_counts(dce_ctx* c, const int32_t* pred, const int64_t* labels, int64_t n,
+                         int on_device, int64_t* counts)
+{
+    if (!c) return DCE_ERR_ARG;
+    if (n < 0 || !counts || (n > 0 && (!pred || !labels))) return fail(c, DCE_ERR_ARG, "dce_confusion_counts: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n == 0) return DCE_OK;
+    if (on_device) {
+        HIP_TRY(c, launch_confusion16(pred, labels, n, reinterpret_cast<unsigned long long*>(counts), c->stream));
+        return DCE_OK;
+    }
+    const size_t pb = (size_t)n * sizeof(int32_t), lb = (size_t)n * sizeof(int64_t), cb = 256 * sizeof(int64_t);
+    const size_t lo = (pb + 255) & ~size_t(255), co = lo + ((lb + 255) & ~size_t(255));
+    int rc = ensure_in(c, co + cb);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(c->d_in);
+    HIP_TRY(c, hipMemcpyAsync(base, pred, pb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + lo, labels, lb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + co, counts, cb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, launch_confusion16(reinterpret_cast<int32_t*>(base), reinterpret_cast<int64_t*>(base + lo), n,
+                                  reinterpret_cast<unsigned long long*>(base + co), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(counts, base + co, cb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DCE_OK;
+}
+
 int dce_profile_enable(dce_ctx* c, int on)
 {
     if (!c) return DCE_ERR_ARG;

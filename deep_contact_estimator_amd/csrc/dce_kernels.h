@@ -57,4 +57,8 @@ hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, 
 hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,
                            float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st);
 
+// counts[gt*16 + pred] += 1 over n (pred, label) pairs; out-of-range classes are skipped
+hipError_t launch_confusion16(const int32_t* pred, const int64_t* label, int64_t n,
+                              unsigned long long* counts, hipStream_t st);
+
 }  // namespace dce

@@ -343,4 +343,35 @@ hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, in
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// 16x16 class confusion counts C[gt][pred] -- the sufficient statistic of every metric the
+// reference's src/test.py:19-70 prints (per-leg 2x2 confusion, FN/FP rates, precision, Jaccard,
+// class / leg accuracy).  Integer histogram: LDS atomics per block, one global atomic per bin.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void confusion16_kernel(const int32_t* __restrict__ pred, const int64_t* __restrict__ label,
+                        int64_t n, unsigned long long* __restrict__ counts)
+{
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int p = pred[i];
+        const int64_t g = label[i];
+        if (p >= 0 && p < 16 && g >= 0 && g < 16) atomicAdd(&h[(int)g * 16 + p], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+hipError_t launch_confusion16(const int32_t* pred, const int64_t* label, int64_t n,
+                              unsigned long long* counts, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(confusion16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, label, n, counts);
+    return hipGetLastError();
+}
+
 }  // namespace dce

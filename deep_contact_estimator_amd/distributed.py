@@ -66,3 +66,45 @@ def infer_sequence_sharded(run, seq, group=None, dst: int = 0):
     out = run(seq[r0:r1])
     res = {k: gather_rows(v, group, dst) for k, v in out.items()}
     return res if rank == dst else None
+
+
+class AsyncRowGather:
+    """The per-step result exchange of bench.py / a serving loop: gather every rank's (rows, cols)
+    block to rank `dst` asynchronously, `depth` gathers in flight, so step i's gather rides behind
+    step i+1's kernels.  The submitted tensor is kept alive until its gather has completed; on
+    `dst`, `latest()` returns the most recently completed list of per-rank blocks."""
+
+    def __init__(self, rows: int, cols: int, dtype, device, group=None, dst: int = 0, depth: int = 2):
+        import torch
+        import torch.distributed as dist
+        self.group, self.dst, self.depth = group, dst, depth
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._bufs = [[torch.empty((rows, cols), dtype=dtype, device=device) for _ in range(self.world)]
+                      if self.rank == dst else None for _ in range(depth)]
+        self._handles = [None] * depth
+        self._keep = [None] * depth
+        self._i = 0
+        self._done = None
+
+    def _wait(self, s):
+        if self._handles[s] is not None:
+            self._handles[s].wait()
+            self._handles[s] = None
+            self._keep[s] = None
+            self._done = s
+
+    def submit(self, t):
+        import torch.distributed as dist
+        s = self._i % self.depth
+        self._wait(s)                         # slot free again (its buffers may be overwritten)
+        self._keep[s] = t
+        self._handles[s] = dist.gather(t, self._bufs[s], dst=self.dst, group=self.group, async_op=True)
+        self._i += 1
+
+    def drain(self):
+        for k in range(self.depth):           # oldest first, so `latest` ends on the newest
+            self._wait((self._i + k) % self.depth)
+
+    def latest(self):
+        return None if self._done is None or self.rank != self.dst else self._bufs[self._done]

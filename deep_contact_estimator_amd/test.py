@@ -3,9 +3,10 @@
     python -m deep_contact_estimator_amd.test --config_name config/test_params.yaml
 
 Same YAML keys (data_folder, model_load_path, window_size, batch_size); runs compute_accuracy
-over <data_folder>/test.npy + test_label.npy and prints the accuracy block.  The sklearn
-precision / Jaccard / confusion-matrix post-processing (src/test.py:19-70,137-220) is CPU
-analysis on the returned arrays and out of scope; the arrays are returned unchanged so the
+over <data_folder>/test.npy + test_label.npy and prints the accuracy block.  The
+precision / Jaccard / confusion-matrix numbers the reference gets from scikit-learn
+(src/test.py:19-70,137-139) are closed forms of one 16x16 integer matrix accumulated on the
+device (dce_confusion_counts + metrics.py); the float64 arrays are still returned unchanged so the
 reference's own functions can consume them.
 """
 from __future__ import annotations
@@ -48,6 +49,19 @@ def main(argv=None):
     for leg in range(4):
         print("Accuracy of leg %d is: %.4f" % (leg, acc_per_leg[leg]))
     print("Accuracy is: %.4f" % (np.sum(acc_per_leg) / 4.0))
+
+    # precision / Jaccard / confusion matrices (src/test.py:137-139) from ONE 16x16 integer matrix
+    # accumulated on the device (dce_confusion_counts) -- no sklearn, no per-window D2H
+    from . import metrics
+    C = model.confusion_counts(model.infer_sequence(test_data.data)["pred"],
+                               test_data.label[test_data.window_size - 1:])
+    mt = metrics.metrics_from_confusion16(C.cpu().numpy())
+    print("Precision of class: %.4f, of legs: %s, of all legs: %.4f" % (
+        mt["precision_of_class"], np.round(mt["precision_of_legs"], 4).tolist(), mt["precision_of_all_legs"]))
+    print("Jaccard of class: %.4f, of legs: %s, of all legs: %.4f" % (
+        mt["jaccard_of_class"], np.round(mt["jaccard_of_legs"], 4).tolist(), mt["jaccard_of_all_legs"]))
+    print("Confusion matrix (all legs):\n", mt["confusion_mat"]["total"])
+    print("False negative rate: %s\nFalse positive rate: %s" % (mt["fn_rate"], mt["fp_rate"]))
     return test_acc, acc_per_leg, bin_pred_arr, bin_gt_arr, pred_arr, gt_arr
 
 

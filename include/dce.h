@@ -115,6 +115,15 @@ int  dce_zscore_windows(dce_ctx* ctx, const float* seq, int64_t T, int64_t first
 int  dce_forward_taps(dce_ctx* ctx, const float* windows, int64_t n, int on_device,
                       float* feat, float* h1, float* h2, float* logits);
 
+/* "Next" row after the path (reference src/test.py:19-70,102-104; src/inference_one_seq.py:48-54):
+ * accumulate the 16x16 class confusion counts  counts[gt*16 + pred] += 1  over n windows.
+ * pred: (n) i32 as written by dce_forward_windows / dce_infer_sequence; labels: (n) or (n,1) i64
+ * decimal contact labels (utils/mat2numpy.py:199-200); counts: 256 x i64, ACCUMULATED (zero it
+ * first).  Every metric the reference prints is a function of this matrix (see metrics.py);
+ * across GPUs the matrices simply add (one all-reduce of 2 KB).  Classes outside [0,16) are skipped. */
+int  dce_confusion_counts(dce_ctx* ctx, const int32_t* pred, const int64_t* labels, int64_t n,
+                          int on_device, int64_t* counts);
+
 /* Kernel timing with HIP events on the ctx's stream, for bench.py's roofline block.
  * Enables per-kernel event recording for subsequent forward calls; dce_profile_read
  * synchronises and returns the accumulated milliseconds and launch counts since the

@@ -151,6 +151,32 @@ def edge_cases():
     print("edge: const-channel pred", p.numpy(), "tie pred", ptie.numpy())
 
 
+def metrics_case():
+    """Golden values of the reference's metric functions (src/test.py:19-70, scikit-learn) on the
+    seq_normal predictions against (a) the synthetic labels and (b) labels that agree with the
+    predictions 70 % of the time, so that every rate is non-trivial."""
+    g = np.load(os.path.join(HERE, "seq_normal.npz"))
+    pred = g["pred"].astype(np.int64)
+    rng = np.random.default_rng(77)
+    lab_b = np.where(rng.random(pred.size) < 0.7, pred, rng.integers(0, 16, pred.size))
+    out = {}
+    for tag, gt in (("a", g["labels"].astype(np.int64)), ("b", lab_b)):
+        bin_pred = ref_test.decimal2binary(torch.from_numpy(pred)).numpy().astype(np.float64)
+        bin_gt = ref_test.decimal2binary(torch.from_numpy(gt)).numpy().astype(np.float64)
+        cm, fn, fp = ref_test.compute_confusion_mat(bin_pred, bin_gt)
+        pc, pl, pa = ref_test.compute_precision(bin_pred, bin_gt, pred.astype(np.float64), gt.astype(np.float64))
+        jc, jl, ja = ref_test.compute_jaccard(bin_pred, bin_gt, pred.astype(np.float64), gt.astype(np.float64))
+        names = ("leg_rf", "leg_lf", "leg_rh", "leg_lh", "total")
+        out.update({
+            f"{tag}_labels": gt, f"{tag}_cm": np.stack([cm[k] for k in names]),
+            f"{tag}_total_ratio": cm["total_ratio"],
+            f"{tag}_fn": np.array([fn[k] for k in names]), f"{tag}_fp": np.array([fp[k] for k in names]),
+            f"{tag}_precision": np.array([pc, *pl, pa]), f"{tag}_jaccard": np.array([jc, *jl, ja]),
+        })
+    np.savez_compressed(os.path.join(HERE, "metrics_seq_normal.npz"), pred=pred.astype(np.int32), **out)
+    print("metrics: precision(b)", out["b_precision"], "jaccard(b)", out["b_jaccard"])
+
+
 if __name__ == "__main__":
     # case A: N(0,1) sequence, biased He weights, batch 30 (config/test_params.yaml:9), 1-D labels
     run_case("seq_normal", wseed=1, bias="uniform", T=150 + 255, sseed=0, kind="normal",
@@ -160,3 +186,4 @@ if __name__ == "__main__":
     run_case("seq_ar1", wseed=2, bias="zero", T=150 + 127, sseed=5, kind="ar1",
              batch=1, label_2d=True)
     edge_cases()
+    metrics_case()

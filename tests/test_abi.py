@@ -83,3 +83,25 @@ def test_state_dict_validation_and_decimal2binary():
     torch = pytest.importorskip("torch")
     t = decimal2binary(torch.arange(16))
     assert t.dtype == torch.uint8 and np.array_equal(t.numpy(), decimal2binary(np.arange(16)))
+
+
+def test_metrics_from_confusion_match_reference_sklearn(golden):
+    """metrics.py (closed forms of the 16x16 matrix) vs the reference's own scikit-learn metric
+    functions (src/test.py:19-70), whose outputs are committed in tests/golden/metrics_seq_normal.npz."""
+    from deep_contact_estimator_amd import metrics
+    g = golden("metrics_seq_normal")
+    names = ("leg_rf", "leg_lf", "leg_rh", "leg_lh", "total")
+    for tag in ("a", "b"):
+        C = metrics.confusion16(g["pred"], g[f"{tag}_labels"])
+        assert C.sum() == g["pred"].size
+        m = metrics.metrics_from_confusion16(C)
+        assert np.array_equal(np.stack([m["confusion_mat"][k] for k in names]), g[f"{tag}_cm"])
+        np.testing.assert_allclose(m["confusion_mat"]["total_ratio"], g[f"{tag}_total_ratio"], rtol=1e-12)
+        np.testing.assert_allclose([m["fn_rate"][k] for k in names], g[f"{tag}_fn"], rtol=1e-12)
+        np.testing.assert_allclose([m["fp_rate"][k] for k in names], g[f"{tag}_fp"], rtol=1e-12)
+        got_p = [m["precision_of_class"], *m["precision_of_legs"], m["precision_of_all_legs"]]
+        got_j = [m["jaccard_of_class"], *m["jaccard_of_legs"], m["jaccard_of_all_legs"]]
+        np.testing.assert_allclose(got_p, g[f"{tag}_precision"], rtol=1e-12)
+        np.testing.assert_allclose(got_j, g[f"{tag}_jaccard"], rtol=1e-12)
+        acc = (g["pred"] == g[f"{tag}_labels"]).mean()
+        assert abs(m["acc"] - acc) < 1e-15

@@ -1,0 +1,45 @@
+"""GPU: BASELINE.json configs[0] -- the reference's entry scripts' plumbing on the mirrored CLI:
+unchanged YAML keys, .npy inputs, a checkpoint in the reference's torch schema, 16-class output."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_entry_scripts_on_synthetic_config(tmp_path):
+    from deep_contact_estimator_amd import synth
+    from oracle import oracle as orc
+    out = tmp_path / "synthetic_data"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_data.py"), "--out", str(out),
+                    "--T", str(150 + 299)], check=True, capture_output=True)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "inference_one_seq_params.yaml")))
+    for k in ("data_path", "label_path", "mat_data_path", "model_load_path", "mat_save_path", "lcm_save_path"):
+        cfg[k] = cfg[k].replace("synthetic_data", str(out))
+    cfg["save_mat"] = True
+    cfg_path = tmp_path / "inference_one_seq_params.yaml"
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for extra in ([], ["--fused"]):
+        r = subprocess.run([sys.executable, "-m", "deep_contact_estimator_amd.inference_one_seq",
+                            "--config_name", str(cfg_path), *extra], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        contacts = np.load(os.path.splitext(cfg["mat_save_path"])[0] + ".npy")
+        ref = orc.Oracle(synth.make_state_dict(1, "uniform")).infer_sequence(
+            synth.make_sequence(150 + 299, 0).astype(np.float32))
+        assert contacts.shape == (300, 4) and contacts.dtype == np.uint8
+        assert np.array_equal(contacts, ref["contacts"])
+    tcfg = yaml.safe_load(open(os.path.join(ROOT, "config", "test_params.yaml")))
+    tcfg["data_folder"] = str(out) + "/"
+    tcfg["model_load_path"] = cfg["model_load_path"]
+    tpath = tmp_path / "test_params.yaml"
+    yaml.safe_dump(tcfg, open(tpath, "w"))
+    r = subprocess.run([sys.executable, "-m", "deep_contact_estimator_amd.test", "--config_name", str(tpath)],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Test accuracy in terms of class is:" in r.stdout and "Jaccard of class:" in r.stdout

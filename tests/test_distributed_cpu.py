@@ -66,3 +66,38 @@ def test_two_rank_gather_matches_single_process(T, tmp_path):
         synth.make_sequence(T, 17).astype(np.float32))
     for k in ("logits", "pred", "contacts"):
         assert np.array_equal(got[k], ref[k]), k
+
+
+def _gather_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from deep_contact_estimator_amd.distributed import AsyncRowGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = AsyncRowGather(8, 16, torch.float32, "cpu", dst=0, depth=2)
+    for step in range(5):                                   # more steps than slots: slots get reused
+        g.submit(torch.full((8, 16), float(100 * step + rank)))
+    g.drain()
+    if rank == 0:
+        got = torch.stack(g.latest()).numpy()
+        np.save(out_path, got)
+    else:
+        assert g.latest() is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_row_gather_two_ranks(tmp_path):
+    """bench.py's per-step logits exchange (2 gathers in flight) delivers, on rank 0, every rank's
+    block of the LAST submitted step."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_gather_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got.shape == (2, 8, 16)
+    assert (got[0] == 400.0).all() and (got[1] == 401.0).all()

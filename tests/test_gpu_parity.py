@@ -284,3 +284,32 @@ def test_reference_loop_api(golden, case_inputs, models, tmp_path):
     from torch.utils.data import DataLoader
     res3 = inf.inference(DataLoader(dataset=ds, batch_size=30), m, "cuda")
     assert np.array_equal(res3.cpu().numpy(), g["contacts"])
+
+
+def test_confusion_counts_on_device(golden, models):
+    """dce_confusion_counts: the 16x16 integer statistic behind every metric of src/test.py:19-70,
+    bit-exact vs its numpy definition; metrics derived from it equal the reference's sklearn values."""
+    import torch
+    from deep_contact_estimator_amd import metrics
+    m = models()
+    g = golden("metrics_seq_normal")
+    for tag in ("a", "b"):
+        C = m.confusion_counts(g["pred"], g[f"{tag}_labels"])
+        assert C.dtype == np.int64 and np.array_equal(C, metrics.confusion16(g["pred"], g[f"{tag}_labels"]))
+        got = metrics.metrics_from_confusion16(C)
+        np.testing.assert_allclose([got["precision_of_class"], *got["precision_of_legs"], got["precision_of_all_legs"]],
+                                   g[f"{tag}_precision"], rtol=1e-12)
+    # device pointers, accumulation over batches, (n,1) labels, out-of-range classes skipped, 1e6 rows
+    rng = np.random.default_rng(5)
+    n = 1_000_003
+    pred = rng.integers(0, 16, n).astype(np.int32)
+    lab = rng.integers(0, 16, n).astype(np.int64)
+    lab[::1000] = 99                                                  # not a contact class
+    ref = metrics.confusion16(pred[lab < 16], lab[lab < 16])
+    pd, ld = torch.from_numpy(pred).cuda(), torch.from_numpy(lab).cuda().reshape(-1, 1)
+    Cd = None
+    for lo in range(0, n, 300_000):                                   # accumulate over ragged batches
+        Cd = m.confusion_counts(pd[lo:lo + 300_000], ld[lo:lo + 300_000], Cd)
+    assert Cd.is_cuda and np.array_equal(Cd.cpu().numpy(), ref)
+    assert np.array_equal(m.confusion_counts(pred, lab), ref)          # host pointers
+    assert m.confusion_counts(pred[:0], lab[:0]).sum() == 0            # empty
