@@ -37,9 +37,10 @@ constexpr int WS1 = 152, RS1 = 2 * WS1 + 2, TP1 = 75;   // RS1 = 306: the transp
                                                         // (lane = channel) then hit 16 banks, not 2
 constexpr int WS2 = 78,  RS2 = 2 * WS2, TP2 = 38;
 constexpr int WACT_FLOATS = 128 * RS2;                       // 19,968 floats (>= 64*RS1 = 19,584)
-constexpr int WLDS_FLOATS = WACT_FLOATS + 384;               // + biases = 81,408 B
+constexpr int WLDS_FLOATS = WACT_FLOATS + 384 + 2;           // + biases + 2 NaN flags = 81,416 B
 constexpr int WRED_ROW = 56;                                 // fp64 z-score scratch: rows 56..63 of stage 1
 static_assert(64 * RS1 <= WACT_FLOATS && WLDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+static_assert(NW == 2, "per-window NaN flags are written for two windows");
 static_assert(NW * 4 * 216 <= 8 * RS1 && (WRED_ROW * RS1) % 2 == 0, "z-score scratch fits, 8-B aligned");
 constexpr int MT = 2, NTW = 5;                               // row / column tiles per wave
 #ifndef WINO_EXP
@@ -47,6 +48,9 @@ constexpr int MT = 2, NTW = 5;                               // row / column til
 #endif
 #ifndef WINO_PK
 #define WINO_PK 2            // 2: input transform as two hand-written v_pk_add_f32; 1: compiler-chosen packed adds
+#endif
+#ifndef WINO_PEEL
+#define WINO_PEEL 0          // peel the first two K-steps (no accumulator init); spills at 256 VGPRs
 #endif
 #ifndef WINO_PHASE_PRIO
 #define WINO_PHASE_PRIO 0    // s_setprio level of the non-MFMA phases (0 = leave priorities alone)
@@ -144,10 +148,14 @@ __device__ __forceinline__ V4 wino_v(const Quad r)
 }
 
 // One K-step (5 column tiles x 8 MFMAs) of the pipelined main loop; see wino_mfma.
-template <int RS>
+// FIRST: the layer's first K-step -- accumulators start from the literal 0 (an inline constant of the
+// MFMA's C operand) or, for component 1, from the bias (it enters y[2m] and y[2m+1] with +1), so no
+// accumulator-initialisation instructions are ever issued.
+template <int RS, bool FIRST>
 __device__ __forceinline__ void wino_step(const float* __restrict__ xs, const float* __restrict__ xn,
                                           const int (&boff)[NTW], const A8 a,
-                                          V4& vcur, Quad& rawb, f32x4 (&acc)[MT][NTW][4])
+                                          V4& vcur, Quad& rawb, f32x4 (&acc)[MT][NTW][4],
+                                          const f32x4 (&bias)[MT])
 {
     const float a0[4] = {a.m0.x, a.m0.y, a.m0.z, a.m0.w};
     const float a1[4] = {a.m1.x, a.m1.y, a.m1.z, a.m1.w};
@@ -164,8 +172,11 @@ __device__ __forceinline__ void wino_step(const float* __restrict__ xs, const fl
         const float v[4] = {vcur.a.x, vcur.b.x, vcur.b.y, vcur.a.y};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            acc[0][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], v[c], acc[0][nt][c], 0, 0, 0);
-            acc[1][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], v[c], acc[1][nt][c], 0, 0, 0);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 c0 = FIRST ? (c == 1 ? bias[0] : zero) : acc[0][nt][c];
+            const f32x4 c1 = FIRST ? (c == 1 ? bias[1] : zero) : acc[1][nt][c];
+            acc[0][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], v[c], c0, 0, 0, 0);
+            acc[1][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], v[c], c1, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         vcur = vnxt;
@@ -189,44 +200,53 @@ __device__ __forceinline__ void wino_step(const float* __restrict__ xs, const fl
 template <int RS, int STEPS>
 __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const int (&boff)[NTW],
                                           const float4* __restrict__ ap, A8 a_even,
+                                          const float* __restrict__ bias_lds, int co0, int lane,
                                           f32x4 (&acc)[MT][NTW][4])
 {
-    static_assert(STEPS % 2 == 0, "two K-steps per iteration");
+    static_assert(STEPS % 2 == 0 && STEPS >= 4, "two K-steps per iteration, first pair peeled");
 #if WINO_PHASE_PRIO
     __builtin_amdgcn_s_setprio(0);                        // MFMA phase: yield issue slots to a partner
 #endif                                                    // workgroup that is loading / writing back
+    f32x4 bias[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[mt][r] = bias_lds[co0 + 16 * mt + 4 * (lane >> 4) + r];
     V4 vcur = wino_v(load_quad2(xrow + boff[0]));         // V of tile (0,0)
     Quad rawb = load_quad2(xrow + boff[1]);               // raw of tile (0,1)
-#pragma unroll 1
-    for (int s = 0; s < STEPS; s += 2) {
-        const int s2 = s + 2 < STEPS ? s + 2 : s;         // last iteration: harmless re-reads
-        const A8 a_odd = load_a8(ap, s + 1);
-        wino_step<RS>(xrow + s * 4 * RS, xrow + (s + 1) * 4 * RS, boff, a_even, vcur, rawb, acc);
-        a_even = load_a8(ap, s2);
-        wino_step<RS>(xrow + (s + 1) * 4 * RS, xrow + s2 * 4 * RS, boff, a_odd, vcur, rawb, acc);
+#if WINO_PEEL
+    {   // K-steps 0 and 1: accumulators start from MFMA C-operand constants, no init instructions
+        const A8 a_odd = load_a8(ap, 1);
+        wino_step<RS, true>(xrow, xrow + 4 * RS, boff, a_even, vcur, rawb, acc, bias);
+        a_even = load_a8(ap, 2);
+        wino_step<RS, false>(xrow + 4 * RS, xrow + 8 * RS, boff, a_odd, vcur, rawb, acc, bias);
     }
-#if WINO_PHASE_PRIO
-    __builtin_amdgcn_s_setprio(WINO_PHASE_PRIO);          // short, latency-critical phases (barrier,
-#endif                                                    // write-back, next layer's set-up) go first
-}
-
-// bias -> initial value of component 1 (it enters y[2m] and y[2m+1] with +1); others start at 0
-__device__ __forceinline__ void wino_init(const float* __restrict__ bias_lds, int co0, int lane,
-                                          f32x4 (&acc)[MT][NTW][4])
-{
+    constexpr int S0 = 2;
+#else
+    // (peeling the first K-step pair would save these 160 moves per layer but costs more VGPRs
+    //  than the 256 available at two workgroups per CU: measured 56 dwords of spill)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        f32x4 b;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = bias_lds[co0 + 16 * mt + 4 * (lane >> 4) + r];
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             acc[mt][nt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[mt][nt][1] = b;
+            acc[mt][nt][1] = bias[mt];
             acc[mt][nt][2] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[mt][nt][3] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    constexpr int S0 = 0;
+#endif
+#pragma unroll 1
+    for (int s = S0; s < STEPS; s += 2) {
+        const int s2 = s + 2 < STEPS ? s + 2 : s;         // last iteration: harmless re-reads
+        const A8 a_odd = load_a8(ap, s + 1);
+        wino_step<RS, false>(xrow + s * 4 * RS, xrow + (s + 1) * 4 * RS, boff, a_even, vcur, rawb, acc, bias);
+        a_even = load_a8(ap, s2);
+        wino_step<RS, false>(xrow + (s + 1) * 4 * RS, xrow + s2 * 4 * RS, boff, a_odd, vcur, rawb, acc, bias);
     }
+#if WINO_PHASE_PRIO
+    __builtin_amdgcn_s_setprio(WINO_PHASE_PRIO);          // short, latency-critical phases go first
+#endif
 }
 
 // column n = w*TP + m of a layout with TP pairs per window -> float offset of pair m (0 for fillers)
@@ -261,8 +281,8 @@ __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const 
                     const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
                     const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
                     float* d = act + (co0 + 16 * mt + 4 * q + r) * RS + w * WSEG + 1 + 2 * m;
-                    d[0] = relu_nan((m0 + m1) + m2);
-                    if (2 * m + 1 < T) d[1] = relu_nan((m1 - m2) - m3);
+                    d[0] = fmaxf((m0 + m1) + m2, 0.f);
+                    d[1] = (T % 2 == 0 || 2 * m + 1 < T) ? fmaxf((m1 - m2) - m3, 0.f) : 0.f;   // index T+1 is a zero pad
                 }
         }
     }
@@ -285,8 +305,9 @@ __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, 
                 for (int r = 0; r < 4; ++r) {
                     const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
                     const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
-                    const float y0 = relu_nan((m0 + m1) + m2), y1 = relu_nan((m1 - m2) - m3);
-                    act[(co0 + 16 * mt + 4 * q + r) * RS2 + w * WS2 + 1 + m] = fmaxf(y0, y1);
+                    // max(relu(y0), relu(y1)) = max(y0, y1, 0)
+                    act[(co0 + 16 * mt + 4 * q + r) * RS2 + w * WS2 + 1 + m] =
+                        fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
                 }
         }
     }
@@ -295,7 +316,8 @@ __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, 
 // output transform + ReLU + MaxPool1d(2,2) (pairs 0..36; t = 74 dropped) + flatten c*37+j -> HBM
 template <typename FT>
 __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t win0, int nvalid,
-                                                const f32x4 (&acc)[MT][NTW][4], int co0, int lane)
+                                                const f32x4 (&acc)[MT][NTW][4], int co0, int lane,
+                                                bool nan0, bool nan1)
 {
     const int j = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -310,8 +332,9 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
                 for (int r = 0; r < 4; ++r) {
                     const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
                     const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
-                    const float y0 = relu_nan((m0 + m1) + m2), y1 = relu_nan((m1 - m2) - m3);
-                    put_feat(feat + (win0 + w) * FEAT + (co0 + 16 * mt + 4 * q + r) * 37 + m, fmaxf(y0, y1));
+                    const float v = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+                    put_feat(feat + (win0 + w) * FEAT + (co0 + 16 * mt + 4 * q + r) * 37 + m,
+                             (w ? nan1 : nan0) ? __builtin_nanf("") : v);
                 }
         }
     }
@@ -343,13 +366,26 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
         const int o = i < 64 ? i : (i < 128 ? i - 64 : (i < 256 ? i - 128 : i - 256));
         act[WACT_FLOATS + i] = pk.b[l][o];
     }
+    if (tid < NW) reinterpret_cast<int*>(act + WACT_FLOATS + 384)[tid] = 0;     // per-window NaN flags
 
     // ---- prologue: HBM -> registers -> (z-score) -> LDS [channel][window segment]
+    int* nanflag = reinterpret_cast<int*>(act + WACT_FLOATS + 384);
     {
         float x[NW][38];
         const int64_t wstride = ZS ? CH : (int64_t)WIN * CH;
         load_windows<ZS, NW>(src + win0 * wstride, wstride, nvalid, act + WRED_ROW * RS1, x, tid);
-        if (ZS) __syncthreads();                 // the reduction scratch (rows 56..) is zeroed below
+        // ReLU runs as v_max_f32 (which drops NaN), so NaN / Inf semantics are carried per WINDOW:
+        // torch turns any non-finite input sample into all-NaN logits (every fc.0 output sums over
+        // every feature); here such a window gets all-NaN features at the end instead.
+        bool bad0 = false, bad1 = false;
+#pragma unroll
+        for (int m = 0; m < 38; ++m) {
+            bad0 |= !(fabsf(x[0][m]) <= 3.0e38f);
+            bad1 |= !(fabsf(x[1][m]) <= 3.0e38f);
+        }
+        __syncthreads();                         // flags were zeroed at kernel entry; also orders the
+        if (bad0) nanflag[0] = 1;                // z-score scratch reads before the pad zeroing of
+        if (bad1) nanflag[1] = 1;                // rows 56.. below
         if (tid < 4 * CH) {
             const int c = tid % CH, g = tid / CH;
 #pragma unroll
@@ -370,6 +406,8 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
     }
     __syncthreads();
     TRACE_MARK(1);
+    const bool nan0 = __builtin_amdgcn_readfirstlane(nanflag[0]) != 0;
+    const bool nan1 = __builtin_amdgcn_readfirstlane(nanflag[1]) != 0;
 
     f32x4 acc[MT][NTW][4];
     int boff[NTW];
@@ -384,16 +422,14 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
         const float4* ap2 = reinterpret_cast<const float4*>(pk.ww[1]) + P * (16 * 128) + 2 * lane;
         col_offsets<TP1, WS1>(nt0, j, boff);
         A8 a = load_a8(ap1, 0);
-        wino_init(bias_lds, co0, lane, acc);
-        wino_mfma<RS1, 14>(xrow1, boff, ap1, a, acc);
+        wino_mfma<RS1, 14>(xrow1, boff, ap1, a, bias_lds, co0, lane, acc);
         TRACE_MARK(2);
         a = load_a8(ap2, 0);                              // next layer's first weights in flight
         __syncthreads();                                  // across the write-back
         wino_store_plain<RS1, WS1, TP1, 150>(act, acc, co0, nt0, lane);
-        wino_init(bias_lds + 64, co0, lane, acc);
         __syncthreads();
         TRACE_MARK(3);
-        wino_mfma<RS1, 16>(xrow1, boff, ap2, a, acc);
+        wino_mfma<RS1, 16>(xrow1, boff, ap2, a, bias_lds + 64, co0, lane, acc);
         TRACE_MARK(4);
         const float4* ap3 = reinterpret_cast<const float4*>(pk.ww[2]) + wv * (16 * 128) + 2 * lane;
         a = load_a8(ap3, 0);
@@ -408,20 +444,18 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
         const int co2 = 32 * wv;
         const float4* ap4 = reinterpret_cast<const float4*>(pk.ww[3]) + wv * (32 * 128) + 2 * lane;
         col_offsets<TP2, WS2>(0, j, boff);
-        wino_init(bias_lds + 128, co2, lane, acc);
         __syncthreads();
         TRACE_MARK(5);
-        wino_mfma<RS2, 16>(xrow2, boff, ap3, a, acc);
+        wino_mfma<RS2, 16>(xrow2, boff, ap3, a, bias_lds + 128, co2, lane, acc);
         TRACE_MARK(6);
         a = load_a8(ap4, 0);
         __syncthreads();
         wino_store_plain<RS2, WS2, TP2, 75>(act, acc, co2, 0, lane);
-        wino_init(bias_lds + 256, co2, lane, acc);
         __syncthreads();
         TRACE_MARK(7);
-        wino_mfma<RS2, 32>(xrow2, boff, ap4, a, acc);
+        wino_mfma<RS2, 32>(xrow2, boff, ap4, a, bias_lds + 256, co2, lane, acc);
         TRACE_MARK(8);
-        wino_store_feat(feat, win0, nvalid, acc, co2, lane);
+        wino_store_feat(feat, win0, nvalid, acc, co2, lane, nan0, nan1);
         TRACE_MARK(9);
     }
 }
