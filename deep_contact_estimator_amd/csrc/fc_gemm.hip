@@ -29,7 +29,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 // One K-tile is 128 BYTES of K per row in either precision (32 floats / 64 bf16); LDS rows are
 // padded to 144 B so the 16-B fragment reads of 16 consecutive rows hit 16 distinct slots.
-constexpr int KT_BYTES = 128, LDR = 144;
+#ifndef DCE_GEMM_KTB
+#define DCE_GEMM_KTB 128
+#endif
+constexpr int KT_BYTES = DCE_GEMM_KTB, LDR = KT_BYTES + 16;    // 128: 2 blocks/CU; 64: 4 blocks/CU
+constexpr int CPR = KT_BYTES / 16, RPP = 256 / CPR;             // 16-B columns per row, rows per staging pass
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -54,14 +58,14 @@ template <int TM, int TN> struct GemmCfg {
 //   BF16 = true : A, W bf16; v_mfma_f32_32x32x16_bf16, fp32 accumulate       -- DCE_BF16_FC
 //   OUT_BF16    : store C as bf16 (input of the next bf16 GEMM) instead of fp32
 template <int TM, int TN, bool BF16, bool OUT_BF16>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, KT_BYTES == 64 ? 4 : 2)
 void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                     const float* __restrict__ bias, void* __restrict__ Cv,
                     int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
 {
     using Cfg = GemmCfg<TM, TN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN;
-    constexpr int SA = BM / 32, SB = BN / 32;            // 16-B pieces staged per thread per K-tile
+    constexpr int SA = BM / RPP, SB = BN / RPP;          // 16-B pieces staged per thread per K-tile
     constexpr int ES = BF16 ? 2 : 4;                     // element size
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                                     // [2][BM][LDR]
@@ -90,18 +94,18 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     const int i = lane & 31, h = lane >> 5;
 
     // staging: thread -> (row = tid/8 + 32*s, 16-byte column tid%8)
-    const int srow = tid >> 3, sk4 = tid & 7;
+    const int srow = tid / CPR, sk4 = tid % CPR;
     const size_t rowb = (size_t)K * ES;                  // bytes per operand row
     const char* ag[SA];
     const char* bg[SB];
 #pragma unroll
     for (int s = 0; s < SA; ++s) {
-        int ra = m0 + srow + 32 * s;
+        int ra = m0 + srow + RPP * s;
         ra = ra < M ? ra : M - 1;                        // clamp: rows >= M are computed, never stored
         ag[s] = A + (size_t)ra * rowb + 16 * sk4;
     }
 #pragma unroll
-    for (int s = 0; s < SB; ++s) bg[s] = W + (size_t)(n0 + srow + 32 * s) * rowb + 16 * sk4;
+    for (int s = 0; s < SB; ++s) bg[s] = W + (size_t)(n0 + srow + RPP * s) * rowb + 16 * sk4;
     const int sdst = srow * LDR + 16 * sk4;
 
     f32x16 acc[TM][TN];
@@ -112,7 +116,7 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    static_assert((SA == 4 && SB == 4) || (SA == 2 && SB == 2), "staging registers are named, 2 or 4 per operand");
+    static_assert(SA == SB && (SA == 4 || SA == 2 || SA == 1), "staging registers are named: 1, 2 or 4 per operand");
     {   // first K-tile: plain loads
         float4 t[SA + SB];
 #pragma unroll
@@ -120,9 +124,9 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
         for (int s = 0; s < SB; ++s) t[SA + s] = *reinterpret_cast<const float4*>(bg[s]);
 #pragma unroll
-        for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(As + sdst + 32 * s * LDR) = t[s];
+        for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(As + sdst + RPP * s * LDR) = t[s];
 #pragma unroll
-        for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(Bs + sdst + 32 * s * LDR) = t[SA + s];
+        for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(Bs + sdst + RPP * s * LDR) = t[SA + s];
     }
     __syncthreads();
     v4f ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;          // staging registers (native vectors: asm operands)
@@ -141,8 +145,8 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         // and names every destination register (cdna_hip_programming.md 5.7, form ii).
         const size_t koff = (size_t)(kt + 1 < KT ? kt + 1 : kt) * KT_BYTES;
 #define DCE_GLOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
-        DCE_GLOAD16(ra0, ag[0] + koff); DCE_GLOAD16(ra1, ag[1] + koff);
-        DCE_GLOAD16(rb0, bg[0] + koff); DCE_GLOAD16(rb1, bg[1] + koff);
+        DCE_GLOAD16(ra0, ag[0] + koff); DCE_GLOAD16(rb0, bg[0] + koff);
+        if constexpr (SA >= 2) { DCE_GLOAD16(ra1, ag[1] + koff); DCE_GLOAD16(rb1, bg[1] + koff); }
         if constexpr (SA == 4) {
             DCE_GLOAD16(ra2, ag[2] + koff); DCE_GLOAD16(ra3, ag[3] + koff);
             DCE_GLOAD16(rb2, bg[2] + koff); DCE_GLOAD16(rb3, bg[3] + koff);
@@ -152,7 +156,7 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         const char* as = As + cur * Cfg::A_BYTES + fa;
         const char* bs = Bs + cur * Cfg::B_BYTES + fb;
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
+        for (int kq = 0; kq < KT_BYTES / 32; ++kq) {
             float4 af[TM], bf[TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(as + 32 * a * LDR + 32 * kq);
@@ -185,13 +189,17 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         if constexpr (SA == 4) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(ra2), "+v"(ra3),
                                                 "+v"(rb0), "+v"(rb1), "+v"(rb2), "+v"(rb3));
-            *reinterpret_cast<v4f*>(ad + 64 * LDR) = ra2; *reinterpret_cast<v4f*>(ad + 96 * LDR) = ra3;
-            *reinterpret_cast<v4f*>(bd + 64 * LDR) = rb2; *reinterpret_cast<v4f*>(bd + 96 * LDR) = rb3;
-        } else {
+            *reinterpret_cast<v4f*>(ad + 2 * RPP * LDR) = ra2; *reinterpret_cast<v4f*>(ad + 3 * RPP * LDR) = ra3;
+            *reinterpret_cast<v4f*>(bd + 2 * RPP * LDR) = rb2; *reinterpret_cast<v4f*>(bd + 3 * RPP * LDR) = rb3;
+        } else if constexpr (SA == 2) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1));
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(rb0));
         }
-        *reinterpret_cast<v4f*>(ad) = ra0; *reinterpret_cast<v4f*>(ad + 32 * LDR) = ra1;
-        *reinterpret_cast<v4f*>(bd) = rb0; *reinterpret_cast<v4f*>(bd + 32 * LDR) = rb1;
+        *reinterpret_cast<v4f*>(ad) = ra0; *reinterpret_cast<v4f*>(bd) = rb0;
+        if constexpr (SA >= 2) {
+            *reinterpret_cast<v4f*>(ad + RPP * LDR) = ra1; *reinterpret_cast<v4f*>(bd + RPP * LDR) = rb1;
+        }
         __syncthreads();
     }
 
