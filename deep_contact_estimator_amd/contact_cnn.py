@@ -283,8 +283,9 @@ class contact_cnn:
         return counts
 
     # ---- profiling (bench.py) ---------------------------------------------------------------
-    def profile(self, on: bool = True):
-        _lib.check(self._lib.dce_profile_enable(self._ensure_ctx(), int(on)), self._ctx)
+    def profile(self, every: int = 1):
+        """Time the four kernels of every `every`-th kernel sequence with HIP events (0 = off)."""
+        _lib.check(self._lib.dce_profile_enable(self._ensure_ctx(), int(every)), self._ctx)
 
     def profile_read(self, reset: bool = True):
         ms = (C.c_double * 4)()

@@ -60,7 +60,9 @@ struct dce_ctx {
     size_t d_out_rows = 0;
 
     // profiling
-    bool prof = false;
+    int prof_period = 0;                   // 0 = off, k = time every k-th kernel sequence
+    int64_t prof_tick = 0;
+    bool prof = false;                     // events are recorded for the CURRENT sequence
     std::vector<hipEvent_t> ev_pool;
     struct Span { int slot; hipEvent_t a, b; };
     std::vector<Span> spans;
@@ -127,6 +129,7 @@ int drain_spans(dce_ctx* c)
 int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
               float* logits, int32_t* pred, uint8_t* contacts)
 {
+    c->prof = c->prof_period > 0 && (c->prof_tick++ % c->prof_period) == 0;
     if (c->precision == DCE_BF16_FC) {
         // conv stack in fp32 -> bf16 features; fc.0 / fc.3 on bf16 MFMA with fp32 accumulate
         // (feat and h1 scratch hold bf16 here); fc.6 + argmax stay fp32
@@ -139,7 +142,7 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
     }
     { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream)); }
-    if (c->prof && c->spans.size() > 4096) return drain_spans(c);
+    if (c->spans.size() > 4096) return drain_spans(c);
     return DCE_OK;
 }
 
@@ -464,8 +467,10 @@ int dce_confusion_counts(dce_ctx* c, const int32_t* pred, const int64_t* labels,
 
 int dce_profile_enable(dce_ctx* c, int on)
 {
-    if (!c) return DCE_ERR_ARG;
-    c->prof = on != 0;
+    if (!c || on < 0) return DCE_ERR_ARG;
+    c->prof_period = on;
+    c->prof_tick = 0;
+    c->prof = false;
     return DCE_OK;
 }
 

@@ -125,9 +125,11 @@ int  dce_confusion_counts(dce_ctx* ctx, const int32_t* pred, const int64_t* labe
                           int on_device, int64_t* counts);
 
 /* Kernel timing with HIP events on the ctx's stream, for bench.py's roofline block.
- * Enables per-kernel event recording for subsequent forward calls; dce_profile_read
- * synchronises and returns the accumulated milliseconds and launch counts since the
- * last reset:  slot 0 = conv stack, 1 = fc1 GEMM, 2 = fc2 GEMM, 3 = fc3+argmax tail. */
+ * on = k > 0 records an event pair around each of the four kernels of every k-th kernel sequence
+ * (k = 1: every one; an event costs ~4 us of stream time, so a sparse sample keeps the timed
+ * region honest), on = 0 stops.  dce_profile_read synchronises and returns the accumulated
+ * milliseconds and launch counts since the last reset:
+ * slot 0 = conv stack, 1 = fc1 GEMM, 2 = fc2 GEMM, 3 = fc3+argmax tail. */
 #define DCE_PROFILE_SLOTS 4
 int  dce_profile_enable(dce_ctx* ctx, int on);
 int  dce_profile_read(dce_ctx* ctx, double ms[DCE_PROFILE_SLOTS], int64_t launches[DCE_PROFILE_SLOTS], int reset);
