@@ -6,8 +6,9 @@ Reads the same YAML keys (data_path, label_path, model_load_path, window_size, b
 calculate_accuracy, save_mat, mat_save_path, save_lcm, lcm_save_path), builds
 contact_dataset / loader / contact_cnn the same way and prints the same accuracy lines.
 ``--fused`` runs the whole sequence through one dce_infer_sequence call instead of the
-per-batch loop (identical results).  .mat / LCM export is out of scope: with
-save_mat the (N,4) estimates go to <mat_save_path minus .mat>.npy; save_lcm is reported and skipped.
+per-batch loop (identical results).  save_mat / save_lcm
+call export.save2mat / export.save2lcm (restated formats, see export.py) when the raw .mat named by
+mat_data_path exists; synthetic runs without one get the (N,4) estimates as .npy instead.
 """
 from __future__ import annotations
 
@@ -57,12 +58,20 @@ def main(argv=None):
     else:
         pred = inference(dataloader, model, device)
 
+    from . import export
+    have_mat = os.path.exists(str(config.get("mat_data_path", "")))
     if config.get("save_mat"):
-        out = os.path.splitext(config["mat_save_path"])[0] + ".npy"
-        np.save(out, pred.cpu().numpy())
-        print("Saved contact estimates to", out, "(.mat export is out of scope)")
+        if have_mat:
+            export.save2mat(pred, config)                      # src/inference_one_seq.py:64-89
+        else:                                                  # synthetic runs have no raw .mat
+            out = os.path.splitext(config["mat_save_path"])[0] + ".npy"
+            np.save(out, pred.cpu().numpy())
+            print("mat_data_path not found: saved the (N,4) contact estimates to", out)
     if config.get("save_lcm"):
-        print("save_lcm requested: LCM export is out of scope here, skipped")
+        if have_mat:
+            export.save2lcm(pred, config)                      # src/inference_one_seq.py:91-133
+        else:
+            print("save_lcm requested but mat_data_path not found: skipped")
     return pred
 
 

@@ -177,6 +177,81 @@ def metrics_case():
     print("metrics: precision(b)", out["b_precision"], "jaccard(b)", out["b_jaccard"])
 
 
+def export_case():
+    """Golden bytes of the three LCM message types from the reference's generated Python codecs
+    (lcm_types/python/*.py, struct-only), and the reference's save2mat output on a synthetic .mat
+    (src/inference_one_seq.py:64-89; the module is imported with a stub `lcm` module, which only
+    save2lcm would touch)."""
+    import types
+    import scipy.io as sio
+    from lcm_types.python import contact_t, leg_control_data_lcmt, microstrain_lcmt
+    rng = np.random.default_rng(123)
+    n = 5
+    T = n + 149
+    mat = {"q": rng.standard_normal((T, 12)), "qd": rng.standard_normal((T, 12)), "p": rng.standard_normal((T, 12)),
+           "v": rng.standard_normal((T, 12)), "tau_est": rng.standard_normal((T, 12)), "F": rng.standard_normal((T, 12)),
+           "imu_acc": rng.standard_normal((T, 3)), "imu_omega": rng.standard_normal((T, 3)),
+           "imu_rpy": rng.standard_normal((T, 3)), "imu_quat": rng.standard_normal((T, 4)),
+           "imu_time": np.cumsum(rng.uniform(0.001, 0.003, T)), "control_time": np.cumsum(rng.uniform(0.001, 0.003, T))}
+    contacts = rng.integers(0, 2, (n, 4)).astype(np.uint8)
+    msgs = {"leg": [], "contact": [], "imu": []}
+    for i in range(n):
+        d = i + 149
+        m = leg_control_data_lcmt()
+        m.q, m.p, m.qd, m.v, m.tau_est = mat["q"][d], mat["p"][d], mat["qd"][d], mat["v"][d], mat["tau_est"][d]
+        msgs["leg"].append(np.frombuffer(m.encode(), np.uint8))
+        c = contact_t()
+        c.num_legs, c.timestamp, c.contact = 4, mat["imu_time"][d], contacts[i]
+        msgs["contact"].append(np.frombuffer(c.encode(), np.uint8))
+        u = microstrain_lcmt()
+        u.acc, u.omega, u.rpy, u.quat = mat["imu_acc"][d], mat["imu_omega"][d], mat["imu_rpy"][d], mat["imu_quat"][d]
+        msgs["imu"].append(np.frombuffer(u.encode(), np.uint8))
+    out = {"n": n, "contacts": contacts, **{"mat_" + k: v for k, v in mat.items()},
+           **{"msg_" + k: np.stack(v) for k, v in msgs.items()}}
+    # reference save2mat
+    sys.modules.setdefault("lcm", types.ModuleType("lcm"))
+    import inference_one_seq as ref_inf
+    with tempfile.TemporaryDirectory() as dd:
+        data = np.concatenate([mat["q"], mat["qd"], mat["imu_acc"], mat["imu_omega"], mat["p"], mat["v"]], axis=1)
+        lab = synth.make_labels(T, 3, two_d=True)
+        cfg = {"mat_data_path": os.path.join(dd, "in.mat"), "data_path": os.path.join(dd, "d.npy"),
+               "label_path": os.path.join(dd, "l.npy"), "window_size": 150, "mat_save_path": os.path.join(dd, "out.mat")}
+        sio.savemat(cfg["mat_data_path"], mat)
+        np.save(cfg["data_path"], data)
+        np.save(cfg["label_path"], lab)
+        ref_inf.save2mat(torch.from_numpy(contacts), cfg)
+        res = sio.loadmat(cfg["mat_save_path"])
+        out.update({"save2mat_" + k: v for k, v in res.items() if not k.startswith("__")})
+        out["labels"] = lab
+    np.savez_compressed(os.path.join(HERE, "lcm_messages.npz"), **out)
+    print("export: message sizes", {k: v[0].size for k, v in msgs.items()}, "save2mat keys",
+          sorted(k for k in out if k.startswith("save2mat_")))
+
+
+def ingest_case():
+    """Reference utils/mat2numpy.py (imported with a stub `lcm`): mat2numpy_one_seq on a synthetic
+    .mat and binary2decimal on all 16 bit patterns."""
+    import types
+    import scipy.io as sio
+    sys.modules.setdefault("lcm", types.ModuleType("lcm"))
+    sys.path.insert(0, os.path.join(REF, "utils"))
+    import mat2numpy as ref_m2n
+    rng = np.random.default_rng(321)
+    T = 40
+    mat = {"q": rng.standard_normal((T, 12)), "qd": rng.standard_normal((T, 12)), "p": rng.standard_normal((T, 12)),
+           "v": rng.standard_normal((T, 12)), "imu_acc": rng.standard_normal((T, 3)), "imu_omega": rng.standard_normal((T, 3)),
+           "contacts": rng.integers(0, 2, (T, 4)).astype(np.uint8)}
+    with tempfile.TemporaryDirectory() as dd:
+        os.makedirs(os.path.join(dd, "mat")); os.makedirs(os.path.join(dd, "npy"))
+        sio.savemat(os.path.join(dd, "mat", "seq0.mat"), mat)
+        ref_m2n.mat2numpy_one_seq(os.path.join(dd, "mat") + "/", os.path.join(dd, "npy") + "/")
+        data = np.load(os.path.join(dd, "npy", "seq0.npy")); label = np.load(os.path.join(dd, "npy", "seq0_label.npy"))
+    bits = ((np.arange(16)[:, None] & np.array([8, 4, 2, 1])) != 0).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "ingest.npz"), data=data, label=label, bits=bits,
+                        dec=ref_m2n.binary2decimal(bits), **{"mat_" + k: v for k, v in mat.items()})
+    print("ingest:", data.shape, data.dtype, label.shape, label.dtype)
+
+
 if __name__ == "__main__":
     # case A: N(0,1) sequence, biased He weights, batch 30 (config/test_params.yaml:9), 1-D labels
     run_case("seq_normal", wseed=1, bias="uniform", T=150 + 255, sseed=0, kind="normal",
@@ -187,3 +262,5 @@ if __name__ == "__main__":
              batch=1, label_2d=True)
     edge_cases()
     metrics_case()
+    export_case()
+    ingest_case()
