@@ -29,11 +29,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 // One K-tile is 128 BYTES of K per row in either precision (32 floats / 64 bf16); LDS rows are
 // padded to 144 B so the 16-B fragment reads of 16 consecutive rows hit 16 distinct slots.
+#ifndef DCE_GEMM_8WAVE
+#define DCE_GEMM_8WAVE 0     // 128x128 tile on 8 waves (4 waves/SIMD) instead of 4 waves
+#endif
 #ifndef DCE_GEMM_KTB
 #define DCE_GEMM_KTB 128
 #endif
 constexpr int KT_BYTES = DCE_GEMM_KTB, LDR = KT_BYTES + 16;    // 128: 2 blocks/CU; 64: 4 blocks/CU
-constexpr int CPR = KT_BYTES / 16, RPP = 256 / CPR;             // 16-B columns per row, rows per staging pass
+constexpr int CPR = KT_BYTES / 16;                               // 16-B columns per staged row
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -47,8 +50,10 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-template <int TM, int TN> struct GemmCfg {
-    static constexpr int BM = 64 * TM, BN = 64 * TN;              // block tile (2x2 waves)
+template <int TM, int TN, int WGN = 2> struct GemmCfg {
+    static constexpr int NT = 128 * WGN;                         // threads: 2 x WGN waves
+    static constexpr int RPP = NT / CPR;                         // rows per staging pass
+    static constexpr int BM = 64 * TM, BN = 32 * TN * WGN;        // block tile
     static constexpr int A_BYTES = BM * LDR, B_BYTES = BN * LDR;
     static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
 };
@@ -57,14 +62,15 @@ template <int TM, int TN> struct GemmCfg {
 //   BF16 = false: A, W fp32; v_mfma_f32_32x32x2_f32  (exact fp32)            -- the headline path
 //   BF16 = true : A, W bf16; v_mfma_f32_32x32x16_bf16, fp32 accumulate       -- DCE_BF16_FC
 //   OUT_BF16    : store C as bf16 (input of the next bf16 GEMM) instead of fp32
-template <int TM, int TN, bool BF16, bool OUT_BF16>
-__global__ __launch_bounds__(256, KT_BYTES == 64 ? 4 : 2)
+//   WGN         : waves along N (2: 256 threads, 2 waves/SIMD at 2 blocks/CU; 4: 512 threads, 4 waves/SIMD)
+template <int TM, int TN, bool BF16, bool OUT_BF16, int WGN = 2>
+__global__ __launch_bounds__(128 * WGN, WGN)
 void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                     const float* __restrict__ bias, void* __restrict__ Cv,
                     int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
 {
-    using Cfg = GemmCfg<TM, TN>;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN;
+    using Cfg = GemmCfg<TM, TN, WGN>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, RPP = Cfg::RPP;
     constexpr int SA = BM / RPP, SB = BN / RPP;          // 16-B pieces staged per thread per K-tile
     constexpr int ES = BF16 ? 2 : 4;                     // element size
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,7 +96,7 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #if DCE_SLOT_PRIO
     if (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1) __builtin_amdgcn_s_setprio(3);
 #endif
-    const int wm = (wv >> 1) * 32 * TM, wn = (wv & 1) * 32 * TN;
+    const int wm = (wv / WGN) * 32 * TM, wn = (wv % WGN) * 32 * TN;
     const int i = lane & 31, h = lane >> 5;
 
     // staging: thread -> (row = tid/8 + 32*s, 16-byte column tid%8)
@@ -224,17 +230,18 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     }
 }
 
-template <int TM, int TN, bool BF16, bool OUT_BF16>
+template <int TM, int TN, bool BF16, bool OUT_BF16, int WGN = 2>
 static hipError_t grant_lds()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel<TM, TN, BF16, OUT_BF16>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<TM, TN>::LDS_BYTES);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel<TM, TN, BF16, OUT_BF16, WGN>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<TM, TN, WGN>::LDS_BYTES);
 }
 
 hipError_t init_fc_gemm()
 {
     hipError_t e;
     if ((e = grant_lds<2, 2, false, false>()) != hipSuccess) return e;
+    if ((e = grant_lds<2, 1, false, false, 4>()) != hipSuccess) return e;
     if ((e = grant_lds<1, 1, false, false>()) != hipSuccess) return e;
     if ((e = grant_lds<2, 2, true, true>()) != hipSuccess) return e;
     if ((e = grant_lds<2, 2, true, false>()) != hipSuccess) return e;
@@ -242,18 +249,18 @@ hipError_t init_fc_gemm()
     return grant_lds<1, 1, true, false>();
 }
 
-template <int TM, int TN, bool BF16, bool OUT_BF16>
+template <int TM, int TN, bool BF16, bool OUT_BF16, int WGN = 2>
 static hipError_t launch_gemm_cfg(const void* A, const void* W, const float* bias, void* C,
                                   int64_t M, int N, int K, int relu, hipStream_t st)
 {
-    using Cfg = GemmCfg<TM, TN>;
+    using Cfg = GemmCfg<TM, TN, WGN>;
     const int mtiles = (int)((M + Cfg::BM - 1) / Cfg::BM), ntiles = N / Cfg::BN;
     int sn_log2 = 3;                                   // super-tile 8 x 8 ...
     while ((1 << sn_log2) > ntiles) --sn_log2;         // ... or (64/ntiles) x ntiles when N is narrow
     const int sm = 64 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 64;
-    hipLaunchKernelGGL((fc_gemm_kernel<TM, TN, BF16, OUT_BF16>), dim3(grid), dim3(256), Cfg::LDS_BYTES, st,
+    hipLaunchKernelGGL((fc_gemm_kernel<TM, TN, BF16, OUT_BF16, WGN>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st,
                        A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
     return hipGetLastError();
 }
@@ -265,6 +272,9 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
     if (N % 128 || K % 32 || M > (1 << 30)) return hipErrorInvalidValue;
     // 128x128 tiles when they alone fill the chip (512 resident blocks), else 64x64
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
+#if DCE_GEMM_8WAVE
+    if (big_blocks >= 384) return launch_gemm_cfg<2, 1, false, false, 4>(A, W, bias, C, M, N, K, relu, st);
+#endif
     if (big_blocks >= 384) return launch_gemm_cfg<2, 2, false, false>(A, W, bias, C, M, N, K, relu, st);
     return launch_gemm_cfg<1, 1, false, false>(A, W, bias, C, M, N, K, relu, st);
 }
