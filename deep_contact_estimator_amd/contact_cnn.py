@@ -53,9 +53,9 @@ def _device_index(device) -> int:
 
 class contact_cnn:
     """contact_cnn on MI355X.  ``max_batch`` bounds the windows per kernel sequence (scratch
-    is 29 KB per window); longer inputs are chunked inside the library."""
+    is 29 KB per window: 0.95 GB at the default, of 288 GB); longer inputs are chunked inside the library."""
 
-    def __init__(self, device=None, max_batch: int = 8192, precision: str = "fp32"):
+    def __init__(self, device=None, max_batch: int = 32768, precision: str = "fp32"):
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
         self._device = device

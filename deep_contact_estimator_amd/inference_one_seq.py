@@ -43,7 +43,7 @@ def main(argv=None):
                               window_size=config["window_size"], device=device)
     dataloader = WindowLoader(dataset, batch_size=config["batch_size"])
 
-    model = contact_cnn(max_batch=max(int(config["batch_size"]), 8192))
+    model = contact_cnn(max_batch=max(int(config["batch_size"]), 32768))
     model.load_state_dict(load_checkpoint(config["model_load_path"]))
     model = model.eval().to(device)
 

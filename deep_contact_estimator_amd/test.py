@@ -40,7 +40,7 @@ def main(argv=None):
                                 label_path=config["data_folder"] + "test_label.npy",
                                 window_size=config["window_size"], device=device)
     test_dataloader = WindowLoader(test_data, batch_size=config["batch_size"])
-    model = contact_cnn(max_batch=max(int(config["batch_size"]), 8192))
+    model = contact_cnn(max_batch=max(int(config["batch_size"]), 32768))
     model.load_state_dict(load_checkpoint(config["model_load_path"]))
     model = model.eval().to(device)
 
