@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2], literally: contacts of the 1e6-window streaming run compared with the
+CPU oracle on EVERY window (OpenMP over the host cores).  Reports flips and their fp32 margins."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deep_contact_estimator_amd import contact_cnn, synth
+from oracle import oracle as orc
+
+N = int(os.environ.get("N_WINDOWS", 1_000_000))
+sd = synth.make_state_dict(1)
+seq = np.random.default_rng(3).standard_normal((N + 149, 54)).astype(np.float32)
+m = contact_cnn(device=0)
+m.load_state_dict(sd)
+t0 = time.time(); out = m.infer_sequence(seq); tg = time.time() - t0
+t0 = time.time(); ref = orc.Oracle(sd).infer_sequence(seq); tc = time.time() - t0
+flips = np.nonzero(out["pred"] != ref["pred"])[0]
+srt = np.sort(ref["logits"], axis=1); margin = srt[:, -1] - srt[:, -2]
+err = np.abs(out["logits"] - ref["logits"])
+bound = 1e-5 * np.abs(ref["logits"]).max() + 1e-4 * np.abs(ref["logits"])
+print(json.dumps({
+    "windows": N, "gpu_s_incl_pcie": tg, "oracle_s": tc, "oracle_threads": os.cpu_count(),
+    "argmax_flips": int(flips.size), "flip_margins": margin[flips][:20].tolist(),
+    "contacts_equal_rows": int((out["contacts"] == ref["contacts"]).all(axis=1).sum()),
+    "max_abs_logit_err": float(err.max()), "max_err_over_bound": float((err / bound).max()),
+    "min_margin": float(margin.min()), "windows_with_margin_below_1e-4": int((margin < 1e-4).sum()),
+    "classes_seen": int(np.unique(ref["pred"]).size)}))
