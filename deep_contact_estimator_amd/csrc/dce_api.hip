@@ -257,6 +257,7 @@ void dce_destroy(dce_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    if (c->stream != c->own_stream) hipStreamSynchronize(c->stream);   // scratch may still be in use there
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->xstream_ev) hipEventDestroy(c->xstream_ev);
