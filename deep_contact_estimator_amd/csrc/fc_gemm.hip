@@ -16,7 +16,7 @@
 //    an 8x8 (or 16x4) super-tile, so each A row-panel and W column-panel is fetched into that
 //    XCD's L2 once per 8 (4) consumers.
 //  * fc3_tail_kernel: 16 lanes per window, one class each (K=512 sequential fmaf from LDS-resident
-//    W3^T), then argmax with torch.max semantics (first maximum; a NaN wins, first NaN first)
+//    W3), then argmax with torch.max semantics (first maximum; a NaN wins, first NaN first)
 //    and the 4-bit unpack, MSB = leg 0.
 #include "dce_kernels.h"
 
@@ -302,18 +302,18 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                      const float* __restrict__ b3, int64_t n, float* __restrict__ logits,
                      int32_t* __restrict__ pred, uint8_t* __restrict__ contacts)
 {
-    __shared__ float w3t[FC2 * NCLS];                    // [k][class], 32 KB
-    __shared__ float lg[TAIL_WINDOWS][NCLS];
-    const int tid = threadIdx.x;
+    __shared__ float w3s[NCLS * (FC2 + 1)];              // [class][k], rows padded to 513 floats:
+    __shared__ float lg[TAIL_WINDOWS][NCLS];             // staging stores and the per-class reads
+    const int tid = threadIdx.x;                         // below are both bank-conflict free
     for (int e = tid; e < FC2 * NCLS; e += 256) {
         const int cls = e / FC2, k = e % FC2;            // coalesced read of W3[cls][k]
-        w3t[k * NCLS + cls] = W3[e];
+        w3s[cls * (FC2 + 1) + k] = W3[e];
     }
     const int cls = tid & 15, wl = tid >> 4;
     const float bv = b3[cls];
     for (int64_t base = (int64_t)blockIdx.x * TAIL_WINDOWS; base < n;
          base += (int64_t)gridDim.x * TAIL_WINDOWS) {
-        __syncthreads();                                 // w3t ready / lg free again
+        __syncthreads();                                 // w3s ready / lg free again
         const int64_t win = base + wl;
         // the 16 lanes of a window read the same h2 row (one broadcast 16-B load per 4 k)
         const float4* hp = reinterpret_cast<const float4*>(h2 + (win < n ? win : n - 1) * FC2);
@@ -321,11 +321,11 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
 #pragma unroll 4
         for (int k4 = 0; k4 < FC2 / 4; ++k4) {
             const float4 hv = hp[k4];
-            const float* wp = w3t + (4 * k4) * NCLS + cls;
+            const float* wp = w3s + cls * (FC2 + 1) + 4 * k4;
             acc = fmaf(hv.x, wp[0], acc);
-            acc = fmaf(hv.y, wp[NCLS], acc);
-            acc = fmaf(hv.z, wp[2 * NCLS], acc);
-            acc = fmaf(hv.w, wp[3 * NCLS], acc);
+            acc = fmaf(hv.y, wp[1], acc);
+            acc = fmaf(hv.z, wp[2], acc);
+            acc = fmaf(hv.w, wp[3], acc);
         }
         acc += bv;
         lg[wl][cls] = acc;
