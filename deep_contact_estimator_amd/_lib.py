@@ -26,6 +26,8 @@ SYMBOLS = {
     "dce_zscore_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "dce_forward_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dce_confusion_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "dce_online_reset": (C.c_int, [C.c_void_p]),
+    "dce_online_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dce_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dce_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), _i64p, C.c_int]),
     "dce_sync": (C.c_int, [C.c_void_p]),

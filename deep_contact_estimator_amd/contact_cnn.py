@@ -258,6 +258,25 @@ class contact_cnn:
                                                 out.ctypes.data_as(C.c_void_p)), ctx)
         return out
 
+    def online_reset(self):
+        """Empty the device-resident sample ring of the online mode."""
+        _lib.check(self._lib.dce_online_reset(self._ensure_ctx()), self._ctx)
+
+    def online_push(self, sample):
+        """Online mode: append one (54,) sample; once 150 samples are in, returns
+        (logits (16,), pred int, contacts (4,) u8) for the newest window, else None."""
+        self._finalize()
+        s = np.ascontiguousarray(np.asarray(sample), dtype=np.float32).reshape(-1)
+        if s.shape[0] != CHANNELS:
+            raise RuntimeError(f"expected a ({CHANNELS},) sample, got {s.shape}")
+        logits = np.empty(CLASSES, np.float32); pred = np.empty(1, np.int32); contacts = np.empty(4, np.uint8)
+        _lib.check(self._lib.dce_set_stream(self._ctx, None, 1), self._ctx)
+        rc = self._lib.dce_online_push(self._ctx, s.ctypes.data_as(C.c_void_p), logits.ctypes.data_as(C.c_void_p),
+                                       pred.ctypes.data_as(C.c_void_p), contacts.ctypes.data_as(C.c_void_p))
+        if rc < 0:
+            _lib.check(rc, self._ctx)
+        return (logits, int(pred[0]), contacts) if rc == 1 else None
+
     def confusion_counts(self, pred, labels, counts=None):
         """Accumulate the 16x16 confusion counts C[gt][pred] on the device (dce_confusion_counts).
         pred: (n,) int32 numpy / CUDA tensor from predict() / infer_sequence(); labels: (n,) or

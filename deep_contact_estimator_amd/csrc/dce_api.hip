@@ -59,6 +59,12 @@ struct dce_ctx {
     float* d_logits = nullptr; int32_t* d_pred = nullptr; uint8_t* d_contacts = nullptr;
     size_t d_out_rows = 0;
 
+    // online mode: linear buffer of ONLINE_ROWS sample rows; the live window is its last 150 rows
+    float* d_ring = nullptr;
+    int64_t ring_rows = 0;
+    float* d_online_out = nullptr;         // logits(16) | pred | contacts, on device
+    float* h_online_pin = nullptr;         // pinned mirror of the above + the incoming sample
+
     // profiling
     int prof_period = 0;                   // 0 = off, k = time every k-th kernel sequence
     int64_t prof_tick = 0;
@@ -263,6 +269,8 @@ void dce_destroy(dce_ctx* c)
     if (c->xstream_ev) hipEventDestroy(c->xstream_ev);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2);
     hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts);
+    hipFree(c->d_ring); hipFree(c->d_online_out);
+    if (c->h_online_pin) hipHostFree(c->h_online_pin);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -464,6 +472,48 @@ int dce_confusion_counts(dce_ctx* c, const int32_t* pred, const int64_t* labels,
     HIP_TRY(c, hipMemcpyAsync(counts, base + co, cb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DCE_OK;
+}
+
+namespace { constexpr int64_t ONLINE_ROWS = 4096; }     // compaction every 4096 - 149 pushes
+
+int dce_online_reset(dce_ctx* c)
+{
+    if (!c) return DCE_ERR_ARG;
+    c->ring_rows = 0;
+    return DCE_OK;
+}
+
+int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pred, uint8_t* contacts)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!sample) return fail(c, DCE_ERR_ARG, "dce_online_push: NULL sample");
+    if (!c->d_ring) {
+        HIP_TRY(c, hipMalloc(&c->d_ring, ONLINE_ROWS * CH * sizeof(float)));
+        HIP_TRY(c, hipMalloc(&c->d_online_out, 32 * sizeof(float)));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_online_pin), (32 + CH) * sizeof(float), hipHostMallocDefault));
+    }
+    if (c->ring_rows == ONLINE_ROWS) {                  // keep the last 149 rows, restart at the front
+        HIP_TRY(c, hipMemcpyAsync(c->d_ring, c->d_ring + (ONLINE_ROWS - (WIN - 1)) * CH,
+                                  (WIN - 1) * CH * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        c->ring_rows = WIN - 1;
+    }
+    memcpy(c->h_online_pin + 32, sample, CH * sizeof(float));
+    HIP_TRY(c, hipMemcpyAsync(c->d_ring + c->ring_rows * CH, c->h_online_pin + 32, CH * sizeof(float),
+                              hipMemcpyHostToDevice, c->stream));
+    c->ring_rows += 1;
+    if (c->ring_rows < WIN) { HIP_TRY(c, hipStreamSynchronize(c->stream)); return 0; }
+    float* dl = c->d_online_out;
+    int32_t* dp = reinterpret_cast<int32_t*>(c->d_online_out + 16);
+    uint8_t* dc = reinterpret_cast<uint8_t*>(c->d_online_out + 17);
+    rc = run_chunk(c, c->d_ring + (c->ring_rows - WIN) * CH, 1, 1, dl, dp, dc);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_online_pin, c->d_online_out, 18 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (logits) memcpy(logits, c->h_online_pin, NCLS * sizeof(float));
+    if (pred) memcpy(pred, c->h_online_pin + 16, sizeof(int32_t));
+    if (contacts) memcpy(contacts, c->h_online_pin + 17, 4);
+    return 1;
 }
 
 int dce_profile_enable(dce_ctx* c, int on)

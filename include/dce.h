@@ -124,6 +124,16 @@ int  dce_forward_taps(dce_ctx* ctx, const float* windows, int64_t n, int on_devi
 int  dce_confusion_counts(dce_ctx* ctx, const int32_t* pred, const int64_t* labels, int64_t n,
                           int on_device, int64_t* counts);
 
+/* Online mode (the reference README.md:67-83 describes a real-time runner that evaluates one
+ * window per new sample at robot rate; its code is not in the reference tree): the ctx keeps the
+ * last 150 samples in a device-resident ring; every push appends one (54,) fp32 HOST sample and,
+ * once 150 samples are present, evaluates the newest window exactly as dce_infer_sequence would
+ * (same kernels, z-score fused), so pushing a sequence row by row reproduces dce_infer_sequence's
+ * rows bit for bit.  Returns 1 when outputs were written (HOST pointers, any may be NULL),
+ * 0 while the ring is still filling, < 0 on error.  dce_online_reset empties the ring. */
+int  dce_online_reset(dce_ctx* ctx);
+int  dce_online_push(dce_ctx* ctx, const float* sample, float* logits, int32_t* pred, uint8_t* contacts);
+
 /* Kernel timing with HIP events on the ctx's stream, for bench.py's roofline block.
  * on = k > 0 records an event pair around each of the four kernels of every k-th kernel sequence
  * (k = 1: every one; an event costs ~4 us of stream time, so a sparse sample keeps the timed
