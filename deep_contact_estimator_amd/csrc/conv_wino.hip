@@ -7,9 +7,11 @@
 //     y[2m] = m0+m1+m2     y[2m+1] = m1-m2-m3
 // Summed over input channels each m_k is a GEMM  M_k[Cout, pairs] = U_k[Cout,Cin] V_k[Cin,pairs]:
 // 4 GEMMs of K = Cin instead of 3 taps x K = Cin over twice the columns.  U_k is precomputed on
-// the host (fp64 -> fp32); V_k is formed on the fly from two 8-byte LDS reads (4 VALU ops per 8
+// the host (fp64 -> fp32); V_k is formed on the fly from two 8-byte LDS reads (2 packed adds per 8
 // MFMAs); the output transform, bias (initial value of M_1), ReLU, zero padding and MaxPool (the
 // two outputs of a pair live in ONE lane -> no cross-lane traffic) are fused in the write-back.
+// ReLU is v_max_f32; NaN/Inf inputs are carried per window (see the prologue) and surface as all-NaN
+// features, which is what torch's logits show for such a window.
 // fp32 Winograd F(2,3) has transform constants 0, +-1, +-1/2 only; measured logit error vs an fp64
 // evaluation is the same as the direct form's.
 //
