@@ -10,7 +10,11 @@ from oracle import oracle as orc
 
 N = int(os.environ.get("N_WINDOWS", 1_000_000))
 sd = synth.make_state_dict(1)
-seq = np.random.default_rng(3).standard_normal((N + 149, 54)).astype(np.float32)
+KIND = os.environ.get("KIND", "normal")
+if KIND == "normal":
+    seq = np.random.default_rng(3).standard_normal((N + 149, 54)).astype(np.float32)
+else:                                   # AR(1) + per-channel offset/scale: stresses the z-score
+    seq = synth.make_sequence(N + 149, 5, "ar1").astype(np.float32)
 m = contact_cnn(device=0)
 m.load_state_dict(sd)
 t0 = time.time(); out = m.infer_sequence(seq); tg = time.time() - t0
@@ -20,7 +24,7 @@ srt = np.sort(ref["logits"], axis=1); margin = srt[:, -1] - srt[:, -2]
 err = np.abs(out["logits"] - ref["logits"])
 bound = 1e-5 * np.abs(ref["logits"]).max() + 1e-4 * np.abs(ref["logits"])
 print(json.dumps({
-    "windows": N, "gpu_s_incl_pcie": tg, "oracle_s": tc, "oracle_threads": os.cpu_count(),
+    "windows": N, "kind": KIND, "gpu_s_incl_pcie": tg, "oracle_s": tc, "oracle_threads": os.cpu_count(),
     "argmax_flips": int(flips.size), "flip_margins": margin[flips][:20].tolist(),
     "contacts_equal_rows": int((out["contacts"] == ref["contacts"]).all(axis=1).sum()),
     "max_abs_logit_err": float(err.max()), "max_err_over_bound": float((err / bound).max()),
