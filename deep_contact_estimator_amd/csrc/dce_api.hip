@@ -45,6 +45,7 @@ struct dce_ctx {
     bool finalized = false;
     int precision = DCE_FP32;
     bool winograd = true;                  // conv stack algorithm; DCE_CONV=direct selects the direct form
+    bool gemv = true;                      // FC layers of <= 32 windows as weight-streaming GEMV; DCE_SMALL_BATCH=gemm disables
 
     float* d_weights = nullptr;            // one allocation: conv packs, biases, fc weights
     ConvPack pk{};
@@ -144,8 +145,10 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, c->stream)); }
     } else {
         { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream)); }
-        { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
-        { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
+        // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
+        auto fc = (c->gemv && n <= FC_GEMV_MAX_M) ? launch_fc_gemv : launch_fc_gemm;
+        { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
+        { Timer t(c, 2); HIP_TRY(c, fc(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
     }
     { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream)); }
     if (c->spans.size() > 4096) return drain_spans(c);
@@ -240,6 +243,7 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     c->device = device_id;
     c->max_batch = max_batch;
     if (const char* e = getenv("DCE_CONV")) c->winograd = strcmp(e, "direct") != 0;
+    if (const char* e = getenv("DCE_SMALL_BATCH")) c->gemv = strcmp(e, "gemm") != 0;
 #define CREATE_TRY(expr)                                                                        \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                        \
         fail(nullptr, DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));              \

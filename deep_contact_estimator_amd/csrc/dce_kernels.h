@@ -48,6 +48,12 @@ hipError_t launch_zscore_windows(const float* seq_first_row, int64_t n, float* o
 hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, float* C,
                           int64_t M, int N, int K, int relu, hipStream_t st);
 
+// The same layer for M <= 32 windows (online mode / batch_size 1 and 30): weight-streaming GEMV on all CUs,
+// bit-identical to launch_fc_gemm (same K order).  N % 8 == 0, K % 128 == 0.
+constexpr int FC_GEMV_MAX_M = 32;
+hipError_t launch_fc_gemv(const float* A, const float* W, const float* bias, float* C,
+                          int64_t M, int N, int K, int relu, hipStream_t st);
+
 // Same GEMM on bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate): A[M,K], W[N,K] bf16,
 // C fp32 or bf16 (out_bf16).  N % 128 == 0, K % 64 == 0.  DCE_BF16_FC precision only.
 hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int out_bf16,
