@@ -31,14 +31,18 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 host = seq.cpu().numpy()
 m.infer_sequence(host[: 4096 + 149])
-t0 = time.perf_counter()
-out_h = m.infer_sequence(host)
-dth = time.perf_counter() - t0
+dths = []
+for _ in range(3):                       # first call also grows the ctx's staging buffers
+    t0 = time.perf_counter()
+    out_h = m.infer_sequence(host)
+    dths.append(time.perf_counter() - t0)
+dth = min(dths)
 assert np.array_equal(out_h["contacts"], out["contacts"].cpu().numpy())
 print(json.dumps({
     "workload": f"configs[2]: infer_sequence over {N} windows (T={N + 149}), max_batch {mb}, {prec}",
     "hbm_resident_windows_per_s": N / dt, "hbm_resident_ms": dt * 1e3,
     "pcie_inclusive_windows_per_s": N / dth, "pcie_inclusive_ms": dth * 1e3,
+    "pcie_inclusive_ms_each_call": [round(d * 1e3, 1) for d in dths],
     "bytes_h2d": int(host.nbytes), "bytes_d2h": int(N * (64 + 4 + 4)),
     "classes_seen": int(len(np.unique(out_h["pred"]))),
 }))
