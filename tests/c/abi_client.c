@@ -1,0 +1,152 @@
+/*
+ * abi_client.c -- a plain C client of libdce.so: what a non-Python host (the InEKF side of the
+ * reference's pipeline, README.md:65) would write against include/dce.h.  Test infrastructure:
+ * it links the CPU oracle (oracle/dce_oracle.c) as the checker.
+ *
+ *   1. error behaviour of the ABI (order of calls, bad keys, bad shapes) -- integer codes, no aborts
+ *   2. load 14 state_dict tensors, finalize, dce_infer_sequence on host buffers
+ *   3. logits within |d| <= 1e-5*max|ref| + 1e-4*|ref| of the oracle; argmax / contact bits equal
+ *      wherever the oracle's top-2 margin exceeds 1e-3*max|logit|
+ *   4. dce_online_push row by row == dce_infer_sequence, bit for bit
+ *   5. dce_forward_windows on the oracle's z-scored windows == the fused sequence path (tolerance)
+ *
+ * Build (tests/test_c_client.py does this):
+ *   gcc -O2 -std=c11 -fopenmp -Iinclude -Ioracle tests/c/abi_client.c oracle/dce_oracle.c \
+ *       -Ldeep_contact_estimator_amd -ldce -L/opt/rocm/lib -lamdhip64 -lm -o abi_client
+ * Exit code 0 and a final line "abi_client: OK" on success.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "dce.h"
+#include "dce_oracle.h"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static double uniform01(void)
+{   /* xorshift64* */
+    rng_state ^= rng_state >> 12; rng_state ^= rng_state << 25; rng_state ^= rng_state >> 27;
+    return (double)((rng_state * 0x2545F4914F6CDD1Dull) >> 11) / 9007199254740992.0;
+}
+
+static const struct { const char* key; int ndim; int64_t shape[3]; } KEYS[14] = {
+    {"block1.0.weight", 3, {64, 54, 3}},   {"block1.0.bias", 1, {64, 0, 0}},
+    {"block1.2.weight", 3, {64, 64, 3}},   {"block1.2.bias", 1, {64, 0, 0}},
+    {"block2.0.weight", 3, {128, 64, 3}},  {"block2.0.bias", 1, {128, 0, 0}},
+    {"block2.2.weight", 3, {128, 128, 3}}, {"block2.2.bias", 1, {128, 0, 0}},
+    {"fc.0.weight", 2, {2048, 4736, 0}},   {"fc.0.bias", 1, {2048, 0, 0}},
+    {"fc.3.weight", 2, {512, 2048, 0}},    {"fc.3.bias", 1, {512, 0, 0}},
+    {"fc.6.weight", 2, {16, 512, 0}},      {"fc.6.bias", 1, {16, 0, 0}},
+};
+
+#define CHECK(cond, ...) do { if (!(cond)) { fprintf(stderr, "abi_client: FAILED %s:%d: ", __FILE__, __LINE__); \
+    fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); return 1; } } while (0)
+
+int main(void)
+{
+    enum { N = 70, T = N + DCE_WINDOW - 1 };
+    float* w[14];
+    for (int k = 0; k < 14; ++k) {
+        int64_t count = 1, fan_in = 1;
+        for (int d = 0; d < KEYS[k].ndim; ++d) count *= KEYS[k].shape[d];
+        for (int d = 1; d < KEYS[k].ndim; ++d) fan_in *= KEYS[k].shape[d];
+        w[k] = (float*)malloc(sizeof(float) * (size_t)count);
+        /* weights: uniform with the He variance 2/fan_in; biases: U(-0.1, 0.1) */
+        const double a = KEYS[k].ndim > 1 ? sqrt(6.0 / (double)fan_in) : 0.1;
+        for (int64_t e = 0; e < count; ++e) w[k][e] = (float)((2.0 * uniform01() - 1.0) * a);
+    }
+    /* a drifting, differently scaled signal per channel (so that the z-score matters) */
+    float* seq = (float*)malloc(sizeof(float) * T * DCE_CHANNELS);
+    for (int c = 0; c < DCE_CHANNELS; ++c) {
+        const double scale = pow(10.0, 3.0 * uniform01() - 2.0), offset = 10.0 * uniform01() - 5.0;
+        double x = 0.0;
+        for (int t = 0; t < T; ++t) {
+            x = 0.9 * x + (2.0 * uniform01() - 1.0);
+            seq[t * DCE_CHANNELS + c] = (float)(offset + scale * x);
+        }
+    }
+
+    /* ---- 1. error behaviour */
+    CHECK(dce_abi_version() >= 1, "abi version");
+    CHECK(dce_device_count() >= 1, "no HIP device: %s", dce_last_error(NULL));
+    dce_ctx* ctx = NULL;
+    CHECK(dce_create(&ctx, 0, 0) == DCE_ERR_ARG, "max_batch 0 must be rejected");
+    CHECK(dce_create(&ctx, 0, 32) == DCE_OK, "dce_create: %s", dce_last_error(NULL));
+    float lg1[DCE_CLASSES];
+    CHECK(dce_infer_sequence(ctx, seq, T, DCE_WINDOW, 0, lg1, NULL, NULL) == DCE_ERR_STATE, "forward before finalize");
+    CHECK(dce_finalize_weights(ctx, DCE_FP32) == DCE_ERR_STATE, "finalize with missing keys");
+    CHECK(dce_load_weight(ctx, "fc.9.weight", w[0], KEYS[0].shape, 3) == DCE_ERR_KEY, "unknown key");
+    { const int64_t bad[3] = {64, 54, 5};
+      CHECK(dce_load_weight(ctx, "block1.0.weight", w[0], bad, 3) == DCE_ERR_ARG, "wrong shape"); }
+    for (int k = 0; k < 14; ++k)
+        CHECK(dce_load_weight(ctx, KEYS[k].key, w[k], KEYS[k].shape, KEYS[k].ndim) == DCE_OK, "%s: %s", KEYS[k].key, dce_last_error(ctx));
+    CHECK(dce_finalize_weights(ctx, DCE_FP32) == DCE_OK, "finalize: %s", dce_last_error(ctx));
+    CHECK(dce_infer_sequence(ctx, seq, T, 100, 0, lg1, NULL, NULL) == DCE_ERR_ARG, "window != 150");
+    lg1[0] = 42.f;   /* T < window: contact_dataset.__len__ <= 0 -> nothing to do, nothing written */
+    CHECK(dce_infer_sequence(ctx, seq, DCE_WINDOW - 1, DCE_WINDOW, 0, lg1, NULL, NULL) == DCE_OK && lg1[0] == 42.f, "T < window");
+    CHECK(dce_infer_sequence(ctx, NULL, T, DCE_WINDOW, 0, lg1, NULL, NULL) == DCE_ERR_ARG, "NULL sequence");
+    CHECK(strlen(dce_last_error(ctx)) > 0, "error message missing");
+
+    /* ---- 2. the path (max_batch 32 < N: chunked inside the library) */
+    static float logits[N * DCE_CLASSES], ref_logits[N * DCE_CLASSES];
+    static int32_t pred[N], ref_pred[N];
+    static uint8_t contacts[N * 4], ref_contacts[N * 4];
+    CHECK(dce_infer_sequence(ctx, seq, T, DCE_WINDOW, 0, logits, pred, contacts) == DCE_OK, "infer: %s", dce_last_error(ctx));
+    const oracle_weights ow = { w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13] };
+    float* zwin = (float*)malloc(sizeof(float) * N * DCE_WINDOW * DCE_CHANNELS);
+    CHECK(oracle_infer_sequence(&ow, seq, T, zwin, ref_logits, ref_pred, ref_contacts) == 0, "oracle");
+
+    /* ---- 3. tolerance + argmax contract */
+    double maxref = 0.0, worst = 0.0;
+    for (int e = 0; e < N * DCE_CLASSES; ++e) maxref = fmax(maxref, fabs(ref_logits[e]));
+    for (int e = 0; e < N * DCE_CLASSES; ++e) {
+        const double bound = 1e-5 * maxref + 1e-4 * fabs(ref_logits[e]);
+        worst = fmax(worst, fabs((double)logits[e] - ref_logits[e]) / bound);
+    }
+    CHECK(worst <= 1.0, "logits outside tolerance: err/bound = %.3f", worst);
+    int distinct[DCE_CLASSES] = {0}, classes = 0;
+    for (int i = 0; i < N; ++i) {
+        float top = -INFINITY, second = -INFINITY;
+        for (int k = 0; k < DCE_CLASSES; ++k) {
+            const float v = ref_logits[i * DCE_CLASSES + k];
+            if (v > top) { second = top; top = v; } else if (v > second) second = v;
+        }
+        if (top - second > 1e-3 * maxref) CHECK(pred[i] == ref_pred[i], "argmax of window %d: %d vs %d", i, pred[i], ref_pred[i]);
+        CHECK(pred[i] == oracle_argmax16(logits + i * DCE_CLASSES), "pred is not the argmax of the returned logits (window %d)", i);
+        uint8_t bits[4];
+        oracle_decimal2binary(pred[i], bits);
+        CHECK(memcmp(bits, contacts + 4 * i, 4) == 0, "contact bits of window %d", i);
+        if (!distinct[pred[i]]++) ++classes;
+    }
+
+    /* ---- 4. online mode reproduces the sequence call bit for bit */
+    CHECK(dce_online_reset(ctx) == DCE_OK, "online reset");
+    for (int t = 0; t < T; ++t) {
+        float lg[DCE_CLASSES]; int32_t p; uint8_t cb[4];
+        const int r = dce_online_push(ctx, seq + t * DCE_CHANNELS, lg, &p, cb);
+        CHECK(r == (t >= DCE_WINDOW - 1 ? 1 : 0), "online push %d returned %d: %s", t, r, dce_last_error(ctx));
+        if (r == 1) {
+            const int j = t - (DCE_WINDOW - 1);
+            CHECK(memcmp(lg, logits + j * DCE_CLASSES, sizeof lg) == 0 && p == pred[j] && memcmp(cb, contacts + 4 * j, 4) == 0,
+                  "online row %d differs from dce_infer_sequence", j);
+        }
+    }
+
+    /* ---- 5. materialised windows through dce_forward_windows */
+    static float logits_w[N * DCE_CLASSES];
+    CHECK(dce_forward_windows(ctx, zwin, N, 0, logits_w, NULL, NULL) == DCE_OK, "forward_windows: %s", dce_last_error(ctx));
+    worst = 0.0;
+    for (int e = 0; e < N * DCE_CLASSES; ++e)
+        worst = fmax(worst, fabs((double)logits_w[e] - ref_logits[e]) / (1e-5 * maxref + 1e-4 * fabs(ref_logits[e])));
+    CHECK(worst <= 1.0, "forward_windows outside tolerance: err/bound = %.3f", worst);
+
+    CHECK(dce_sync(ctx) == DCE_OK, "sync");
+    dce_destroy(ctx);
+    dce_destroy(NULL);
+    printf("abi_client: OK (%d windows, %d distinct classes, max|logit| %.2f)\n", N, classes, maxref);
+    for (int k = 0; k < 14; ++k) free(w[k]);
+    free(seq); free(zwin);
+    return 0;
+}
