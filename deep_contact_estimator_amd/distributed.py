@@ -38,6 +38,9 @@ def gather_rows(t, group=None, dst: int = 0):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    home = t.device
+    if dist.get_backend(group) == "gloo":     # CPU transport (tests; no xGMI): exchange host copies
+        t = t.cpu()
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
@@ -51,7 +54,7 @@ def gather_rows(t, group=None, dst: int = 0):
     dist.gather(pad, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0).to(home)
 
 
 def infer_sequence_sharded(run, seq, group=None, dst: int = 0):
@@ -66,6 +69,56 @@ def infer_sequence_sharded(run, seq, group=None, dst: int = 0):
     out = run(seq[r0:r1])
     res = {k: gather_rows(v, group, dst) for k, v in out.items()}
     return res if rank == dst else None
+
+
+def confusion_sharded(run, count, seq, labels, group=None):
+    """The accuracy epilogue of the reference's test loop (src/test.py:19-70,102-104) over the GPUs
+    of a node: every rank classifies its shard of windows with ``run(seq_rows) -> {'pred', ...}``,
+    forms the 16x16 counts of (label, prediction) pairs with ``count(pred, labels) -> (16,16) int64
+    tensor`` (e.g. contact_cnn.confusion_counts) and the matrices are summed with ONE all-reduce
+    (2 KB).  Window j carries ``labels[j + 149]`` (utils/data_handler.py:57).  Every rank gets the
+    full matrix; every metric the reference prints is a function of it (metrics.py)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    r0, r1, w0, w1 = shard_rows(seq.shape[0], rank, world)
+    if w1 > w0:
+        pred = run(seq[r0:r1])["pred"]
+        C = count(pred, labels[w0 + WINDOW - 1:w1 + WINDOW - 1])
+        C = torch.as_tensor(C).to(torch.int64).reshape(16, 16).clone()
+    else:                                      # more ranks than windows: this rank contributes zeros
+        C = torch.zeros((16, 16), dtype=torch.int64, device=getattr(seq, "device", None))
+    if dist.get_backend(group) == "gloo":
+        C = C.cpu()
+    dist.all_reduce(C, op=dist.ReduceOp.SUM, group=group)
+    return C
+
+
+def init_from_env():
+    """One process per GPU under ``python -m torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE
+    in the environment): bind this process to its GPU and join the RCCL ("nccl") group.
+    -> (rank, world, local_rank); (0, 1, 0) and no process group when launched plainly."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        # DCE_DIST_BACKEND=gloo: functional test of the multi-process path on a box with fewer GPUs
+        # than ranks (RCCL refuses two ranks on one device); ranks then share GPUs round-robin
+        backend = os.environ.get("DCE_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local = local % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
+    return rank, world, local
 
 
 class AsyncRowGather:

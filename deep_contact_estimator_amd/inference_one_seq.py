@@ -6,7 +6,9 @@ Reads the same YAML keys (data_path, label_path, model_load_path, window_size, b
 calculate_accuracy, save_mat, mat_save_path, save_lcm, lcm_save_path), builds
 contact_dataset / loader / contact_cnn the same way and prints the same accuracy lines.
 ``--fused`` runs the whole sequence through one dce_infer_sequence call instead of the
-per-batch loop (identical results).  save_mat / save_lcm
+per-batch loop (identical results).  Under ``python -m torch.distributed.run --nproc-per-node G``
+the windows are sharded over the G GPUs (one fused pass each, 149-row halo) and the (N,4) estimates
+gathered to rank 0 over RCCL, which alone writes the outputs.  save_mat / save_lcm
 call export.save2mat / export.save2lcm (restated formats, see export.py) when the raw .mat named by
 mat_data_path exists; synthetic runs without one get the (N,4) estimates as .npy instead.
 """
@@ -28,8 +30,11 @@ def main(argv=None):
     import torch
     if not torch.cuda.is_available():
         sys.exit("deep_contact_estimator_amd needs an MI355X (no CPU path)")
-    device = torch.device("cuda")
-    print("Using ", device)
+    from .distributed import init_from_env, infer_sequence_sharded, confusion_sharded
+    rank, world, local = init_from_env()
+    device = torch.device("cuda", local)
+    if rank == 0:
+        print("Using ", device, "" if world == 1 else f"(+{world - 1} more ranks)")
 
     parser = argparse.ArgumentParser(description="Run the contact network on one sequence")
     parser.add_argument("--config_name", type=str,
@@ -43,11 +48,28 @@ def main(argv=None):
                               window_size=config["window_size"], device=device)
     dataloader = WindowLoader(dataset, batch_size=config["batch_size"])
 
-    model = contact_cnn(max_batch=max(int(config["batch_size"]), 32768))
+    model = contact_cnn(device=local, max_batch=max(int(config["batch_size"]), 32768))
     model.load_state_dict(load_checkpoint(config["model_load_path"]))
     model = model.eval().to(device)
 
-    if config["calculate_accuracy"]:
+    if world > 1:
+        import torch.distributed as dist
+        from . import metrics
+        if config["calculate_accuracy"]:
+            C = confusion_sharded(model.infer_sequence, model.confusion_counts, dataset.data, dataset.label)
+            mt = metrics.metrics_from_confusion16(C.cpu().numpy())
+            if rank == 0:
+                print("Accuracy in terms of class: %.4f" % mt["acc"])
+                for leg in range(4):
+                    print("Accuracy of leg %d is: %.4f" % (leg, mt["acc_per_leg"][leg]))
+                print("Accuracy is: %.4f" % (np.sum(mt["acc_per_leg"]) / 4.0))
+        res = infer_sequence_sharded(model.infer_sequence, dataset.data, dst=0)
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
+            return None
+        pred = res["contacts"]
+    elif config["calculate_accuracy"]:
         pred, acc, acc_per_leg = inference_and_compute_acc(dataloader, model, device)
         print("Accuracy in terms of class: %.4f" % acc)
         for leg in range(4):
@@ -72,6 +94,9 @@ def main(argv=None):
             export.save2lcm(pred, config)                      # src/inference_one_seq.py:91-133
         else:
             print("save_lcm requested but mat_data_path not found: skipped")
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     return pred
 
 

@@ -3,7 +3,9 @@
     python -m deep_contact_estimator_amd.test --config_name config/test_params.yaml
 
 Same YAML keys (data_folder, model_load_path, window_size, batch_size); runs compute_accuracy
-over <data_folder>/test.npy + test_label.npy and prints the accuracy block.  The
+over <data_folder>/test.npy + test_label.npy and prints the accuracy block.  Launched as
+``python -m torch.distributed.run --nproc-per-node G -m deep_contact_estimator_amd.test ...`` the
+windows are sharded over the G GPUs (one process each) and the counts summed with one all-reduce.  The
 precision / Jaccard / confusion-matrix numbers the reference gets from scikit-learn
 (src/test.py:19-70,137-139) are closed forms of one 16x16 integer matrix accumulated on the
 device (dce_confusion_counts + metrics.py); the float64 arrays are still returned unchanged so the
@@ -27,8 +29,11 @@ def main(argv=None):
     import torch
     if not torch.cuda.is_available():
         sys.exit("deep_contact_estimator_amd needs an MI355X (no CPU path)")
-    device = torch.device("cuda")
-    print("Using ", device)
+    from .distributed import init_from_env, confusion_sharded
+    rank, world, local = init_from_env()
+    device = torch.device("cuda", local)
+    if rank == 0:
+        print("Using ", device, "" if world == 1 else f"(+{world - 1} more ranks)")
     parser = argparse.ArgumentParser(description="Test the contact network")
     parser.add_argument("--config_name", type=str,
                         default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "config",
@@ -40,9 +45,22 @@ def main(argv=None):
                                 label_path=config["data_folder"] + "test_label.npy",
                                 window_size=config["window_size"], device=device)
     test_dataloader = WindowLoader(test_data, batch_size=config["batch_size"])
-    model = contact_cnn(max_batch=max(int(config["batch_size"]), 32768))
+    model = contact_cnn(device=local, max_batch=max(int(config["batch_size"]), 32768))
     model.load_state_dict(load_checkpoint(config["model_load_path"]))
     model = model.eval().to(device)
+
+    if world > 1:
+        # sharded evaluation: each rank one fused pass over its windows, one 2 KB all-reduce
+        from . import metrics
+        C = confusion_sharded(lambda rows: model.infer_sequence(rows), model.confusion_counts,
+                              test_data.data, test_data.label)
+        mt = metrics.metrics_from_confusion16(C.cpu().numpy())
+        if rank == 0:
+            _print_metrics(mt, header=True)
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+        return mt
 
     test_acc, acc_per_leg, bin_pred_arr, bin_gt_arr, pred_arr, gt_arr = compute_accuracy(test_dataloader, model)
     print("Test accuracy in terms of class is: %.4f" % test_acc)
@@ -56,13 +74,22 @@ def main(argv=None):
     C = model.confusion_counts(model.infer_sequence(test_data.data)["pred"],
                                test_data.label[test_data.window_size - 1:])
     mt = metrics.metrics_from_confusion16(C.cpu().numpy())
+    _print_metrics(mt)
+    return test_acc, acc_per_leg, bin_pred_arr, bin_gt_arr, pred_arr, gt_arr
+
+
+def _print_metrics(mt, header=False):
+    if header:                                   # the accuracy block, from the same matrix
+        print("Test accuracy in terms of class is: %.4f" % mt["acc"])
+        for leg in range(4):
+            print("Accuracy of leg %d is: %.4f" % (leg, mt["acc_per_leg"][leg]))
+        print("Accuracy is: %.4f" % (np.sum(mt["acc_per_leg"]) / 4.0))
     print("Precision of class: %.4f, of legs: %s, of all legs: %.4f" % (
         mt["precision_of_class"], np.round(mt["precision_of_legs"], 4).tolist(), mt["precision_of_all_legs"]))
     print("Jaccard of class: %.4f, of legs: %s, of all legs: %.4f" % (
         mt["jaccard_of_class"], np.round(mt["jaccard_of_legs"], 4).tolist(), mt["jaccard_of_all_legs"]))
     print("Confusion matrix (all legs):\n", mt["confusion_mat"]["total"])
     print("False negative rate: %s\nFalse positive rate: %s" % (mt["fn_rate"], mt["fp_rate"]))
-    return test_acc, acc_per_leg, bin_pred_arr, bin_gt_arr, pred_arr, gt_arr
 
 
 if __name__ == "__main__":

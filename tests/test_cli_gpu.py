@@ -43,3 +43,51 @@ def test_entry_scripts_on_synthetic_config(tmp_path):
                        env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Test accuracy in terms of class is:" in r.stdout and "Jaccard of class:" in r.stdout
+
+
+def test_entry_scripts_sharded_over_two_processes(tmp_path):
+    """The multi-GPU launch of the entry scripts (one process per rank under torch.distributed.run),
+    on ONE GPU: two ranks share it and exchange over gloo (RCCL refuses two ranks per device), which
+    exercises everything but the transport -- halo sharding, per-rank fused pass, gather of the (N,4)
+    estimates to rank 0, all-reduce of the 16x16 counts -- against the single-process run."""
+    from deep_contact_estimator_amd import synth
+    from oracle import oracle as orc
+    out = tmp_path / "synthetic_data"
+    T = 150 + 300                                        # 301 windows: uneven split 151 / 150
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_data.py"), "--out", str(out),
+                    "--T", str(T)], check=True, capture_output=True)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "inference_one_seq_params.yaml")))
+    for k in ("data_path", "label_path", "mat_data_path", "model_load_path", "mat_save_path", "lcm_save_path"):
+        cfg[k] = cfg[k].replace("synthetic_data", str(out))
+    cfg["save_mat"] = True
+    cfg["calculate_accuracy"] = True
+    cfg_path = tmp_path / "inference_one_seq_params.yaml"
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    tcfg = yaml.safe_load(open(os.path.join(ROOT, "config", "test_params.yaml")))
+    tcfg["data_folder"] = str(out) + "/"
+    tcfg["model_load_path"] = cfg["model_load_path"]
+    tpath = tmp_path / "test_params.yaml"
+    yaml.safe_dump(tcfg, open(tpath, "w"))
+    env = dict(os.environ, PYTHONPATH=ROOT, DCE_DIST_BACKEND="gloo")
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+              "--master-addr", "127.0.0.1", "--master-port", "29571"]
+
+    r = subprocess.run(launch + ["-m", "deep_contact_estimator_amd.inference_one_seq", "--config_name", str(cfg_path)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    contacts = np.load(os.path.splitext(cfg["mat_save_path"])[0] + ".npy")
+    ref = orc.Oracle(synth.make_state_dict(1, "uniform")).infer_sequence(synth.make_sequence(T, 0).astype(np.float32))
+    assert contacts.shape == (T - 149, 4) and np.array_equal(contacts, ref["contacts"])
+    single = subprocess.run([sys.executable, "-m", "deep_contact_estimator_amd.inference_one_seq", "--config_name", str(cfg_path)],
+                            env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True)
+    acc = [l for l in r.stdout.splitlines() if l.startswith("Accuracy")]
+    assert len(acc) == 6 and acc == [l for l in single.stdout.splitlines() if l.startswith("Accuracy")]
+
+    r = subprocess.run(launch + ["-m", "deep_contact_estimator_amd.test", "--config_name", str(tpath)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    single = subprocess.run([sys.executable, "-m", "deep_contact_estimator_amd.test", "--config_name", str(tpath)],
+                            env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True)
+    keep = ("Test accuracy", "Accuracy", "Precision of class", "Jaccard of class", "False ")
+    pick = lambda txt: [l for l in txt.splitlines() if l.startswith(keep)]
+    assert pick(r.stdout) == pick(single.stdout) and len(pick(r.stdout)) >= 9

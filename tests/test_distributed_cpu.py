@@ -101,3 +101,49 @@ def test_async_row_gather_two_ranks(tmp_path):
     got = np.load(out)
     assert got.shape == (2, 8, 16)
     assert (got[0] == 400.0).all() and (got[1] == 401.0).all()
+
+
+def _confusion_worker(rank, world, port, T, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from deep_contact_estimator_amd import synth, metrics
+    from deep_contact_estimator_amd.distributed import confusion_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seq = torch.from_numpy(synth.make_sequence(T, 23).astype(np.float32))
+    labels = torch.from_numpy(synth.make_labels(T, 5).reshape(-1))
+
+    def run(rows):               # a stand-in classifier that depends on the window's own rows only
+        x = rows.numpy()
+        n = x.shape[0] - 149
+        pred = np.array([int(abs(x[j:j + 150].sum()) * 7) % 16 for j in range(n)], np.int32)
+        return {"pred": torch.from_numpy(pred)}
+
+    def count(pred, lab):
+        return torch.from_numpy(metrics.confusion16(pred.numpy(), lab.numpy()))
+
+    C = confusion_sharded(run, count, seq, labels)
+    np.save(out_path + f".{rank}.npy", C.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T", [150 + 75, 150])               # 76 windows over 2 ranks; 1 window (rank 1 empty)
+def test_two_rank_confusion_matches_single_process(T, tmp_path):
+    import torch.multiprocessing as mp
+    from deep_contact_estimator_amd import synth, metrics
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "conf")
+    mp.spawn(_confusion_worker, args=(2, port, T, out), nprocs=2, join=True)
+    seq = synth.make_sequence(T, 23).astype(np.float32)
+    labels = synth.make_labels(T, 5).reshape(-1)
+    n = T - 149
+    pred = np.array([int(abs(seq[j:j + 150].sum()) * 7) % 16 for j in range(n)], np.int32)
+    want = metrics.confusion16(pred, labels[149:])
+    for r in range(2):                                       # all-reduce: every rank holds the full matrix
+        got = np.load(out + f".{r}.npy")
+        assert got.sum() == n and np.array_equal(got, want)
