@@ -125,11 +125,17 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
         args.gpus = world
+    backend = os.environ.get("DCE_DIST_BACKEND", "nccl")   # "gloo": functional check of the N>1 flow on
+    if backend != "nccl":                                   # fewer GPUs than ranks (ranks share devices)
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = args.batch
     sd = synth.make_state_dict(1, "uniform")
@@ -179,7 +185,7 @@ def main():
 
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

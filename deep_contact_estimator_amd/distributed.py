@@ -133,6 +133,9 @@ class AsyncRowGather:
         self.group, self.dst, self.depth = group, dst, depth
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self._host = dist.get_backend(group) == "gloo"      # CPU transport (functional tests only)
+        if self._host:
+            device = "cpu"
         self._bufs = [[torch.empty((rows, cols), dtype=dtype, device=device) for _ in range(self.world)]
                       if self.rank == dst else None for _ in range(depth)]
         self._handles = [None] * depth
@@ -151,6 +154,8 @@ class AsyncRowGather:
         import torch.distributed as dist
         s = self._i % self.depth
         self._wait(s)                         # slot free again (its buffers may be overwritten)
+        if self._host:
+            t = t.cpu()
         self._keep[s] = t
         self._handles[s] = dist.gather(t, self._bufs[s], dst=self.dst, group=self.group, async_op=True)
         self._i += 1

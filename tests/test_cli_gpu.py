@@ -91,3 +91,21 @@ def test_entry_scripts_sharded_over_two_processes(tmp_path):
     keep = ("Test accuracy", "Accuracy", "Precision of class", "Jaccard of class", "False ")
     pick = lambda txt: [l for l in txt.splitlines() if l.startswith(keep)]
     assert pick(r.stdout) == pick(single.stdout) and len(pick(r.stdout)) >= 9
+
+
+def test_bench_two_rank_flow():
+    """bench.py's N>1 flow (rank env from torch.distributed.run, per-step async gather, barrier +
+    max-over-ranks timing, one JSON line from rank 0) with two ranks sharing the one GPU over gloo."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, DCE_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29573", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["global_batch"] == 2 * j["config"]["batch_per_gpu"]
+    assert abs(j["value"] - 2 * 4096 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
