@@ -49,13 +49,19 @@ __device__ __forceinline__ void load_windows(const float* __restrict__ src, int6
 {
     const int c = tid % CH, g = tid / CH;
     const bool loader = tid < 4 * CH;
+    // Every load is issued unconditionally from an always-valid address: under a per-element
+    // runtime condition hipcc wraps each load in its own saveexec/branch block (~7 instructions per
+    // element, all of which queue behind the partner workgroup's MFMAs).  Threads >= 216 re-read
+    // row group 0 and a missing window (odd n) re-reads window 0; neither is ever stored.  Only
+    // the last row group (t = 148..151) has rows past the window: those two read 0.
+    const int gl = loader ? g : 0;
 #pragma unroll
-    for (int w = 0; w < NWIN; ++w)
+    for (int w = 0; w < NWIN; ++w) {
+        const float* wsrc = src + (w < nvalid ? w : 0) * win_stride + gl * CH + c;
 #pragma unroll
-        for (int m = 0; m < 38; ++m) {
-            const int t = 4 * m + g;
-            x[w][m] = (loader && t < WIN && w < nvalid) ? src[w * win_stride + t * CH + c] : 0.f;
-        }
+        for (int m = 0; m < 37; ++m) x[w][m] = wsrc[4 * m * CH];
+        x[w][37] = gl < 2 ? wsrc[148 * CH] : 0.f;             // rows 148 + gl
+    }
     if (ZS) {
         double* dred = reinterpret_cast<double*>(red);
 #pragma unroll
