@@ -54,6 +54,9 @@ constexpr int MT = 2, NTW = 5;                               // row / column til
 #ifndef WINO_PEEL
 #define WINO_PEEL 0          // peel the first two K-steps (no accumulator init); spills at 256 VGPRs
 #endif
+#ifndef WINO_STAGGER
+#define WINO_STAGGER 0
+#endif
 #ifndef WINO_PHASE_PRIO
 #define WINO_PHASE_PRIO 0    // s_setprio level of the non-MFMA phases (0 = leave priorities alone)
 #endif
@@ -358,6 +361,12 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
 
 #if WINO_PHASE_PRIO
     __builtin_amdgcn_s_setprio(WINO_PHASE_PRIO);
+#endif
+#if WINO_STAGGER
+    // experiment: the first 512 workgroups start in lockstep, two per CU; hold the second of each
+    // pair back by WINO_STAGGER x 4096 cycles so that the pair runs its phases out of step
+    if (blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < WINO_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
 #endif
     TRACE_MARK(0);
 #if DCE_TRACE
