@@ -45,6 +45,7 @@ static_assert(64 * RS1 <= WACT_FLOATS && WLDS_FLOATS * 4 <= 80 * 1024, "two work
 static_assert(NW == 2, "per-window NaN flags are written for two windows");
 static_assert(NW * 4 * 216 <= 8 * RS1 && (WRED_ROW * RS1) % 2 == 0, "z-score scratch fits, 8-B aligned");
 constexpr int MT = 2, NTW = 5;                               // row / column tiles per wave
+constexpr int WINO1_MAX_N = 256;                             // <= this many windows: conv_wino1_kernel (one window per workgroup)
 #ifndef WINO_EXP
 #define WINO_EXP 0           // bit flags for tools/micro/wino_loop.hip ablations; 0 in the product
 #endif
@@ -101,9 +102,10 @@ void conv_wino_pack_host(int l, const float* w, float* out)
 // ------------------------------------------------------------------------------------------
 struct A8 { float4 m0, m1; };            // this lane's weights for one K-step: [mt][comp]
 
+template <int MTT = 2>
 __device__ __forceinline__ A8 load_a8(const float4* __restrict__ ap, int s)
-{
-    A8 a; a.m0 = ap[s * 128]; a.m1 = ap[s * 128 + 1]; return a;
+{   // MTT = 1: ap is pre-offset to this wave's half of the row-tile pair; m1 is never read
+    A8 a; a.m0 = ap[s * 128]; a.m1 = MTT == 2 ? ap[s * 128 + 1] : a.m0; return a;
 }
 
 // the 4 inputs of pair m: (x[2m-1], x[2m], x[2m+1], x[2m+2]) -- two 8-byte LDS reads
@@ -156,7 +158,7 @@ __device__ __forceinline__ V4 wino_v(const Quad r)
 // FIRST: the layer's first K-step -- accumulators start from the literal 0 (an inline constant of the
 // MFMA's C operand) or, for component 1, from the bias (it enters y[2m] and y[2m+1] with +1), so no
 // accumulator-initialisation instructions are ever issued.
-template <int RS, bool FIRST>
+template <int RS, bool FIRST, int MT = dce::MT, int NTW = dce::NTW>
 __device__ __forceinline__ void wino_step(const float* __restrict__ xs, const float* __restrict__ xn,
                                           const int (&boff)[NTW], const A8 a,
                                           V4& vcur, Quad& rawb, f32x4 (&acc)[MT][NTW][4],
@@ -179,9 +181,11 @@ __device__ __forceinline__ void wino_step(const float* __restrict__ xs, const fl
         for (int c = 0; c < 4; ++c) {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             const f32x4 c0 = FIRST ? (c == 1 ? bias[0] : zero) : acc[0][nt][c];
-            const f32x4 c1 = FIRST ? (c == 1 ? bias[1] : zero) : acc[1][nt][c];
             acc[0][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], v[c], c0, 0, 0, 0);
-            acc[1][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], v[c], c1, 0, 0, 0);
+            if constexpr (MT == 2) {
+                const f32x4 c1 = FIRST ? (c == 1 ? bias[1] : zero) : acc[1][nt][c];
+                acc[1][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], v[c], c1, 0, 0, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         vcur = vnxt;
@@ -202,7 +206,7 @@ __device__ __forceinline__ void wino_step(const float* __restrict__ xs, const fl
 //   xrow : act + (lane>>4)*RS               (this lane's channel within the K-step)
 //   boff : per column tile, this lane's float offset of pair m inside a row (w*WSEG + 2m)
 //   ap   : packed weights of this wave's row-tile pair, + 2*lane float4
-template <int RS, int STEPS>
+template <int RS, int STEPS, int MT = dce::MT, int NTW = dce::NTW>
 __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const int (&boff)[NTW],
                                           const float4* __restrict__ ap, A8 a_even,
                                           const float* __restrict__ bias_lds, int co0, int lane,
@@ -221,10 +225,10 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
     Quad rawb = load_quad2(xrow + boff[1]);               // raw of tile (0,1)
 #if WINO_PEEL
     {   // K-steps 0 and 1: accumulators start from MFMA C-operand constants, no init instructions
-        const A8 a_odd = load_a8(ap, 1);
-        wino_step<RS, true>(xrow, xrow + 4 * RS, boff, a_even, vcur, rawb, acc, bias);
-        a_even = load_a8(ap, 2);
-        wino_step<RS, false>(xrow + 4 * RS, xrow + 8 * RS, boff, a_odd, vcur, rawb, acc, bias);
+        const A8 a_odd = load_a8<MT>(ap, 1);
+        wino_step<RS, true, MT, NTW>(xrow, xrow + 4 * RS, boff, a_even, vcur, rawb, acc, bias);
+        a_even = load_a8<MT>(ap, 2);
+        wino_step<RS, false, MT, NTW>(xrow + 4 * RS, xrow + 8 * RS, boff, a_odd, vcur, rawb, acc, bias);
     }
     constexpr int S0 = 2;
 #else
@@ -244,31 +248,70 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
 #pragma unroll 1
     for (int s = S0; s < STEPS; s += 2) {
         const int s2 = s + 2 < STEPS ? s + 2 : s;         // last iteration: harmless re-reads
-        const A8 a_odd = load_a8(ap, s + 1);
-        wino_step<RS, false>(xrow + s * 4 * RS, xrow + (s + 1) * 4 * RS, boff, a_even, vcur, rawb, acc, bias);
-        a_even = load_a8(ap, s2);
-        wino_step<RS, false>(xrow + (s + 1) * 4 * RS, xrow + s2 * 4 * RS, boff, a_odd, vcur, rawb, acc, bias);
+        const A8 a_odd = load_a8<MT>(ap, s + 1);
+        wino_step<RS, false, MT, NTW>(xrow + s * 4 * RS, xrow + (s + 1) * 4 * RS, boff, a_even, vcur, rawb, acc, bias);
+        a_even = load_a8<MT>(ap, s2);
+        wino_step<RS, false, MT, NTW>(xrow + (s + 1) * 4 * RS, xrow + s2 * 4 * RS, boff, a_odd, vcur, rawb, acc, bias);
     }
 #if WINO_PHASE_PRIO
     __builtin_amdgcn_s_setprio(WINO_PHASE_PRIO);          // short, latency-critical phases go first
 #endif
 }
 
+// The same layer loop for the one-window kernel, where a workgroup runs alone on its CU and a
+// K-step (20-24 MFMAs = 640-768 cycles) is far shorter than an L2 / MALL round trip: the packed
+// weights are prefetched PF K-steps ahead through a register ring, and the ring runs on into the
+// NEXT layer's weights (ap_next) so that the write-back between two layers does not drain it.
+// Fully unrolled (<= 32 K-steps), so every ring index is a compile-time constant.
+// Ring slot of K-step s is (BASE + s) % PF, BASE = K-steps of all earlier layers (mod PF).
+template <int RS, int STEPS, int MT, int NTW, int PF, int MTN, int BASE>   // MTN: row tiles per wave of the next layer
+__device__ __forceinline__ void wino_mfma_deep(const float* __restrict__ xrow, const int (&boff)[NTW],
+                                               const float4* __restrict__ ap, const float4* __restrict__ ap_next,
+                                               A8 (&ring)[PF], const float* __restrict__ bias_lds, int co0, int lane,
+                                               f32x4 (&acc)[MT][NTW][4])
+{
+    static_assert(STEPS >= PF, "ring shorter than the layer");
+    f32x4 bias[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[mt][r] = bias_lds[co0 + 16 * mt + 4 * (lane >> 4) + r];
+    V4 vcur = wino_v(load_quad2(xrow + boff[0]));
+    Quad rawb = load_quad2(xrow + boff[1]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            acc[mt][nt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[mt][nt][1] = bias[mt];
+            acc[mt][nt][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[mt][nt][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const A8 a = ring[(BASE + s) % PF];
+        if (s + PF < STEPS) ring[(BASE + s) % PF] = load_a8<MT>(ap, s + PF);
+        else if (ap_next)   ring[(BASE + s) % PF] = load_a8<MTN>(ap_next, s + PF - STEPS);
+        const int sn = s + 1 < STEPS ? s + 1 : s;          // last step: harmless re-read
+        wino_step<RS, false, MT, NTW>(xrow + s * 4 * RS, xrow + sn * 4 * RS, boff, a, vcur, rawb, acc, bias);
+    }
+}
+
 // column n = w*TP + m of a layout with TP pairs per window -> float offset of pair m (0 for fillers)
-template <int TP, int WSEG>
+template <int TP, int WSEG, int NTW = dce::NTW, int NWIN = NW>
 __device__ __forceinline__ void col_offsets(int nt0, int j, int (&boff)[NTW])
 {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = 16 * (nt0 + nt) + j;
-        const int w = n >= TP ? 1 : 0;
+        const int w = (NWIN > 1 && n >= TP) ? 1 : 0;
         const int m = n - w * TP;
-        boff[nt] = n < NW * TP ? w * WSEG + 2 * m : 0;
+        boff[nt] = n < NWIN * TP ? w * WSEG + 2 * m : 0;
     }
 }
 
 // output transform + ReLU + in-place write-back, no pooling (conv1: T=150, conv3: T=75)
-template <int RS, int WSEG, int TP, int T>
+template <int RS, int WSEG, int TP, int T, int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW>
 __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const f32x4 (&acc)[MT][NTW][4],
                                                  int co0, int nt0, int lane)
 {
@@ -276,9 +319,9 @@ __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const 
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = 16 * (nt0 + nt) + j;
-        const int w = n >= TP ? 1 : 0;
+        const int w = (NWIN > 1 && n >= TP) ? 1 : 0;
         const int m = n - w * TP;
-        if (n < NW * TP) {
+        if (n < NWIN * TP) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -294,6 +337,7 @@ __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const 
 }
 
 // output transform + ReLU + MaxPool1d(2,2) -> stage-2 layout (conv2)
+template <int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW>
 __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, const f32x4 (&acc)[MT][NTW][4],
                                                        int co0, int nt0, int lane)
 {
@@ -301,9 +345,9 @@ __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, 
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = 16 * (nt0 + nt) + j;
-        const int w = n >= TP1 ? 1 : 0;
+        const int w = (NWIN > 1 && n >= TP1) ? 1 : 0;
         const int m = n - w * TP1;
-        if (n < NW * TP1) {
+        if (n < NWIN * TP1) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -319,7 +363,7 @@ __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, 
 }
 
 // output transform + ReLU + MaxPool1d(2,2) (pairs 0..36; t = 74 dropped) + flatten c*37+j -> HBM
-template <typename FT>
+template <typename FT, int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW>
 __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t win0, int nvalid,
                                                 const f32x4 (&acc)[MT][NTW][4], int co0, int lane,
                                                 bool nan0, bool nan1)
@@ -328,9 +372,9 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = 16 * nt + j;
-        const int w = n >= TP2 ? 1 : 0;
+        const int w = (NWIN > 1 && n >= TP2) ? 1 : 0;
         const int m = n - w * TP2;
-        if (n < NW * TP2 && m < 37 && w < nvalid) {
+        if (n < NWIN * TP2 && m < 37 && w < nvalid) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -471,6 +515,98 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// One window per workgroup: the latency variant for a handful of windows (online mode, the
+// reference's batch_size 1).  Same layers, same LDS layout (window segment 0 only), same per-
+// accumulator K order -> the features are bit-identical to conv_wino_kernel's; only the tiling
+// changes: stage 1 = one row tile x 5 column tiles per wave (75 pairs), stage 2 = two row tiles x
+// 3 column tiles (38 pairs): 1752 MFMAs per wave instead of 3120 for a half-empty two-window
+// workgroup, and twice as many workgroups to spread over the CUs.
+// ------------------------------------------------------------------------------------------
+template <bool ZS>
+__global__ __launch_bounds__(256)
+void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat)
+{
+    extern __shared__ __attribute__((aligned(16))) float act[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const int64_t win0 = blockIdx.x;
+    if (win0 >= n) return;
+
+    for (int i = tid; i < 384; i += 256) {
+        const int l = i < 64 ? 0 : (i < 128 ? 1 : (i < 256 ? 2 : 3));
+        const int o = i < 64 ? i : (i < 128 ? i - 64 : (i < 256 ? i - 128 : i - 256));
+        act[WACT_FLOATS + i] = pk.b[l][o];
+    }
+    int* nanflag = reinterpret_cast<int*>(act + WACT_FLOATS + 384);
+    if (tid == 0) nanflag[0] = 0;
+    // conv1's first PF K-steps of weights are requested before the window itself
+    constexpr int PF = 8;                                 // weight prefetch depth, K-steps
+    A8 ring[PF];
+    const float4* ap1 = reinterpret_cast<const float4*>(pk.ww[0]) + (wv >> 1) * (14 * 128) + 2 * lane + (wv & 1);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = load_a8<1>(ap1, i);
+    {
+        float x[1][38];
+        const int64_t wstride = ZS ? CH : (int64_t)WIN * CH;
+        load_windows<ZS, 1>(src + win0 * wstride, wstride, 1, act + WRED_ROW * RS1, x, tid);
+        bool bad0 = false;
+#pragma unroll
+        for (int m = 0; m < 38; ++m) bad0 |= !(fabsf(x[0][m]) <= 3.0e38f);
+        __syncthreads();
+        if (bad0) nanflag[0] = 1;
+        if (tid < 4 * CH) {
+            const int c = tid % CH, g = tid / CH;
+#pragma unroll
+            for (int m = 0; m < 38; ++m) {
+                const int t = 4 * m + g;
+                if (t < WIN) act[c * RS1 + 1 + t] = x[0][m];
+            }
+        }
+        for (int i = tid; i < 64 * 2; i += 256) act[(i >> 1) * RS1 + (i & 1) * (WS1 - 1)] = 0.f;   // x[-1], x[150]
+        for (int i = tid; i < 2 * RS1; i += 256) act[CH * RS1 + i] = 0.f;                          // channels 54, 55
+    }
+    __syncthreads();
+    const bool nan0 = __builtin_amdgcn_readfirstlane(nanflag[0]) != 0;
+    const float* bias_lds = act + WACT_FLOATS;
+    const float* xrow1 = act + q * RS1;
+    const float* xrow2 = act + q * RS2;
+    const float4* ap2 = reinterpret_cast<const float4*>(pk.ww[1]) + (wv >> 1) * (16 * 128) + 2 * lane + (wv & 1);
+    const float4* ap3 = reinterpret_cast<const float4*>(pk.ww[2]) + wv * (16 * 128) + 2 * lane;
+    const float4* ap4 = reinterpret_cast<const float4*>(pk.ww[3]) + wv * (32 * 128) + 2 * lane;
+    {   // ---- stage 1: wave = row tile wv (16 output channels) x all 5 column tiles
+        f32x4 acc[1][5][4];
+        int boff[5];
+        const int co0 = 16 * wv;
+        col_offsets<TP1, WS1, 5, 1>(0, j, boff);
+        wino_mfma_deep<RS1, 14, 1, 5, PF, 1, 0>(xrow1, boff, ap1, ap2, ring, bias_lds, co0, lane, acc);
+        __syncthreads();
+        wino_store_plain<RS1, WS1, TP1, 150, 1, 5, 1>(act, acc, co0, 0, lane);
+        __syncthreads();
+        wino_mfma_deep<RS1, 16, 1, 5, PF, 2, 14 % PF>(xrow1, boff, ap2, ap3, ring, bias_lds + 64, co0, lane, acc);
+        __syncthreads();
+        wino_store_pool_stage2<1, 5, 1>(act, acc, co0, 0, lane);
+        for (int i = tid; i < 128 * 3; i += 256) {       // stage-2 pads: index 0, 76, 77
+            const int c = i / 3, k = i % 3;
+            act[c * RS2 + (k == 0 ? 0 : 75 + k)] = 0.f;
+        }
+    }
+    {   // ---- stage 2: wave = row-tile pair wv (32 output channels) x 3 column tiles
+        f32x4 acc[2][3][4];
+        int boff[3];
+        const int co2 = 32 * wv;
+        col_offsets<TP2, WS2, 3, 1>(0, j, boff);
+        __syncthreads();
+        wino_mfma_deep<RS2, 16, 2, 3, PF, 2, 30 % PF>(xrow2, boff, ap3, ap4, ring, bias_lds + 128, co2, lane, acc);
+        __syncthreads();
+        wino_store_plain<RS2, WS2, TP2, 75, 2, 3, 1>(act, acc, co2, 0, lane);
+        __syncthreads();
+        wino_mfma_deep<RS2, 32, 2, 3, PF, 2, 46 % PF>(xrow2, boff, ap4, nullptr, ring, bias_lds + 256, co2, lane, acc);
+        wino_store_feat<float, 2, 3, 1>(feat, win0, 1, acc, co2, lane, nan0, false);
+    }
+}
+
 #if DCE_TRACE
 }  // namespace dce
 extern "C" int dce_debug_trace_read_wino(unsigned long long* out, int nblocks)
@@ -492,7 +628,10 @@ hipError_t init_conv_wino()
     if ((e = grant_wino_lds<true, float>()) != hipSuccess) return e;
     if ((e = grant_wino_lds<false, float>()) != hipSuccess) return e;
     if ((e = grant_wino_lds<true, unsigned short>()) != hipSuccess) return e;
-    return grant_wino_lds<false, unsigned short>();
+    if ((e = grant_wino_lds<false, unsigned short>()) != hipSuccess) return e;
+    for (const void* k : {reinterpret_cast<const void*>(&conv_wino1_kernel<true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvPack& pk,
@@ -504,6 +643,13 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
     if (getenv("DCE_ONE_PER_CU")) lds = 100 * 1024;      // debug: force one workgroup per CU
 #endif
     const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
+    if (!feat_bf16 && n <= WINO1_MAX_N && !DCE_TRACE) {
+        // at most one workgroup per CU: one window each finishes in 56 % of a two-window workgroup's time
+        float* f = static_cast<float*>(feat);
+        if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f);
+        else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f);
+        return hipGetLastError();
+    }
     if (feat_bf16) {
         unsigned short* f = static_cast<unsigned short*>(feat);
         if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f);

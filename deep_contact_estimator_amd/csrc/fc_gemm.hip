@@ -32,6 +32,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef DCE_GEMM_GLDS
 #define DCE_GEMM_GLDS 0      // fc.0 through the LDS-direct (global_load_lds) variant
 #endif
+#ifndef DCE_GEMM_FRAGPF
+#define DCE_GEMM_FRAGPF 0     // register double-buffering of the LDS fragments
+#endif
 #ifndef DCE_GEMM_8WAVE
 #define DCE_GEMM_8WAVE 0     // 128x128 tile on 8 waves (4 waves/SIMD) instead of 4 waves
 #endif
@@ -164,13 +167,34 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 
         const char* as = As + cur * Cfg::A_BYTES + fa;
         const char* bs = Bs + cur * Cfg::B_BYTES + fb;
+#if DCE_GEMM_FRAGPF
+        // fragments double-buffered in registers: the reads of K slice kq+1 are issued before the
+        // MFMAs of slice kq, so only the first slice of a K-tile waits out an LDS round trip
+        float4 afq[2][TM], bfq[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) afq[0][a] = *reinterpret_cast<const float4*>(as + 32 * a * LDR);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bfq[0][b] = *reinterpret_cast<const float4*>(bs + 32 * b * LDR);
+#endif
 #pragma unroll
         for (int kq = 0; kq < KT_BYTES / 32; ++kq) {
+#if DCE_GEMM_FRAGPF
+            if (kq + 1 < KT_BYTES / 32) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) afq[(kq + 1) & 1][a] = *reinterpret_cast<const float4*>(as + 32 * a * LDR + 32 * (kq + 1));
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bfq[(kq + 1) & 1][b] = *reinterpret_cast<const float4*>(bs + 32 * b * LDR + 32 * (kq + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float4 (&af)[TM] = afq[kq & 1];
+            float4 (&bf)[TN] = bfq[kq & 1];
+#else
             float4 af[TM], bf[TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(as + 32 * a * LDR + 32 * kq);
 #pragma unroll
             for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(bs + 32 * b * LDR + 32 * kq);
+#endif
             if constexpr (BF16) {
                 // lane (i,h) holds k = 16*kq + 8*h .. +7 of its row: the 32x32x16 fragment
 #pragma unroll
@@ -192,6 +216,9 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
                         }
             }
+#if DCE_GEMM_FRAGPF
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         char* ad = As + (cur ^ 1) * Cfg::A_BYTES + sdst;
         char* bd = Bs + (cur ^ 1) * Cfg::B_BYTES + sdst;

@@ -102,20 +102,24 @@ def test_forward_windows_vs_oracle(n, models, orc):
     tol_ok(m(x), ref["logits"], "__call__")
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 8, 9, 16, 17, 30, 32])
-def test_small_batch_gemv_is_bit_identical_to_gemm(n, models):
+@pytest.mark.parametrize("n", [1, 2, 5, 8, 9, 16, 17, 30, 32, 100, 256])
+def test_small_batch_kernels_are_bit_identical(n, models):
     """<= 32 windows (batch_size 1 and 30 of the reference's configs) take the weight-streaming GEMV kernels (csrc/fc_gemv.hip); they walk K in the
     order the MFMA GEMM does, so every FC activation and logit must equal, bit for bit, the rows the
-    same windows get inside a large batch (MFMA tiles)."""
+    same windows get inside a large batch (MFMA tiles).  Likewise <= 256 windows take the
+    one-window-per-workgroup conv kernel (conv_wino1_kernel): same per-accumulator K order, so the
+    features are the bits of the two-window kernel."""
     rng = np.random.default_rng(900 + n)
     x = rng.standard_normal((300, 150, 54), dtype=np.float32)
     m = models()
     big, small = m.forward_taps(x), m.forward_taps(x[:n])
     for k in ("feat", "h1", "h2", "logits"):
         assert np.array_equal(small[k], big[k][:n]), k
-    # 33 windows are back on the GEMM (64x64 tiles): same bits again
-    more = m.forward_taps(x[:33])
-    assert np.array_equal(more["logits"], big["logits"][:33])
+    # 33 windows are back on the GEMM (64x64 tiles), 257 on the two-window conv kernel with an odd
+    # tail: same bits again
+    for k in (33, 257):
+        more = m.forward_taps(x[:k])
+        assert np.array_equal(more["feat"], big["feat"][:k]) and np.array_equal(more["logits"], big["logits"][:k])
 
 
 def test_chunking_and_determinism(models, orc):
