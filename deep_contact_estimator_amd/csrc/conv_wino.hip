@@ -643,7 +643,8 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
     if (getenv("DCE_ONE_PER_CU")) lds = 100 * 1024;      // debug: force one workgroup per CU
 #endif
     const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
-    if (!feat_bf16 && n <= WINO1_MAX_N && !DCE_TRACE) {
+    static const int64_t wino1_max = getenv("DCE_WINO1_MAX") ? atoll(getenv("DCE_WINO1_MAX")) : WINO1_MAX_N;
+    if (!feat_bf16 && n <= wino1_max && !DCE_TRACE) {
         // at most one workgroup per CU: one window each finishes in 56 % of a two-window workgroup's time
         float* f = static_cast<float*>(feat);
         if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f);
