@@ -105,6 +105,9 @@ struct A8 { float4 m0, m1; };            // this lane's weights for one K-step: 
 template <int MTT = 2>
 __device__ __forceinline__ A8 load_a8(const float4* __restrict__ ap, int s)
 {   // MTT = 1: ap is pre-offset to this wave's half of the row-tile pair; m1 is never read
+#if WINO_EXP & 4
+    s = 0;                                               // ablation: every K-step re-reads one L1-hot line
+#endif
     A8 a; a.m0 = ap[s * 128]; a.m1 = MTT == 2 ? ap[s * 128 + 1] : a.m0; return a;
 }
 

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Turn the raw outputs of tools/profile_gpu.sh <tag> (under gpurun_out/) into the tracked
+summaries under profiles/: <tag>_kernel_stats.csv, <tag>_pmc_summary.md, pmc_latest.json.
+Usage: tools/make_profile_summary.py <tag>"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import pmc_summary  # noqa: E402
+
+B = 4096
+# algorithmic bytes per window (DESIGN.md 4.x / SURVEY.md 8(d)); weights once per launch
+ALGO = {
+    "conv_stack": 51344 * B + 4 * (96768 + 384),
+    "fc1_gemm(128x128)": (18944 + 8192) * B + 4 * (2048 * 4736 + 2048),
+    "fc2_gemm(64x64)": (8192 + 2048) * B + 4 * (512 * 2048 + 512),
+    "fc3_tail": (2048 + 64 + 4 + 4) * B + 4 * (16 * 512 + 16),
+}
+NAMES = {"conv_stack": "conv_stack", "fc1_gemm(128x128)": "fc1_gemm", "fc2_gemm(64x64)": "fc2_gemm", "fc3_tail": "fc3_tail"}
+
+
+def main(tag):
+    out = os.path.join(ROOT, "gpurun_out")
+    shutil.copy(os.path.join(out, f"{tag}_stats", f"{tag}_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+    avg_us = {}
+    for r in csv.DictReader(open(os.path.join(out, f"{tag}_stats", f"{tag}_kernel_stats.csv"))):
+        avg_us[pmc_summary.short(r["Name"])] = float(r["AverageNs"]) / 1e3
+    ctr = {}
+    for part in ("fetch", "write", "sq", "lds"):
+        p = os.path.join(out, f"{tag}_pmc_{part}", f"{tag}_counter_collection.csv")
+        for k, v in pmc_summary.main([p]).items():
+            ctr.setdefault(k, {}).update(v)
+    lines = [f"rocprofv3 passes of tools/profile_gpu.sh {tag}; {B} windows per launch. Kernel-trace averages: `python bench.py --steps 300 --warmup 50 "
+             "--no-cpu-baseline` (long enough for the clocks to settle: they agree with the HIP-event times in the bench json of the same tag to <1 %); "
+             "PMC passes: `--steps 20 --warmup 3`, one counter group per pass.",
+             "",
+             "| kernel | avg us (kernel-trace) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes/launch (2*FETCH+WRITE)*1024 | algorithmic bytes/launch | ratio | MFMA busy (SQ_VALU_MFMA_BUSY/1024 / GRBM_GUI_ACTIVE/8) | LDS bank-conflict cycles / LDS active cycles |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    latest = {}
+    for k, algo in ALGO.items():
+        c = ctr.get(k)
+        if not c:
+            continue
+        hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (c["GRBM_GUI_ACTIVE"] / 8)
+        lines.append(f"| {NAMES[k]} | {avg_us.get(k, float('nan')):.1f} | {c['FETCH_SIZE']:.0f} | {c['WRITE_SIZE']:.0f} | {hbm / 1e6:.1f} MB | "
+                     f"{algo / 1e6:.1f} MB | {hbm / algo:.2f} | {busy:.3f} | {c.get('SQ_LDS_BANK_CONFLICT', 0):.3g} / {c.get('SQ_LDS_IDX_ACTIVE', 0):.3g} |")
+        latest[NAMES[k]] = {"hbm_bytes_per_launch": hbm, "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
+                            "algorithmic_bytes_per_launch": algo, "mfma_busy_frac": busy, "profile": tag,
+                            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 counts 128-B requests as 64 B)"}
+    open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
+    json.dump(latest, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
