@@ -5,6 +5,7 @@
 // No exception or abort crosses the boundary; every failure is a negative dce_status plus a message.
 #include "../../include/dce.h"
 #include "dce_kernels.h"
+#include <chrono>
 
 #include <cstdarg>
 #include <cstdio>
@@ -65,8 +66,10 @@ struct dce_ctx {
     // online mode: linear buffer of ONLINE_ROWS sample rows; the live window is its last 150 rows
     float* d_ring = nullptr;
     int64_t ring_rows = 0;
-    float* d_online_out = nullptr;         // logits(16) | pred | contacts, on device
-    float* h_online_pin = nullptr;         // pinned mirror of the above + the incoming sample
+    float* h_online_pin = nullptr;         // pinned, device-visible: logits(16) | pred | contacts | ... | flag
+    unsigned online_seq = 0;
+    unsigned* done_flag = nullptr;         // set around an online push: the tail kernel publishes done_seq there
+    unsigned done_seq = 0;
 
     // profiling
     int prof_period = 0;                   // 0 = off, k = time every k-th kernel sequence
@@ -152,7 +155,7 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
         { Timer t(c, 2); HIP_TRY(c, fc(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
     }
-    { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream)); }
+    { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream, c->done_flag, c->done_seq)); }
     if (c->spans.size() > 4096) return drain_spans(c);
     return DCE_OK;
 }
@@ -313,7 +316,7 @@ void dce_destroy(dce_ctx* c)
     for (auto e : c->xfer_ev) hipEventDestroy(e);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2);
     hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts);
-    hipFree(c->d_ring); hipFree(c->d_online_out);
+    hipFree(c->d_ring);
     if (c->h_online_pin) hipHostFree(c->h_online_pin);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -534,29 +537,45 @@ int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pre
     if (!sample) return fail(c, DCE_ERR_ARG, "dce_online_push: NULL sample");
     if (!c->d_ring) {
         HIP_TRY(c, hipMalloc(&c->d_ring, ONLINE_ROWS * CH * sizeof(float)));
-        HIP_TRY(c, hipMalloc(&c->d_online_out, 32 * sizeof(float)));
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_online_pin), (32 + CH) * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_online_pin), 64 * sizeof(float), hipHostMallocDefault));
+        memset(c->h_online_pin, 0, 64 * sizeof(float));
     }
     if (c->ring_rows == ONLINE_ROWS) {                  // keep the last 149 rows, restart at the front
         HIP_TRY(c, hipMemcpyAsync(c->d_ring, c->d_ring + (ONLINE_ROWS - (WIN - 1)) * CH,
                                   (WIN - 1) * CH * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         c->ring_rows = WIN - 1;
     }
-    memcpy(c->h_online_pin + 32, sample, CH * sizeof(float));
-    HIP_TRY(c, hipMemcpyAsync(c->d_ring + c->ring_rows * CH, c->h_online_pin + 32, CH * sizeof(float),
-                              hipMemcpyHostToDevice, c->stream));
+    // The sample rides in the kernel arguments of a one-wave append kernel (no H2D copy); the tail
+    // kernel writes the result straight into pinned host memory and then a sequence number that
+    // this thread polls (no D2H copy, no stream synchronisation on the latency path).
+    OnlineSample s;
+    memcpy(s.v, sample, CH * sizeof(float));
+    HIP_TRY(c, launch_online_append(c->d_ring + c->ring_rows * CH, s, c->stream));
     c->ring_rows += 1;
-    if (c->ring_rows < WIN) { HIP_TRY(c, hipStreamSynchronize(c->stream)); return 0; }
-    float* dl = c->d_online_out;
-    int32_t* dp = reinterpret_cast<int32_t*>(c->d_online_out + 16);
-    uint8_t* dc = reinterpret_cast<uint8_t*>(c->d_online_out + 17);
-    rc = run_chunk(c, c->d_ring + (c->ring_rows - WIN) * CH, 1, 1, dl, dp, dc);
+    if (c->ring_rows < WIN) return 0;
+    float* hl = c->h_online_pin;
+    int32_t* hp = reinterpret_cast<int32_t*>(c->h_online_pin + 16);
+    uint8_t* hc = reinterpret_cast<uint8_t*>(c->h_online_pin + 17);
+    unsigned* flag = reinterpret_cast<unsigned*>(c->h_online_pin + 32);
+    c->done_flag = flag;
+    c->done_seq = ++c->online_seq;
+    if (c->done_seq == 0) c->done_seq = ++c->online_seq;          // 0 is the idle value
+    rc = run_chunk(c, c->d_ring + (c->ring_rows - WIN) * CH, 1, 1, hl, hp, hc);
+    c->done_flag = nullptr;
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->h_online_pin, c->d_online_out, 18 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (logits) memcpy(logits, c->h_online_pin, NCLS * sizeof(float));
-    if (pred) memcpy(pred, c->h_online_pin + 16, sizeof(int32_t));
-    if (contacts) memcpy(contacts, c->h_online_pin + 17, 4);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));         // something is wrong or very slow: fall back
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq)
+                return fail(c, DCE_ERR_HIP, "dce_online_push: the result never arrived");
+            break;
+        }
+    }
+    if (logits) memcpy(logits, hl, NCLS * sizeof(float));
+    if (pred) memcpy(pred, hp, sizeof(int32_t));
+    if (contacts) memcpy(contacts, hc, 4);
     return 1;
 }
 

@@ -60,8 +60,15 @@ hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, 
                                int64_t M, int N, int K, int relu, hipStream_t st);
 
 // logits = h2 * W3^T + b3 ; argmax (first max, NaN-first) ; 4-bit unpack (MSB = leg 0)
+// done_flag (optional, single-block launches only): a system-scope release store of done_seq after the
+// outputs, for a host that polls instead of synchronising the stream (online mode).
 hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,
-                           float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st);
+                           float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st,
+                           unsigned* done_flag = nullptr, unsigned done_seq = 0);
+
+// online mode: write one (54,) sample, carried in the kernel arguments, to its row of the sample buffer
+struct OnlineSample { float v[54]; };
+hipError_t launch_online_append(float* row, const OnlineSample& s, hipStream_t st);
 
 // counts[gt*16 + pred] += 1 over n (pred, label) pairs; out-of-range classes are skipped
 hipError_t launch_confusion16(const int32_t* pred, const int64_t* label, int64_t n,

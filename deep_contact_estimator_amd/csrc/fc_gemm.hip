@@ -496,7 +496,8 @@ constexpr int TAIL_WINDOWS = 16;       // windows per 256-thread block (16 lanes
 __global__ __launch_bounds__(256)
 void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                      const float* __restrict__ b3, int64_t n, float* __restrict__ logits,
-                     int32_t* __restrict__ pred, uint8_t* __restrict__ contacts)
+                     int32_t* __restrict__ pred, uint8_t* __restrict__ contacts,
+                     unsigned* __restrict__ done_flag, unsigned done_seq)
 {
     __shared__ float w3s[NCLS * (FC2 + 1)];              // [class][k], rows padded to 513 floats:
     __shared__ float lg[TAIL_WINDOWS][NCLS];             // staging stores and the per-class reads
@@ -544,16 +545,38 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
             }
         }
     }
+    if (done_flag) {
+        // online mode (one block, outputs in pinned host memory): publish completion to a host that
+        // polls the flag instead of paying for a D2H copy and a stream synchronisation
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,
-                           float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st)
+                           float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st,
+                           unsigned* done_flag, unsigned done_seq)
 {
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n + TAIL_WINDOWS - 1) / TAIL_WINDOWS;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(fc3_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                       h2, W3, b3, n, logits, pred, contacts);
+                       h2, W3, b3, n, logits, pred, contacts, blocks == 1 ? done_flag : nullptr, done_seq);
+    return hipGetLastError();
+}
+
+// online mode: the new sample travels in the kernel arguments (no H2D copy) into its row of the
+// device-resident sample buffer
+__global__ __launch_bounds__(64)
+void online_append_kernel(float* __restrict__ row, OnlineSample s)
+{
+    if (threadIdx.x < CH) row[threadIdx.x] = s.v[threadIdx.x];
+}
+
+hipError_t launch_online_append(float* row, const OnlineSample& s, hipStream_t st)
+{
+    hipLaunchKernelGGL(online_append_kernel, dim3(1), dim3(64), 0, st, row, s);
     return hipGetLastError();
 }
 

@@ -15,11 +15,13 @@
  *       -Ldeep_contact_estimator_amd -ldce -L/opt/rocm/lib -lamdhip64 -lm -o abi_client
  * Exit code 0 and a final line "abi_client: OK" on success.
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "dce.h"
 #include "dce_oracle.h"
@@ -131,6 +133,20 @@ int main(void)
             const int j = t - (DCE_WINDOW - 1);
             CHECK(memcmp(lg, logits + j * DCE_CLASSES, sizeof lg) == 0 && p == pred[j] && memcmp(cb, contacts + 4 * j, 4) == 0,
                   "online row %d differs from dce_infer_sequence", j);
+        }
+    }
+
+    {   /* latency of the online path from C (informative) */
+        for (int round = 0; round < 3; ++round) {
+            struct timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (int rep = 0; rep < 1000; ++rep) {
+                float lg[DCE_CLASSES]; int32_t p; uint8_t cb[4];
+                CHECK(dce_online_push(ctx, seq + (rep % T) * DCE_CHANNELS, lg, &p, cb) == 1, "online push (timing)");
+            }
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            printf("abi_client: dce_online_push %.1f us per sample (1000 pushes, sample in -> estimate out)\n",
+                   ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1000.0 / 1e3);
         }
     }
 
