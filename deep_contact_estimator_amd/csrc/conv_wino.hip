@@ -545,7 +545,10 @@ void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
     int* nanflag = reinterpret_cast<int*>(act + WACT_FLOATS + 384);
     if (tid == 0) nanflag[0] = 0;
     // conv1's first PF K-steps of weights are requested before the window itself
-    constexpr int PF = 8;                                 // weight prefetch depth, K-steps
+#ifndef WINO1_PF
+#define WINO1_PF 8
+#endif
+    constexpr int PF = WINO1_PF;                          // weight prefetch depth, K-steps
     A8 ring[PF];
     const float4* ap1 = reinterpret_cast<const float4*>(pk.ww[0]) + (wv >> 1) * (14 * 128) + 2 * lane + (wv & 1);
 #pragma unroll
