@@ -585,6 +585,9 @@ hipError_t launch_online_append(float* row, const OnlineSample& s, hipStream_t s
 // reference's src/test.py:19-70 prints (per-leg 2x2 confusion, FN/FP rates, precision, Jaccard,
 // class / leg accuracy).  Integer histogram: LDS atomics per block, one global atomic per bin.
 // ------------------------------------------------------------------------------------------
+// HBM-bound integer work: 12 B per window (i32 prediction + i64 label).  VEC: four windows per thread
+// per trip through 16-byte loads (one for the predictions, two for the labels), two trips in flight.
+template <bool VEC>
 __global__ __launch_bounds__(256)
 void confusion16_kernel(const int32_t* __restrict__ pred, const int64_t* __restrict__ label,
                         int64_t n, unsigned long long* __restrict__ counts)
@@ -592,10 +595,30 @@ void confusion16_kernel(const int32_t* __restrict__ pred, const int64_t* __restr
     __shared__ unsigned int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int p = pred[i];
-        const int64_t g = label[i];
+    auto tally = [&](int p, int64_t g) {
         if (p >= 0 && p < 16 && g >= 0 && g < 16) atomicAdd(&h[(int)g * 16 + p], 1u);
+    };
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthr = (int64_t)gridDim.x * 256;
+    if (VEC) {
+        const int64_t n4 = n / 4;
+        const int4* p4 = reinterpret_cast<const int4*>(pred);
+        const longlong2* g2 = reinterpret_cast<const longlong2*>(label);
+        int64_t i = tid;
+        for (; i + nthr < n4; i += 2 * nthr) {             // two independent trips per iteration
+            const int4 pa = p4[i], pb = p4[i + nthr];
+            const longlong2 ga0 = g2[2 * i], ga1 = g2[2 * i + 1];
+            const longlong2 gb0 = g2[2 * (i + nthr)], gb1 = g2[2 * (i + nthr) + 1];
+            tally(pa.x, ga0.x); tally(pa.y, ga0.y); tally(pa.z, ga1.x); tally(pa.w, ga1.y);
+            tally(pb.x, gb0.x); tally(pb.y, gb0.y); tally(pb.z, gb1.x); tally(pb.w, gb1.y);
+        }
+        if (i < n4) {
+            const int4 pa = p4[i];
+            const longlong2 ga0 = g2[2 * i], ga1 = g2[2 * i + 1];
+            tally(pa.x, ga0.x); tally(pa.y, ga0.y); tally(pa.z, ga1.x); tally(pa.w, ga1.y);
+        }
+        if (tid < (n & 3)) tally(pred[4 * n4 + tid], label[4 * n4 + tid]);
+    } else {
+        for (int64_t i = tid; i < n; i += nthr) tally(pred[i], label[i]);
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
@@ -605,9 +628,11 @@ hipError_t launch_confusion16(const int32_t* pred, const int64_t* label, int64_t
                               unsigned long long* counts, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(confusion16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, label, n, counts);
+    const bool vec = (reinterpret_cast<uintptr_t>(pred) % 16 == 0) && (reinterpret_cast<uintptr_t>(label) % 16 == 0);
+    int64_t blocks = ((vec ? (n + 3) / 4 : n) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (vec) hipLaunchKernelGGL(confusion16_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, pred, label, n, counts);
+    else     hipLaunchKernelGGL(confusion16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, pred, label, n, counts);
     return hipGetLastError();
 }
 

@@ -332,6 +332,12 @@ def test_confusion_counts_on_device(golden, models):
         Cd = m.confusion_counts(pd[lo:lo + 300_000], ld[lo:lo + 300_000], Cd)
     assert Cd.is_cuda and np.array_equal(Cd.cpu().numpy(), ref)
     assert np.array_equal(m.confusion_counts(pred, lab), ref)          # host pointers
+    # slices that break the 16-byte alignment of the vector path, and every tail length n % 4
+    for off, cnt in ((1, 1001), (2, 1002), (3, 1003), (5, 4), (7, 3), (0, 1)):
+        sl = slice(off, off + cnt)
+        keep = lab[sl] < 16
+        want = metrics.confusion16(pred[sl][keep], lab[sl][keep])
+        assert np.array_equal(m.confusion_counts(pd[sl], ld[sl]).cpu().numpy(), want), (off, cnt)
     assert m.confusion_counts(pred[:0], lab[:0]).sum() == 0            # empty
 
 
