@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (run on the GPU box; not part of the timed test suite): random batch
+sizes around every kernel-selection threshold (GEMV <= 32, one-window conv <= 256, 64x64 vs 128x128
+GEMM tiles, max_batch chunking), random checkpoints (He-normal x random gain, non-zero biases) and
+random input statistics, checked against the CPU oracle (tolerance + argmax contract) and for
+bit-identity between the streaming (fused z-score) path, the materialised-window path and the
+same windows embedded in a larger batch."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deep_contact_estimator_amd import contact_cnn, synth
+from oracle import oracle as orc
+
+TRIALS = int(os.environ.get("TRIALS", 120))
+rng = np.random.default_rng(int(os.environ.get("SEED", 2024)))
+edges = [1, 2, 3, 8, 9, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 513, 700]
+worst, flips, total = 0.0, 0, 0
+t0 = time.time()
+for trial in range(TRIALS):
+    seed = int(rng.integers(1, 1 << 30))
+    sd = synth.make_state_dict(seed, "uniform")
+    gain = float(rng.uniform(0.6, 1.6))
+    sd = {k: (v * gain if k.endswith("weight") else v) for k, v in sd.items()}
+    n = int(rng.choice(edges)) if rng.random() < 0.7 else int(rng.integers(1, 700))
+    kind = "ar1" if rng.random() < 0.5 else "normal"
+    seq = synth.make_sequence(n + 149, int(rng.integers(0, 1 << 30)), kind).astype(np.float32)
+    if rng.random() < 0.3:                                   # wild per-channel scales / offsets
+        seq = seq * (10.0 ** rng.uniform(-3, 3, 54)).astype(np.float32) + rng.uniform(-100, 100, 54).astype(np.float32)
+    mb = int(rng.choice([64, 96, 300, 4096]))
+    m = contact_cnn(device=0, max_batch=mb)
+    m.load_state_dict(sd).eval()
+    ref = orc.Oracle(sd).infer_sequence(seq)
+    a = m.infer_sequence(seq)                                # streaming, fused z-score, chunked by mb
+    w = m.zscore_windows(seq)
+    b = m.predict(w)                                         # materialised windows
+    scale = np.abs(ref["logits"]).max()
+    for tag, o in (("stream", a), ("windows", b)):
+        bound = 1e-5 * scale + 1e-4 * np.abs(ref["logits"])
+        r = float((np.abs(o["logits"] - ref["logits"]) / bound).max())
+        worst = max(worst, r)
+        assert r <= 1.0, (trial, tag, n, seed, r)
+        srt = np.sort(ref["logits"], axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-3 * scale
+        assert np.array_equal(o["pred"][clear], ref["pred"][clear]), (trial, tag, "argmax")
+        flips += int((o["pred"] != ref["pred"]).sum()); total += n
+        bits = ((o["pred"][:, None] >> np.array([3, 2, 1, 0])) & 1).astype(np.uint8)
+        assert np.array_equal(o["contacts"], bits), (trial, tag, "bits")
+    # the same windows, alone and as the head of a 2x larger batch: same bits whatever kernels ran
+    big = contact_cnn(device=0, max_batch=4096)
+    big.load_state_dict(sd).eval()
+    w2 = np.concatenate([w, w[::-1]], 0)[: max(n + 300, 2 * n)] if n < 4096 else w
+    if len(w2) < n + 300:
+        w2 = np.concatenate([w2, np.repeat(w[:1], n + 300 - len(w2), 0)], 0)
+    c = big.predict(w2)
+    assert np.array_equal(c["logits"][:n], b["logits"]), (trial, "embedding", n, mb)
+    m.close(); big.close()
+print(json.dumps({"trials": TRIALS, "windows": total, "worst_err_over_bound": worst, "sub_margin_argmax_flips": flips,
+                  "seconds": round(time.time() - t0, 1)}))
