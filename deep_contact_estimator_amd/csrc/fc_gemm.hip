@@ -19,6 +19,7 @@
 //    W3), then argmax with torch.max semantics (first maximum; a NaN wins, first NaN first)
 //    and the 4-bit unpack, MSB = leg 0.
 #include "dce_kernels.h"
+#include <cstdlib>
 
 namespace dce {
 
@@ -411,6 +412,118 @@ void fc_gemm_glds_kernel(const void* __restrict__ Av, const void* __restrict__ W
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 64x64 tiles for batches that do not fill the chip (33 .. ~3000 windows: at most one block per CU).
+// Nothing then overlaps a block's K-tile with another's, and a K-tile (16 MFMAs per wave, ~0.45 us)
+// is shorter than the memory round trip of its successor: with one tile of lookahead fc.0 walked
+// K at 0.75 us per tile.  Here the staging loads run GS_DEPTH tiles ahead through a register ring
+// (asm loads + counted vmcnt, as above).  Tiling, K order and epilogue are fc_gemm_kernel<1,1>'s:
+// bit-identical results.
+// ------------------------------------------------------------------------------------------
+constexpr int GS_DEPTH = 4;
+
+__global__ __launch_bounds__(256, 2)
+void fc_gemm_small_kernel(const float* __restrict__ Af, const float* __restrict__ Wf,
+                          const float* __restrict__ bias, float* __restrict__ C,
+                          int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
+{
+    using Cfg = GemmCfg<1, 1, 2>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, RPP = Cfg::RPP;
+    static_assert(BM / RPP == 2 && BN / RPP == 2 && KT_BYTES == 128, "two 16-byte pieces per operand per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + 2 * Cfg::A_BYTES;
+    const char* A = reinterpret_cast<const char*>(Af);
+    const char* W = reinterpret_cast<const char*>(Wf);
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, li = bid >> 3;
+    const int sid = (li >> 6) * 8 + xcd;
+    const int within = li & 63;
+    const int sn = 1 << sn_log2, sm = 64 >> sn_log2;
+    const int nsn = ntiles >> sn_log2;
+    const int tm = (sid / nsn) * sm + (within >> sn_log2);
+    const int tn = (sid % nsn) * sn + (within & (sn - 1));
+    if (tm >= mtiles) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;
+    const int i = lane & 31, h = lane >> 5;
+    const int srow = tid / CPR, sk4 = tid % CPR;
+    const size_t rowb = (size_t)K * 4;
+    int r0 = m0 + srow, r1 = m0 + srow + RPP;
+    r0 = r0 < M ? r0 : M - 1; r1 = r1 < M ? r1 : M - 1;
+    const char* ag0 = A + (size_t)r0 * rowb + 16 * sk4;
+    const char* ag1 = A + (size_t)r1 * rowb + 16 * sk4;
+    const char* bg0 = W + (size_t)(n0 + srow) * rowb + 16 * sk4;
+    const char* bg1 = W + (size_t)(n0 + srow + RPP) * rowb + 16 * sk4;
+    const int sdst = srow * LDR + 16 * sk4;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int KT = (int)(rowb / KT_BYTES);               // a multiple of GS_DEPTH (checked by the launcher)
+
+    *reinterpret_cast<float4*>(As + sdst) = *reinterpret_cast<const float4*>(ag0);
+    *reinterpret_cast<float4*>(As + sdst + RPP * LDR) = *reinterpret_cast<const float4*>(ag1);
+    *reinterpret_cast<float4*>(Bs + sdst) = *reinterpret_cast<const float4*>(bg0);
+    *reinterpret_cast<float4*>(Bs + sdst + RPP * LDR) = *reinterpret_cast<const float4*>(bg1);
+
+    // ring slot of tile t = t % 4; four named register quads (a0, a1, b0, b1) per slot
+    v4f q0a0, q0a1, q0b0, q0b1, q1a0, q1a1, q1b0, q1b1, q2a0, q2a1, q2b0, q2b1, q3a0, q3a1, q3b0, q3b1;
+#define GS_LD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
+#define GS_LOAD(S, tile)                                                                          \
+    { const size_t ko = (size_t)((tile) < KT ? (tile) : KT - 1) * KT_BYTES;                       \
+      GS_LD(q##S##a0, ag0 + ko); GS_LD(q##S##a1, ag1 + ko); GS_LD(q##S##b0, bg0 + ko); GS_LD(q##S##b1, bg1 + ko); }
+    GS_LOAD(1, 1) GS_LOAD(2, 2) GS_LOAD(3, 3)
+    __syncthreads();
+
+    const int fa = (wm + i) * LDR + 16 * h, fb = (wn + i) * LDR + 16 * h;
+    auto compute = [&](int cur) {
+        const char* as = As + cur * Cfg::A_BYTES + fa;
+        const char* bs = Bs + cur * Cfg::B_BYTES + fb;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const float4 af = *reinterpret_cast<const float4*>(as + 32 * kq);
+            const float4 bf = *reinterpret_cast<const float4*>(bs + 32 * kq);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+        }
+    };
+    // one K-tile: refill the slot tile kt left free with tile kt+4, multiply tile kt out of LDS, then
+    // hand tile kt+1 (the oldest of the four in flight: 12 younger loads may stay outstanding) to LDS
+#define GS_STEP(SFREE, SNEXT, kt)                                                                 \
+    { GS_LOAD(SFREE, (kt) + GS_DEPTH)                                                             \
+      compute((kt) & 1);                                                                          \
+      asm volatile("s_waitcnt vmcnt(12)" : "+v"(q##SNEXT##a0), "+v"(q##SNEXT##a1), "+v"(q##SNEXT##b0), "+v"(q##SNEXT##b1)); \
+      char* ad = As + (((kt) + 1) & 1) * Cfg::A_BYTES + sdst;                                     \
+      char* bd = Bs + (((kt) + 1) & 1) * Cfg::B_BYTES + sdst;                                     \
+      *reinterpret_cast<v4f*>(ad) = q##SNEXT##a0; *reinterpret_cast<v4f*>(ad + RPP * LDR) = q##SNEXT##a1; \
+      *reinterpret_cast<v4f*>(bd) = q##SNEXT##b0; *reinterpret_cast<v4f*>(bd + RPP * LDR) = q##SNEXT##b1; \
+      __syncthreads(); }
+    for (int kt = 0; kt < KT; kt += GS_DEPTH) {
+        GS_STEP(0, 1, kt) GS_STEP(1, 2, kt + 1) GS_STEP(2, 3, kt + 2) GS_STEP(3, 0, kt + 3)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's trailing (clamped) loads
+#undef GS_STEP
+#undef GS_LOAD
+#undef GS_LD
+
+    const int col = n0 + wn + i;
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[r] + bv;
+        if (relu) v = relu_nan(v);
+        if (row < M) C[(size_t)row * N + col] = v;
+    }
+}
+
 template <int TM, int TN, bool BF16, bool OUT_BF16, int WGN = 2>
 static hipError_t grant_lds()
 {
@@ -422,6 +535,8 @@ hipError_t init_fc_gemm()
 {
     hipError_t e;
     if ((e = grant_lds<2, 2, false, false>()) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_small_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<1, 1, 2>::LDS_BYTES)) != hipSuccess) return e;
     if ((e = grant_lds<2, 1, false, false, 4>()) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_glds_kernel<2, 2, false, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 128 * 128)) != hipSuccess) return e;
@@ -472,6 +587,20 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
     }
 #endif
     if (big_blocks >= 384) return launch_gemm_cfg<2, 2, false, false>(A, W, bias, C, M, N, K, relu, st);
+    static const bool deep = !(getenv("DCE_GEMM_SMALL") && atoi(getenv("DCE_GEMM_SMALL")) == 0);
+    const int64_t small_blocks = ((M + 63) / 64) * (N / 64);
+    if (deep && small_blocks <= 512 && (K * 4 / KT_BYTES) % GS_DEPTH == 0) {
+        using Cfg = GemmCfg<1, 1, 2>;
+        const int mtiles = (int)((M + Cfg::BM - 1) / Cfg::BM), ntiles = N / Cfg::BN;
+        int sn_log2 = 3;
+        while ((1 << sn_log2) > ntiles) --sn_log2;
+        const int sm = 64 >> sn_log2, nsn = ntiles >> sn_log2;
+        const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
+        const int grid = ((nsuper + 7) / 8) * 8 * 64;
+        hipLaunchKernelGGL(fc_gemm_small_kernel, dim3(grid), dim3(256), Cfg::LDS_BYTES, st,
+                           A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+        return hipGetLastError();
+    }
     return launch_gemm_cfg<1, 1, false, false>(A, W, bias, C, M, N, K, relu, st);
 }
 
