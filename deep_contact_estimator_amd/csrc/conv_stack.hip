@@ -397,8 +397,9 @@ hipError_t init_conv_stack()
 }
 
 hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const ConvPack& pk,
-                             void* feat, int feat_bf16, hipStream_t st)
+                             void* feat, int feat_bf16, hipStream_t st, const long long* src_row)
 {
+    if (src_row) return hipErrorNotSupported;          // the online graph runs on the Winograd kernels only
     if (n <= 0) return hipSuccess;
     size_t lds = LDS_FLOATS * sizeof(float);
 #if DCE_TRACE

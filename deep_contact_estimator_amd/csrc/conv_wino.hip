@@ -397,9 +397,11 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
 // ------------------------------------------------------------------------------------------
 template <bool ZS, typename FT>
 __global__ __launch_bounds__(256, 2)
-void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT* __restrict__ feat)
+void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT* __restrict__ feat,
+                      const long long* __restrict__ src_row)
 {
     extern __shared__ __attribute__((aligned(16))) float act[];
+    if (src_row) src += *src_row * CH;                    // online graph: the window start lives in device memory
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, q = lane >> 4;
@@ -528,9 +530,11 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
 // ------------------------------------------------------------------------------------------
 template <bool ZS>
 __global__ __launch_bounds__(256)
-void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat)
+void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat,
+                       const long long* __restrict__ src_row)
 {
     extern __shared__ __attribute__((aligned(16))) float act[];
+    if (src_row) src += *src_row * CH;                    // online graph: the window start lives in device memory
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, q = lane >> 4;
@@ -641,7 +645,7 @@ hipError_t init_conv_wino()
 }
 
 hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvPack& pk,
-                            void* feat, int feat_bf16, hipStream_t st)
+                            void* feat, int feat_bf16, hipStream_t st, const long long* src_row)
 {
     if (n <= 0) return hipSuccess;
     size_t lds = WLDS_FLOATS * sizeof(float);
@@ -653,18 +657,18 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
     if (!feat_bf16 && n <= wino1_max && !DCE_TRACE) {
         // at most one workgroup per CU: one window each finishes in 56 % of a two-window workgroup's time
         float* f = static_cast<float*>(feat);
-        if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f);
-        else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f);
+        if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row);
+        else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row);
         return hipGetLastError();
     }
     if (feat_bf16) {
         unsigned short* f = static_cast<unsigned short*>(feat);
-        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f);
-        else        hipLaunchKernelGGL((conv_wino_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f);
+        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f, src_row);
+        else        hipLaunchKernelGGL((conv_wino_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f, src_row);
     } else {
         float* f = static_cast<float*>(feat);
-        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, float>), grid, block, lds, st, src, n, pk, f);
-        else        hipLaunchKernelGGL((conv_wino_kernel<false, float>), grid, block, lds, st, src, n, pk, f);
+        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, float>), grid, block, lds, st, src, n, pk, f, src_row);
+        else        hipLaunchKernelGGL((conv_wino_kernel<false, float>), grid, block, lds, st, src, n, pk, f, src_row);
     }
     return hipGetLastError();
 }

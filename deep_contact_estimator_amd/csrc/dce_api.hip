@@ -70,6 +70,14 @@ struct dce_ctx {
     unsigned online_seq = 0;
     unsigned* done_flag = nullptr;         // set around an online push: the tail kernel publishes done_seq there
     unsigned done_seq = 0;
+    // online mode as one hipGraph launch per sample (constant launch parameters; see dce_kernels.h)
+    OnlineState* d_online_state = nullptr;
+    const long long* src_row_dev = nullptr;   // set around the graph's kernel sequence
+    unsigned* seq_counter_dev = nullptr;
+    hipGraph_t online_graph = nullptr;
+    hipGraphExec_t online_exec = nullptr;
+    int online_mode = -1;                  // -1 undecided, 0 direct launches, 1 graph
+    bool online_state_dirty = true;        // device state must be zeroed before the next push
 
     // profiling
     int prof_period = 0;                   // 0 = off, k = time every k-th kernel sequence
@@ -145,17 +153,17 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
     if (c->precision == DCE_BF16_FC) {
         // conv stack in fp32 -> bf16 features; fc.0 / fc.3 on bf16 MFMA with fp32 accumulate
         // (feat and h1 scratch hold bf16 here); fc.6 + argmax stay fp32
-        { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream)); }
+        { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream, c->src_row_dev)); }
         { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
         { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, c->stream)); }
     } else {
-        { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream)); }
+        { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream, c->src_row_dev)); }
         // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
         auto fc = (c->gemv && n <= FC_GEMV_MAX_M) ? launch_fc_gemv : launch_fc_gemm;
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
         { Timer t(c, 2); HIP_TRY(c, fc(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
     }
-    { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream, c->done_flag, c->done_seq)); }
+    { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream, c->done_flag, c->done_seq, c->seq_counter_dev)); }
     if (c->spans.size() > 4096) return drain_spans(c);
     return DCE_OK;
 }
@@ -316,7 +324,9 @@ void dce_destroy(dce_ctx* c)
     for (auto e : c->xfer_ev) hipEventDestroy(e);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2);
     hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts);
-    hipFree(c->d_ring);
+    if (c->online_exec) hipGraphExecDestroy(c->online_exec);
+    if (c->online_graph) hipGraphDestroy(c->online_graph);
+    hipFree(c->d_ring); hipFree(c->d_online_state);
     if (c->h_online_pin) hipHostFree(c->h_online_pin);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -367,6 +377,9 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     for (int k = 0; k < 14; ++k)
         if (!c->have[k]) return fail(c, DCE_ERR_STATE, "missing state_dict key '%s'", kKeys[k].name);
     HIP_TRY(c, hipSetDevice(c->device));
+    // a captured online graph holds the old weight pointers / precision: drop it, the next push re-captures
+    if (c->online_exec) { hipGraphExecDestroy(c->online_exec); c->online_exec = nullptr; }
+    if (c->online_graph) { hipGraphDestroy(c->online_graph); c->online_graph = nullptr; }
 
     // one host image -> one upload.  Offsets kept 256-B aligned.
     std::vector<float> img;
@@ -521,14 +534,76 @@ int dce_confusion_counts(dce_ctx* c, const int32_t* pred, const int64_t* labels,
     return DCE_OK;
 }
 
-namespace { constexpr int64_t ONLINE_ROWS = 4096; }     // compaction every 4096 - 149 pushes
-
 int dce_online_reset(dce_ctx* c)
 {
     if (!c) return DCE_ERR_ARG;
     c->ring_rows = 0;
+    c->online_seq = 0;
+    c->online_state_dirty = true;
+    if (c->h_online_pin) reinterpret_cast<unsigned*>(c->h_online_pin + 32)[0] = 0;
     return DCE_OK;
 }
+
+namespace {
+
+// pinned block: [0,16) logits | [16] pred | [17] contacts | [32] completion flag | [40,94) the incoming sample
+constexpr int PIN_FLAG = 32, PIN_SAMPLE = 40, PIN_FLOATS = 96;
+
+int online_wait(dce_ctx* c, unsigned expect)
+{
+    unsigned* flag = reinterpret_cast<unsigned*>(c->h_online_pin + PIN_FLAG);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != expect; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));         // something is wrong or very slow: fall back
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != expect)
+                return fail(c, DCE_ERR_HIP, "dce_online_push: the result never arrived");
+            break;
+        }
+    }
+    return DCE_OK;
+}
+
+// The kernels of one push with CONSTANT launch parameters (what the graph captures): append the
+// sample waiting in pinned memory, run the path on the window the device-side cursor points at,
+// publish the estimate and the next sequence number to pinned memory.
+int online_enqueue(dce_ctx* c)
+{
+    HIP_TRY(c, launch_online_append_state(c->d_ring, c->d_online_state, c->h_online_pin + PIN_SAMPLE, c->stream));
+    const int period = c->prof_period;
+    c->prof_period = 0;                                  // no event records inside the (captured) sequence
+    c->src_row_dev = &c->d_online_state->src_row;
+    c->seq_counter_dev = &c->d_online_state->seq;
+    c->done_flag = reinterpret_cast<unsigned*>(c->h_online_pin + PIN_FLAG);
+    const int rc = run_chunk(c, c->d_ring, 1, 1, c->h_online_pin, reinterpret_cast<int32_t*>(c->h_online_pin + 16),
+                             reinterpret_cast<uint8_t*>(c->h_online_pin + 17));
+    c->src_row_dev = nullptr; c->seq_counter_dev = nullptr; c->done_flag = nullptr;
+    c->prof_period = period;
+    return rc;
+}
+
+// DCE_ONLINE_GRAPH=1: capture online_enqueue once; later pushes are one hipGraphLaunch.  Opt-in:
+// measured on MI355X / ROCm 7.2 (three alternating runs of tests/c/abi_client.c) the graph launch
+// costs 90.1 us per push against 89.1 us for the same five kernels launched one by one -- the
+// launches already hide behind the first kernel -- so plain launches are the default.  Any capture failure (e.g. a caller stream that cannot be captured)
+// leaves online_exec null and the push falls back to plain launches.
+void online_build_graph(dce_ctx* c)
+{
+    const char* want = getenv("DCE_ONLINE_GRAPH");
+    if (c->online_exec || !want || atoi(want) == 0) return;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return; }
+    const int rc = online_enqueue(c);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (rc != DCE_OK || e != hipSuccess || !g) { if (g) hipGraphDestroy(g); (void)hipGetLastError(); return; }
+    hipGraphExec_t x = nullptr;
+    if (hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(g); (void)hipGetLastError(); return; }
+    c->online_graph = g;
+    c->online_exec = x;
+}
+
+}  // namespace
 
 int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pred, uint8_t* contacts)
 {
@@ -536,43 +611,58 @@ int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pre
     if (rc) return rc;
     if (!sample) return fail(c, DCE_ERR_ARG, "dce_online_push: NULL sample");
     if (!c->d_ring) {
-        HIP_TRY(c, hipMalloc(&c->d_ring, ONLINE_ROWS * CH * sizeof(float)));
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_online_pin), 64 * sizeof(float), hipHostMallocDefault));
-        memset(c->h_online_pin, 0, 64 * sizeof(float));
+        HIP_TRY(c, hipMalloc(&c->d_ring, (size_t)ONLINE_ROWS * CH * sizeof(float)));
+        HIP_TRY(c, hipMalloc(&c->d_online_state, sizeof(OnlineState)));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_online_pin), PIN_FLOATS * sizeof(float), hipHostMallocDefault));
+        memset(c->h_online_pin, 0, PIN_FLOATS * sizeof(float));
+        // constant-parameter (graph) form needs the Winograd kernels' indirect window start
+        c->online_mode = (c->winograd && !getenv("DCE_ONLINE_DIRECT")) ? 1 : 0;
     }
-    if (c->ring_rows == ONLINE_ROWS) {                  // keep the last 149 rows, restart at the front
-        HIP_TRY(c, hipMemcpyAsync(c->d_ring, c->d_ring + (ONLINE_ROWS - (WIN - 1)) * CH,
-                                  (WIN - 1) * CH * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        c->ring_rows = WIN - 1;
-    }
-    // The sample rides in the kernel arguments of a one-wave append kernel (no H2D copy); the tail
-    // kernel writes the result straight into pinned host memory and then a sequence number that
-    // this thread polls (no D2H copy, no stream synchronisation on the latency path).
-    OnlineSample s;
-    memcpy(s.v, sample, CH * sizeof(float));
-    HIP_TRY(c, launch_online_append(c->d_ring + c->ring_rows * CH, s, c->stream));
-    c->ring_rows += 1;
-    if (c->ring_rows < WIN) return 0;
     float* hl = c->h_online_pin;
     int32_t* hp = reinterpret_cast<int32_t*>(c->h_online_pin + 16);
     uint8_t* hc = reinterpret_cast<uint8_t*>(c->h_online_pin + 17);
-    unsigned* flag = reinterpret_cast<unsigned*>(c->h_online_pin + 32);
-    c->done_flag = flag;
-    c->done_seq = ++c->online_seq;
-    if (c->done_seq == 0) c->done_seq = ++c->online_seq;          // 0 is the idle value
-    rc = run_chunk(c, c->d_ring + (c->ring_rows - WIN) * CH, 1, 1, hl, hp, hc);
-    c->done_flag = nullptr;
-    if (rc) return rc;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq; ++spins) {
-        __builtin_ia32_pause();
-        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));         // something is wrong or very slow: fall back
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->done_seq)
-                return fail(c, DCE_ERR_HIP, "dce_online_push: the result never arrived");
-            break;
+    unsigned expect = 0;
+
+    if (c->online_mode == 1) {
+        // ---- one graph launch per sample; host and device advance the same cursor
+        if (c->online_state_dirty) {
+            HIP_TRY(c, hipMemsetAsync(c->d_online_state, 0, sizeof(OnlineState), c->stream));
+            c->online_state_dirty = false;
         }
+        memcpy(c->h_online_pin + PIN_SAMPLE, sample, CH * sizeof(float));
+        if (c->ring_rows == ONLINE_ROWS) c->ring_rows = WIN - 1;       // the append kernel compacts
+        c->ring_rows += 1;
+        if (c->ring_rows < WIN) {                                      // still filling: append only
+            HIP_TRY(c, launch_online_append_state(c->d_ring, c->d_online_state, c->h_online_pin + PIN_SAMPLE, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));               // the pinned sample is free again
+            return 0;
+        }
+        expect = ++c->online_seq;
+        if (!c->online_exec) online_build_graph(c);
+        if (c->online_exec) HIP_TRY(c, hipGraphLaunch(c->online_exec, c->stream));
+        else if ((rc = online_enqueue(c))) return rc;
+    } else {
+        // ---- plain launches with per-push parameters (direct-form conv, or DCE_ONLINE_DIRECT)
+        if (c->ring_rows == ONLINE_ROWS) {              // keep the last 149 rows, restart at the front
+            HIP_TRY(c, hipMemcpyAsync(c->d_ring, c->d_ring + (ONLINE_ROWS - (WIN - 1)) * CH,
+                                      (WIN - 1) * CH * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            c->ring_rows = WIN - 1;
+        }
+        // the sample rides in the kernel arguments of a one-wave append kernel (no H2D copy)
+        OnlineSample s;
+        memcpy(s.v, sample, CH * sizeof(float));
+        HIP_TRY(c, launch_online_append(c->d_ring + c->ring_rows * CH, s, c->stream));
+        c->ring_rows += 1;
+        if (c->ring_rows < WIN) return 0;
+        c->done_flag = reinterpret_cast<unsigned*>(c->h_online_pin + PIN_FLAG);
+        expect = c->done_seq = ++c->online_seq;
+        rc = run_chunk(c, c->d_ring + (c->ring_rows - WIN) * CH, 1, 1, hl, hp, hc);
+        c->done_flag = nullptr;
+        if (rc) return rc;
     }
+    // The tail kernel wrote the estimate straight into pinned host memory, then the sequence number
+    // this thread polls: no D2H copy and no stream synchronisation on the latency path.
+    if ((rc = online_wait(c, expect))) return rc;
     if (logits) memcpy(logits, hl, NCLS * sizeof(float));
     if (pred) memcpy(pred, hp, sizeof(int32_t));
     if (contacts) memcpy(contacts, hc, 4);

@@ -27,8 +27,10 @@ void   conv_pack_host(int layer, const float* w_torch, float* out);  // [Cout][C
 size_t conv_wino_pack_floats(int layer);
 void   conv_wino_pack_host(int layer, const float* w_torch, float* out);
 hipError_t init_conv_wino();
+//   src_row (optional, device memory): the kernel adds *src_row rows to src -- the online graph keeps the
+//   position of the live window on the device so that its launch parameters never change
 hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvPack& pk,
-                            void* feat, int feat_bf16, hipStream_t st);
+                            void* feat, int feat_bf16, hipStream_t st, const long long* src_row = nullptr);
 
 // Per-device one-time setup (dynamic-LDS grants); call after hipSetDevice.
 hipError_t init_conv_stack();
@@ -39,7 +41,7 @@ hipError_t init_fc_gemm();
 //   zscore == 0: src is (n,150,54) pre-normalised windows, window i at src + i*8100
 //   feat_bf16 != 0: feat is (n,4736) bf16 (round-to-nearest-even) for the bf16 FC path
 hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const ConvPack& pk,
-                             void* feat, int feat_bf16, hipStream_t st);
+                             void* feat, int feat_bf16, hipStream_t st, const long long* src_row = nullptr);
 
 // z-scored windows only: out (n,150,54) from seq rows [first, first+n+149)
 hipError_t launch_zscore_windows(const float* seq_first_row, int64_t n, float* out, hipStream_t st);
@@ -62,13 +64,21 @@ hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, 
 // logits = h2 * W3^T + b3 ; argmax (first max, NaN-first) ; 4-bit unpack (MSB = leg 0)
 // done_flag (optional, single-block launches only): a system-scope release store of done_seq after the
 // outputs, for a host that polls instead of synchronising the stream (online mode).
+//   seq_counter (optional, device memory, with done_flag): publish ++*seq_counter instead of done_seq.
 hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,
                            float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st,
-                           unsigned* done_flag = nullptr, unsigned done_seq = 0);
+                           unsigned* done_flag = nullptr, unsigned done_seq = 0, unsigned* seq_counter = nullptr);
 
 // online mode: write one (54,) sample, carried in the kernel arguments, to its row of the sample buffer
 struct OnlineSample { float v[54]; };
 hipError_t launch_online_append(float* row, const OnlineSample& s, hipStream_t st);
+
+// online mode as ONE hipGraph launch per sample: every kernel of the push has constant launch
+// parameters because the moving parts live in memory -- the sample in pinned host memory (read by the
+// append kernel), the write cursor / window start / sequence number in this device-resident state.
+struct OnlineState { long long src_row; int cursor; unsigned seq; };
+constexpr int ONLINE_ROWS = 4096;     // rows of the sample buffer; the last 149 move to the front when it is full
+hipError_t launch_online_append_state(float* ring, OnlineState* state, const float* sample_host, hipStream_t st);
 
 // counts[gt*16 + pred] += 1 over n (pred, label) pairs; out-of-range classes are skipped
 hipError_t launch_confusion16(const int32_t* pred, const int64_t* label, int64_t n,

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256)
 void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                      const float* __restrict__ b3, int64_t n, float* __restrict__ logits,
                      int32_t* __restrict__ pred, uint8_t* __restrict__ contacts,
-                     unsigned* __restrict__ done_flag, unsigned done_seq)
+                     unsigned* __restrict__ done_flag, unsigned done_seq, unsigned* __restrict__ seq_counter)
 {
     __shared__ float w3s[NCLS * (FC2 + 1)];              // [class][k], rows padded to 513 floats:
     __shared__ float lg[TAIL_WINDOWS][NCLS];             // staging stores and the per-class reads
@@ -679,19 +679,22 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
         // polls the flag instead of paying for a D2H copy and a stream synchronisation
         __threadfence_system();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) {
+            if (seq_counter) done_seq = *seq_counter = *seq_counter + 1;    // graph launches: the count lives on the device
+            __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
 hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,
                            float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st,
-                           unsigned* done_flag, unsigned done_seq)
+                           unsigned* done_flag, unsigned done_seq, unsigned* seq_counter)
 {
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n + TAIL_WINDOWS - 1) / TAIL_WINDOWS;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(fc3_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                       h2, W3, b3, n, logits, pred, contacts, blocks == 1 ? done_flag : nullptr, done_seq);
+                       h2, W3, b3, n, logits, pred, contacts, blocks == 1 ? done_flag : nullptr, done_seq, seq_counter);
     return hipGetLastError();
 }
 
@@ -706,6 +709,30 @@ void online_append_kernel(float* __restrict__ row, OnlineSample s)
 hipError_t launch_online_append(float* row, const OnlineSample& s, hipStream_t st)
 {
     hipLaunchKernelGGL(online_append_kernel, dim3(1), dim3(64), 0, st, row, s);
+    return hipGetLastError();
+}
+
+// The graph form: the sample is read from pinned host memory, the cursor kept in device memory;
+// when the buffer is full its last 149 rows move to the front first.
+__global__ __launch_bounds__(256)
+void online_append_state_kernel(float* __restrict__ ring, OnlineState* __restrict__ state,
+                                const float* __restrict__ sample_host)
+{
+    const int tid = threadIdx.x;
+    int cur = state->cursor;                             // (read by every thread before thread 0 updates it)
+    __syncthreads();
+    if (cur == ONLINE_ROWS) {
+        for (int i = tid; i < (WIN - 1) * CH; i += 256) ring[i] = ring[(ONLINE_ROWS - (WIN - 1)) * CH + i];
+        cur = WIN - 1;
+        __syncthreads();
+    }
+    if (tid < CH) ring[cur * CH + tid] = sample_host[tid];
+    if (tid == 0) { state->cursor = cur + 1; state->src_row = (long long)cur + 1 - WIN; }
+}
+
+hipError_t launch_online_append_state(float* ring, OnlineState* state, const float* sample_host, hipStream_t st)
+{
+    hipLaunchKernelGGL(online_append_state_kernel, dim3(1), dim3(256), 0, st, ring, state, sample_host);
     return hipGetLastError();
 }
 

@@ -389,3 +389,47 @@ def test_online_mode_matches_sequence(models):
     m.online_reset()
     assert m.online_push(seq[0]) is None
     print(f"online mode: {dt * 1e6:.0f} us per sample end to end (host sample in, result out)")
+    # after a reset the stream starts over (device cursor / sequence number re-zeroed) ...
+    m.online_reset()
+    again = [m.online_push(seq[t]) for t in range(160)]
+    assert all(r is None for r in again[:149])
+    assert all(np.array_equal(r[0], ref["logits"][k]) for k, r in enumerate(again[149:]))
+    # ... new weights take effect (the captured graph is dropped), and batch calls may be interleaved
+    from deep_contact_estimator_amd import synth as _s
+    m.load_state_dict(_s.make_state_dict(3, "uniform"))
+    ref3 = m.infer_sequence(seq[:200])
+    m.online_reset()
+    rows3 = []
+    for t in range(200):
+        r = m.online_push(seq[t])
+        if t == 170:
+            m.predict(np.zeros((5, 150, 54), np.float32))           # shares the ctx scratch, stream-ordered
+        if r is not None:
+            rows3.append(r[0])
+    assert np.array_equal(np.stack(rows3), ref3["logits"])
+    m.load_state_dict(_s.make_state_dict(1, "uniform"))
+
+
+@pytest.mark.parametrize("mode", ["default", "graph", "direct"])
+def test_online_mode_variants(mode, monkeypatch):
+    """The three forms of a push -- constant-parameter kernels launched one by one (default), the same
+    sequence as one captured hipGraph (DCE_ONLINE_GRAPH=1), per-push parameters (DCE_ONLINE_DIRECT=1)
+    -- give the same bits, across a reset and across the sample-buffer compaction."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    if mode == "graph":
+        monkeypatch.setenv("DCE_ONLINE_GRAPH", "1")
+    if mode == "direct":
+        monkeypatch.setenv("DCE_ONLINE_DIRECT", "1")
+    m = contact_cnn(device=0, max_batch=64)
+    m.load_state_dict(synth.make_state_dict(1, "uniform"))
+    T = 150 + 4000                                        # crosses the compaction at 4096 rows
+    seq = synth.make_sequence(T, 77).astype(np.float32)
+    ref = m.infer_sequence(seq)
+    for rounds in range(2):
+        m.online_reset()
+        n_cmp = T if rounds == 0 else 400
+        got = [m.online_push(seq[t]) for t in range(n_cmp)]
+        assert all(g is None for g in got[:149])
+        assert np.array_equal(np.stack([g[0] for g in got[149:]]), ref["logits"][: n_cmp - 149])
+        assert np.array_equal(np.array([g[1] for g in got[149:]], np.int32), ref["pred"][: n_cmp - 149])
+    m.close()
