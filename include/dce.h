@@ -130,7 +130,10 @@ int  dce_confusion_counts(dce_ctx* ctx, const int32_t* pred, const int64_t* labe
  * once 150 samples are present, evaluates the newest window exactly as dce_infer_sequence would
  * (same kernels, z-score fused), so pushing a sequence row by row reproduces dce_infer_sequence's
  * rows bit for bit.  Returns 1 when outputs were written (HOST pointers, any may be NULL),
- * 0 while the ring is still filling, < 0 on error.  dce_online_reset empties the ring. */
+ * 0 while the ring is still filling, < 0 on error.  dce_online_reset empties the ring.
+ * Latency path: no H2D/D2H copies and no stream synchronisation -- the sample is read by the first
+ * kernel from pinned host memory, the estimate is written by the last kernel to pinned host memory
+ * followed by a sequence number the call polls (~89 us per push on MI355X). */
 int  dce_online_reset(dce_ctx* ctx);
 int  dce_online_push(dce_ctx* ctx, const float* sample, float* logits, int32_t* pred, uint8_t* contacts);
 
