@@ -44,12 +44,6 @@ static_assert((RED_ROW * S1) % 2 == 0 && NW * 4 * 216 <= 8 * S1, "fp64 reduction
 static_assert(64 * S1 + 16 <= ACT_FLOATS, "stage-1 image must fit");
 constexpr int LDS_FLOATS = ACT_FLOATS + 384;          // + the four bias vectors
 static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
-#ifndef DCE_STAGGER
-#define DCE_STAGGER 0
-#endif
-#ifndef DCE_SLOT_PRIO
-#define DCE_SLOT_PRIO 0      // measured: s_setprio by wave slot makes the kernel 11 % SLOWER (r1 notes)
-#endif
 // ------------------------------------------------------------------------------------------
 // Host-side weight packing
 // ------------------------------------------------------------------------------------------
@@ -271,21 +265,6 @@ void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT
     TRACE_MARK(0);
 #if DCE_TRACE
     if (tid == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
-#endif
-#if DCE_SLOT_PRIO
-    // Two workgroups share every SIMD (one wave each, wave slots 0 and 1).  With equal priority
-    // they split the matrix pipe 50/50, their waves drift apart SIMD by SIMD, and each block's
-    // barriers then wait for its slowest wave while the pipe idles (measured: 26 % of a block's
-    // life in load / write-back phases).  Strict priority by wave slot makes the slot-1 block run
-    // as if alone, in lockstep across its 4 SIMDs, while the slot-0 block soaks up every gap.
-    if (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1) __builtin_amdgcn_s_setprio(3);
-#endif
-#if DCE_STAGGER
-    // Two workgroups share each CU and would otherwise run their load / write-back phases in
-    // lockstep (both idle the matrix pipe at the same moments).  Offset the one whose waves sit
-    // in an odd wave slot of their SIMD (HW_ID.wave_id bit 0); first residency round only.
-    if (blockIdx.x < 2 * 256 && (__builtin_amdgcn_s_getreg((1 - 1) << 11 | 0 << 6 | 4) & 1))
-        __builtin_amdgcn_s_sleep(127);
 #endif
     // biases of the four layers -> LDS once (read back as accumulator init values)
     for (int i = tid; i < 384; i += 256) {

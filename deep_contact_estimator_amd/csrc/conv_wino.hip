@@ -52,18 +52,6 @@ constexpr int WINO1_MAX_N = 256;                             // <= this many win
 #ifndef WINO_PK
 #define WINO_PK 2            // 2: input transform as two hand-written v_pk_add_f32; 1: compiler-chosen packed adds
 #endif
-#ifndef WINO_PEEL
-#define WINO_PEEL 0          // peel the first two K-steps (no accumulator init); spills at 256 VGPRs
-#endif
-#ifndef WINO_STAGGER
-#define WINO_STAGGER 0
-#endif
-#ifndef WINO_PHASE_PRIO
-#define WINO_PHASE_PRIO 0    // s_setprio level of the non-MFMA phases (0 = leave priorities alone)
-#endif
-#ifndef WINO_PF
-#define WINO_PF 2            // LDS prefetch distance of the main loop, in column tiles (2 or 3)
-#endif
 
 // ------------------------------------------------------------------------------------------
 // Host-side weight transform + packing:  [mtile_pair][kstep][lane][mt(2) x comp(4)]
@@ -215,10 +203,7 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
                                           const float* __restrict__ bias_lds, int co0, int lane,
                                           f32x4 (&acc)[MT][NTW][4])
 {
-    static_assert(STEPS % 2 == 0 && STEPS >= 4, "two K-steps per iteration, first pair peeled");
-#if WINO_PHASE_PRIO
-    __builtin_amdgcn_s_setprio(0);                        // MFMA phase: yield issue slots to a partner
-#endif                                                    // workgroup that is loading / writing back
+    static_assert(STEPS % 2 == 0 && STEPS >= 4, "two K-steps per iteration");
     f32x4 bias[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -226,15 +211,6 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
         for (int r = 0; r < 4; ++r) bias[mt][r] = bias_lds[co0 + 16 * mt + 4 * (lane >> 4) + r];
     V4 vcur = wino_v(load_quad2(xrow + boff[0]));         // V of tile (0,0)
     Quad rawb = load_quad2(xrow + boff[1]);               // raw of tile (0,1)
-#if WINO_PEEL
-    {   // K-steps 0 and 1: accumulators start from MFMA C-operand constants, no init instructions
-        const A8 a_odd = load_a8<MT>(ap, 1);
-        wino_step<RS, true, MT, NTW>(xrow, xrow + 4 * RS, boff, a_even, vcur, rawb, acc, bias);
-        a_even = load_a8<MT>(ap, 2);
-        wino_step<RS, false, MT, NTW>(xrow + 4 * RS, xrow + 8 * RS, boff, a_odd, vcur, rawb, acc, bias);
-    }
-    constexpr int S0 = 2;
-#else
     // (peeling the first K-step pair would save these 160 moves per layer but costs more VGPRs
     //  than the 256 available at two workgroups per CU: measured 56 dwords of spill)
 #pragma unroll
@@ -246,19 +222,14 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
             acc[mt][nt][2] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[mt][nt][3] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    constexpr int S0 = 0;
-#endif
 #pragma unroll 1
-    for (int s = S0; s < STEPS; s += 2) {
+    for (int s = 0; s < STEPS; s += 2) {
         const int s2 = s + 2 < STEPS ? s + 2 : s;         // last iteration: harmless re-reads
         const A8 a_odd = load_a8<MT>(ap, s + 1);
         wino_step<RS, false, MT, NTW>(xrow + s * 4 * RS, xrow + (s + 1) * 4 * RS, boff, a_even, vcur, rawb, acc, bias);
         a_even = load_a8<MT>(ap, s2);
         wino_step<RS, false, MT, NTW>(xrow + (s + 1) * 4 * RS, xrow + s2 * 4 * RS, boff, a_odd, vcur, rawb, acc, bias);
     }
-#if WINO_PHASE_PRIO
-    __builtin_amdgcn_s_setprio(WINO_PHASE_PRIO);          // short, latency-critical phases go first
-#endif
 }
 
 // The same layer loop for the one-window kernel, where a workgroup runs alone on its CU and a
@@ -408,15 +379,6 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
     const int64_t win0 = (int64_t)blockIdx.x * NW;
     const int nvalid = (n - win0) < NW ? (int)(n - win0) : NW;
 
-#if WINO_PHASE_PRIO
-    __builtin_amdgcn_s_setprio(WINO_PHASE_PRIO);
-#endif
-#if WINO_STAGGER
-    // experiment: the first 512 workgroups start in lockstep, two per CU; hold the second of each
-    // pair back by WINO_STAGGER x 4096 cycles so that the pair runs its phases out of step
-    if (blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < WINO_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
-#endif
     TRACE_MARK(0);
 #if DCE_TRACE
     if (tid == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);

@@ -25,24 +25,12 @@ namespace dce {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef DCE_SLOT_PRIO
-#define DCE_SLOT_PRIO 0      // no effect on the GEMM, harmful on the conv kernel (r1 notes)
-#endif
 // One K-tile is 128 BYTES of K per row in either precision (32 floats / 64 bf16); LDS rows are
 // padded to 144 B so the 16-B fragment reads of 16 consecutive rows hit 16 distinct slots.
 #ifndef DCE_GEMM_GLDS
 #define DCE_GEMM_GLDS 0      // fc.0 through the LDS-direct (global_load_lds) variant
 #endif
-#ifndef DCE_GEMM_FRAGPF
-#define DCE_GEMM_FRAGPF 0     // register double-buffering of the LDS fragments
-#endif
-#ifndef DCE_GEMM_8WAVE
-#define DCE_GEMM_8WAVE 0     // 128x128 tile on 8 waves (4 waves/SIMD) instead of 4 waves
-#endif
-#ifndef DCE_GEMM_KTB
-#define DCE_GEMM_KTB 128
-#endif
-constexpr int KT_BYTES = DCE_GEMM_KTB, LDR = KT_BYTES + 16;    // 128: 2 blocks/CU; 64: 4 blocks/CU
+constexpr int KT_BYTES = 128, LDR = KT_BYTES + 16;             // (64-byte K-tiles: 4 blocks/CU but -14 %)
 constexpr int CPR = KT_BYTES / 16;                               // 16-B columns per staged row
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -100,9 +88,6 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#if DCE_SLOT_PRIO
-    if (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1) __builtin_amdgcn_s_setprio(3);
-#endif
     const int wm = (wv / WGN) * 32 * TM, wn = (wv % WGN) * 32 * TN;
     const int i = lane & 31, h = lane >> 5;
 
@@ -168,34 +153,13 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 
         const char* as = As + cur * Cfg::A_BYTES + fa;
         const char* bs = Bs + cur * Cfg::B_BYTES + fb;
-#if DCE_GEMM_FRAGPF
-        // fragments double-buffered in registers: the reads of K slice kq+1 are issued before the
-        // MFMAs of slice kq, so only the first slice of a K-tile waits out an LDS round trip
-        float4 afq[2][TM], bfq[2][TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) afq[0][a] = *reinterpret_cast<const float4*>(as + 32 * a * LDR);
-#pragma unroll
-        for (int b = 0; b < TN; ++b) bfq[0][b] = *reinterpret_cast<const float4*>(bs + 32 * b * LDR);
-#endif
 #pragma unroll
         for (int kq = 0; kq < KT_BYTES / 32; ++kq) {
-#if DCE_GEMM_FRAGPF
-            if (kq + 1 < KT_BYTES / 32) {
-#pragma unroll
-                for (int a = 0; a < TM; ++a) afq[(kq + 1) & 1][a] = *reinterpret_cast<const float4*>(as + 32 * a * LDR + 32 * (kq + 1));
-#pragma unroll
-                for (int b = 0; b < TN; ++b) bfq[(kq + 1) & 1][b] = *reinterpret_cast<const float4*>(bs + 32 * b * LDR + 32 * (kq + 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            float4 (&af)[TM] = afq[kq & 1];
-            float4 (&bf)[TN] = bfq[kq & 1];
-#else
             float4 af[TM], bf[TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(as + 32 * a * LDR + 32 * kq);
 #pragma unroll
             for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(bs + 32 * b * LDR + 32 * kq);
-#endif
             if constexpr (BF16) {
                 // lane (i,h) holds k = 16*kq + 8*h .. +7 of its row: the 32x32x16 fragment
 #pragma unroll
@@ -217,9 +181,6 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
                         }
             }
-#if DCE_GEMM_FRAGPF
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         char* ad = As + (cur ^ 1) * Cfg::A_BYTES + sdst;
         char* bd = Bs + (cur ^ 1) * Cfg::B_BYTES + sdst;
@@ -537,7 +498,6 @@ hipError_t init_fc_gemm()
     if ((e = grant_lds<2, 2, false, false>()) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_small_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<1, 1, 2>::LDS_BYTES)) != hipSuccess) return e;
-    if ((e = grant_lds<2, 1, false, false, 4>()) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_glds_kernel<2, 2, false, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 128 * 128)) != hipSuccess) return e;
     if ((e = grant_lds<1, 1, false, false>()) != hipSuccess) return e;
@@ -570,9 +530,6 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
     if (N % 128 || K % 32 || M > (1 << 30)) return hipErrorInvalidValue;
     // 128x128 tiles when they alone fill the chip (512 resident blocks), else 64x64
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
-#if DCE_GEMM_8WAVE
-    if (big_blocks >= 384) return launch_gemm_cfg<2, 1, false, false, 4>(A, W, bias, C, M, N, K, relu, st);
-#endif
 #if DCE_GEMM_GLDS
     if (big_blocks >= 384) {
         const int mtiles = (int)((M + 127) / 128), ntiles = N / 128;
