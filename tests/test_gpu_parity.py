@@ -433,3 +433,49 @@ def test_online_mode_variants(mode, monkeypatch):
         assert np.array_equal(np.stack([g[0] for g in got[149:]]), ref["logits"][: n_cmp - 149])
         assert np.array_equal(np.array([g[1] for g in got[149:]], np.int32), ref["pred"][: n_cmp - 149])
     m.close()
+
+
+def test_two_contexts_on_two_threads(orc):
+    """One ctx per thread is the documented threading model: two host threads drive their own
+    contexts (different checkpoints) at the same time -- ctypes releases the GIL during the calls --
+    and each gets exactly what it gets alone."""
+    import threading
+    from deep_contact_estimator_amd import contact_cnn, synth
+    seqs = [synth.make_sequence(150 + 2999, 90 + k).astype(np.float32) for k in range(2)]
+    models_ = []
+    for k in range(2):
+        m = contact_cnn(device=0, max_batch=512)
+        m.load_state_dict(synth.make_state_dict(5 + k, "uniform"))
+        models_.append(m)
+    alone = [m.infer_sequence(s) for m, s in zip(models_, seqs)]
+    out, err = [None, None], []
+
+    def work(k):
+        try:
+            for _ in range(5):
+                out[k] = models_[k].infer_sequence(seqs[k])
+                models_[k].predict(np.zeros((3, 150, 54), np.float32))      # small-batch kernels in between
+        except Exception as e:                                               # pragma: no cover
+            err.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err, err
+    for k in range(2):
+        assert np.array_equal(out[k]["logits"], alone[k]["logits"]) and np.array_equal(out[k]["contacts"], alone[k]["contacts"])
+        models_[k].close()
+
+
+def test_max_batch_one(orc):
+    """The smallest legal max_batch: every window is its own chunk (one-window conv kernel + GEMV per
+    chunk); same bits as one large chunk."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    seq = synth.make_sequence(150 + 11, 33).astype(np.float32)
+    sd = synth.make_state_dict(1, "uniform")
+    a = contact_cnn(device=0, max_batch=1); a.load_state_dict(sd)
+    b = contact_cnn(device=0, max_batch=4096); b.load_state_dict(sd)
+    ra, rb = a.infer_sequence(seq), b.infer_sequence(seq)
+    for k in ("logits", "pred", "contacts"):
+        assert np.array_equal(ra[k], rb[k]), k
+    a.close(); b.close()
