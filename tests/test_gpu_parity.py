@@ -479,3 +479,18 @@ def test_max_batch_one(orc):
     for k in ("logits", "pred", "contacts"):
         assert np.array_equal(ra[k], rb[k]), k
     a.close(); b.close()
+
+
+def test_online_mode_bf16_fc():
+    """Online pushes in the bf16-FC precision mode reproduce that mode's own sequence results bit for
+    bit (two-window conv kernel with the device-side window start, bf16 64x64 GEMM tiles)."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    m = contact_cnn(device=0, max_batch=256, precision="bf16_fc")
+    m.load_state_dict(synth.make_state_dict(1, "uniform"))
+    seq = synth.make_sequence(150 + 120, 8).astype(np.float32)
+    ref = m.infer_sequence(seq)
+    rows = [r for r in (m.online_push(s) for s in seq) if r is not None]
+    assert len(rows) == 121
+    assert np.array_equal(np.stack([r[0] for r in rows]), ref["logits"])
+    assert np.array_equal(np.stack([r[2] for r in rows]), ref["contacts"])
+    m.close()
