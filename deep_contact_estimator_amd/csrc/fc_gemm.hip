@@ -492,10 +492,18 @@ static hipError_t grant_lds()
                                hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<TM, TN, WGN>::LDS_BYTES);
 }
 
+constexpr int TAIL_WINDOWS = 16;       // fc3_tail_kernel: windows per 256-thread block (16 lanes per window)
+constexpr int TAIL_W3_FLOATS = NCLS * (FC2 + 1), TAIL_H2_LD = FC2 + 4;
+constexpr int TAIL_LDS_BYTES = (TAIL_W3_FLOATS + TAIL_WINDOWS * TAIL_H2_LD + TAIL_WINDOWS * NCLS) * (int)sizeof(float);
+__global__ void fc3_tail_kernel(const float*, const float*, const float*, int64_t, float*, int32_t*, uint8_t*,
+                                unsigned*, unsigned, unsigned*);
+
 hipError_t init_fc_gemm()
 {
     hipError_t e;
     if ((e = grant_lds<2, 2, false, false>()) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc3_tail_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_BYTES)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_small_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<1, 1, 2>::LDS_BYTES)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_glds_kernel<2, 2, false, false>),
@@ -577,7 +585,6 @@ hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, 
 // ------------------------------------------------------------------------------------------
 // fc.6 (512 -> 16) + torch.max(output,1) + decimal2binary
 // ------------------------------------------------------------------------------------------
-constexpr int TAIL_WINDOWS = 16;       // windows per 256-thread block (16 lanes per window)
 
 __global__ __launch_bounds__(256)
 void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
@@ -585,23 +592,50 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                      int32_t* __restrict__ pred, uint8_t* __restrict__ contacts,
                      unsigned* __restrict__ done_flag, unsigned done_seq, unsigned* __restrict__ seq_counter)
 {
-    __shared__ float w3s[NCLS * (FC2 + 1)];              // [class][k], rows padded to 513 floats:
-    __shared__ float lg[TAIL_WINDOWS][NCLS];             // staging stores and the per-class reads
-    const int tid = threadIdx.x;                         // below are both bank-conflict free
-    for (int e = tid; e < FC2 * NCLS; e += 256) {
-        const int cls = e / FC2, k = e % FC2;            // coalesced read of W3[cls][k]
-        w3s[cls * (FC2 + 1) + k] = W3[e];
+    // dynamic LDS (66.9 KB): W3 [class][513] | the 16 h2 rows of the current window tile [16][516] | logits [16][16]
+    // (row strides 513 / 516 floats: the per-class W3 reads and the per-window h2 reads are bank-conflict free)
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    float* w3s = tsm;
+    float* h2s = tsm + TAIL_W3_FLOATS;
+    float (*lg)[NCLS] = reinterpret_cast<float (*)[NCLS]>(tsm + TAIL_W3_FLOATS + TAIL_WINDOWS * TAIL_H2_LD);
+    const int tid = threadIdx.x;
+    {   // W3 (32 KB) -> LDS: 8 x 16-byte loads per thread, all issued before the first store
+        const float4* W4 = reinterpret_cast<const float4*>(W3);
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = W4[tid + 256 * i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e4 = tid + 256 * i, cls = e4 / (FC2 / 4), k = 4 * (e4 % (FC2 / 4));
+            float* d = w3s + cls * (FC2 + 1) + k;
+            d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+        }
     }
     const int cls = tid & 15, wl = tid >> 4;
     const float bv = b3[cls];
     for (int64_t base = (int64_t)blockIdx.x * TAIL_WINDOWS; base < n;
          base += (int64_t)gridDim.x * TAIL_WINDOWS) {
-        __syncthreads();                                 // w3s ready / lg free again
+        __syncthreads();                                 // lg / h2s free again
+        {   // the tile's 16 h2 rows -> LDS, coalesced, 8 loads in flight per thread.  (Read from global
+            // inside the chain below they were 32 dependent L2 round trips: 12 of 12.6 us at n = 1.)
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e4 = tid + 256 * i;
+                const int64_t row = base + e4 / (FC2 / 4);
+                v[i] = reinterpret_cast<const float4*>(h2 + (row < n ? row : n - 1) * FC2)[e4 % (FC2 / 4)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e4 = tid + 256 * i;
+                *reinterpret_cast<float4*>(h2s + (e4 / (FC2 / 4)) * TAIL_H2_LD + 4 * (e4 % (FC2 / 4))) = v[i];
+            }
+        }
+        __syncthreads();                                 // w3s and h2s ready
         const int64_t win = base + wl;
-        // the 16 lanes of a window read the same h2 row (one broadcast 16-B load per 4 k)
-        const float4* hp = reinterpret_cast<const float4*>(h2 + (win < n ? win : n - 1) * FC2);
+        const float4* hp = reinterpret_cast<const float4*>(h2s + wl * TAIL_H2_LD);   // broadcast to the window's 16 lanes
         float acc = 0.f;
-#pragma unroll 4
+#pragma unroll 8
         for (int k4 = 0; k4 < FC2 / 4; ++k4) {
             const float4 hv = hp[k4];
             const float* wp = w3s + cls * (FC2 + 1) + 4 * k4;
@@ -650,7 +684,7 @@ hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, in
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n + TAIL_WINDOWS - 1) / TAIL_WINDOWS;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(fc3_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+    hipLaunchKernelGGL(fc3_tail_kernel, dim3((unsigned)blocks), dim3(256), TAIL_LDS_BYTES, st,
                        h2, W3, b3, n, logits, pred, contacts, blocks == 1 ? done_flag : nullptr, done_seq, seq_counter);
     return hipGetLastError();
 }
