@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdce.so")
 SOURCES = ["conv_stack.hip", "conv_wino.hip", "fc_gemm.hip", "fc_gemv.hip", "dce_api.hip"]
 HEADERS = ["dce_kernels.h", "conv_common.h", os.path.join("..", "..", "include", "dce.h")]
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-inline-asm"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 OBJDIR = os.path.join(HERE, "build")
 
 

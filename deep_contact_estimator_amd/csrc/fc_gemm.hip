@@ -27,9 +27,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // One K-tile is 128 BYTES of K per row in either precision (32 floats / 64 bf16); LDS rows are
 // padded to 144 B so the 16-B fragment reads of 16 consecutive rows hit 16 distinct slots.
-#ifndef DCE_GEMM_GLDS
-#define DCE_GEMM_GLDS 0      // fc.0 through the LDS-direct (global_load_lds) variant
-#endif
 constexpr int KT_BYTES = 128, LDR = KT_BYTES + 16;             // (64-byte K-tiles: 4 blocks/CU but -14 %)
 constexpr int CPR = KT_BYTES / 16;                               // 16-B columns per staged row
 
@@ -223,157 +220,6 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 }
 
 // ------------------------------------------------------------------------------------------
-// Variant with LDS-direct staging (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through
-// VGPRs, no ds_write pass).  The DMA writes lane-linear images (wave-uniform base + lane*16 B), so
-// rows are unpadded 128 B and the bank-conflict fix moves into an XOR swizzle applied on BOTH
-// sides: 16-B slot q of row r lives at physical slot q ^ ((r>>1)&7) -- the source address of each
-// lane is pre-swizzled, the fragment reads apply the same involution (16 consecutive rows then
-// cover all 16 slots of the 256-B bank row: conflict-free ds_read_b128).
-// Same tiling, K order and epilogue as fc_gemm_kernel, hence bit-identical results.
-// ------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-template <int TM, int TN, bool BF16, bool OUT_BF16>
-__global__ __launch_bounds__(256, 2)
-void fc_gemm_glds_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
-                         const float* __restrict__ bias, void* __restrict__ Cv,
-                         int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
-{
-    constexpr int BM = 64 * TM, BN = 64 * TN, ROWB = 128;
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    constexpr int SA = BM / 32, SB = BN / 32;
-    constexpr int ES = BF16 ? 2 : 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                                     // [2][BM][128]
-    char* Bs = smem + 2 * A_BYTES;                       // [2][BN][128]
-    const char* A = static_cast<const char*>(Av);
-    const char* W = static_cast<const char*>(Wv);
-
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, li = bid >> 3;
-    const int sid = (li >> 6) * 8 + xcd;
-    const int within = li & 63;
-    const int sn = 1 << sn_log2, sm = 64 >> sn_log2;
-    const int nsn = ntiles >> sn_log2;
-    const int tm = (sid / nsn) * sm + (within >> sn_log2);
-    const int tn = (sid % nsn) * sn + (within & (sn - 1));
-    if (tm >= mtiles) return;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wv >> 1) * 32 * TM, wn = (wv & 1) * 32 * TN;
-    const int i = lane & 31, h = lane >> 5;
-
-    // DMA source addresses: wave wv, piece s covers tile rows 8*wv + 32*s .. +7; lane l writes
-    // physical slot l&7 of row (l>>3) and therefore fetches logical slot (l&7) ^ ((row>>1)&7)
-    const size_t rowb = (size_t)K * ES;
-    const int drow = 8 * wv + (lane >> 3);
-    const int dq = (lane & 7) ^ ((drow >> 1) & 7);       // (32*s does not change (row>>1)&7)
-    const char* ag[SA];
-    const char* bg[SB];
-#pragma unroll
-    for (int s = 0; s < SA; ++s) {
-        int ra = m0 + drow + 32 * s;
-        ra = ra < M ? ra : M - 1;
-        ag[s] = A + (size_t)ra * rowb + 16 * dq;
-    }
-#pragma unroll
-    for (int s = 0; s < SB; ++s) bg[s] = W + (size_t)(n0 + drow + 32 * s) * rowb + 16 * dq;
-    const int dbase = 8 * wv * ROWB;                     // wave-uniform LDS offset of piece 0
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int KT = (int)(rowb / 128);
-    // The DMA is issued from inline asm: through the builtin hipcc treats the transfer as an LDS store
-    // that may alias the fragment reads and drains it (vmcnt(0)) before the first ds_read of the tile.
-    const unsigned lds_a = (unsigned)(size_t)(lds_void*)As + dbase;
-    const unsigned lds_b = (unsigned)(size_t)(lds_void*)Bs + dbase;
-    auto issue = [&](int buf, int tile) {
-        const size_t koff = (size_t)(tile < KT ? tile : KT - 1) * 128;
-#pragma unroll
-        for (int s = 0; s < SA; ++s)
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
-                         :: "s"(lds_a + buf * A_BYTES + 32 * s * ROWB), "v"(ag[s] + koff) : "memory", "m0");
-#pragma unroll
-        for (int s = 0; s < SB; ++s)
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
-                         :: "s"(lds_b + buf * B_BYTES + 32 * s * ROWB), "v"(bg[s] + koff) : "memory", "m0");
-    };
-    // fragment reads: row wm+32a+i, logical slot 2*kq+h -> physical slot ^ ((i>>1)&7)
-    const int sw = (i >> 1) & 7;
-    int foff[4];
-#pragma unroll
-    for (int kq = 0; kq < 4; ++kq) foff[kq] = ((2 * kq + h) ^ sw) * 16;
-    const int fa = (wm + i) * ROWB, fb = (wn + i) * ROWB;
-
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        issue(cur ^ 1, kt + 1);
-        const char* as = As + cur * A_BYTES + fa;
-        const char* bs = Bs + cur * B_BYTES + fb;
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(as + 32 * a * ROWB + foff[kq]);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(bs + 32 * b * ROWB + foff[kq]);
-            if constexpr (BF16) {
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bf[b]), acc[a][b], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int b = 0; b < TN; ++b) {
-                            const float av = u == 0 ? af[a].x : u == 1 ? af[a].y : u == 2 ? af[a].z : af[a].w;
-                            const float bv = u == 0 ? bf[b].x : u == 1 ? bf[b].y : u == 2 ? bf[b].z : bf[b].w;
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
-                        }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int col = n0 + wn + 32 * b + i;
-        const float bv = bias[col];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = acc[a][b][r] + bv;
-                if (relu) v = relu_nan(v);
-                if (row < M) {
-                    if constexpr (OUT_BF16) static_cast<unsigned short*>(Cv)[(size_t)row * N + col] = f32_to_bf16_rne(v);
-                    else static_cast<float*>(Cv)[(size_t)row * N + col] = v;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // 64x64 tiles for batches that do not fill the chip (33 .. ~3000 windows: at most one block per CU).
 // Nothing then overlaps a block's K-tile with another's, and a K-tile (16 MFMAs per wave, ~0.45 us)
 // is shorter than the memory round trip of its successor: with one tile of lookahead fc.0 walked
@@ -506,8 +352,6 @@ hipError_t init_fc_gemm()
                                  hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_BYTES)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_small_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<1, 1, 2>::LDS_BYTES)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_glds_kernel<2, 2, false, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 128 * 128)) != hipSuccess) return e;
     if ((e = grant_lds<1, 1, false, false>()) != hipSuccess) return e;
     if ((e = grant_lds<2, 2, true, true>()) != hipSuccess) return e;
     if ((e = grant_lds<2, 2, true, false>()) != hipSuccess) return e;
@@ -538,19 +382,6 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
     if (N % 128 || K % 32 || M > (1 << 30)) return hipErrorInvalidValue;
     // 128x128 tiles when they alone fill the chip (512 resident blocks), else 64x64
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
-#if DCE_GEMM_GLDS
-    if (big_blocks >= 384) {
-        const int mtiles = (int)((M + 127) / 128), ntiles = N / 128;
-        int sn_log2 = 3;
-        while ((1 << sn_log2) > ntiles) --sn_log2;
-        const int sm = 64 >> sn_log2, nsn = ntiles >> sn_log2;
-        const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
-        const int grid = ((nsuper + 7) / 8) * 8 * 64;
-        hipLaunchKernelGGL((fc_gemm_glds_kernel<2, 2, false, false>), dim3(grid), dim3(256), 2 * 2 * 128 * 128, st,
-                           A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
-        return hipGetLastError();
-    }
-#endif
     if (big_blocks >= 384) return launch_gemm_cfg<2, 2, false, false>(A, W, bias, C, M, N, K, relu, st);
     static const bool deep = !(getenv("DCE_GEMM_SMALL") && atoi(getenv("DCE_GEMM_SMALL")) == 0);
     const int64_t small_blocks = ((M + 63) / 64) * (N / 64);
