@@ -109,3 +109,18 @@ def test_bench_two_rank_flow():
     assert j["n_gpus"] == 2 and j["steps"] == 5 and j["scaling"] == "weak" and j["value"] > 0
     assert j["config"]["global_batch"] == 2 * j["config"]["batch_per_gpu"]
     assert abs(j["value"] - 2 * 4096 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
+
+
+def test_config3_full_size_shards_equal_single_call():
+    """BASELINE configs[3] at its full size (8e6 windows, 1.73 GB sequence): the 8 halo-sharded ranges
+    of a node, computed one after the other on this GPU, equal the single call bit for bit, and the
+    size-independent properties hold (tools/check_sharding_8e6.py)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_sharding_8e6.py")],
+                       env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("shards_equal_single_call_bitwise", "deterministic", "pred_is_argmax_of_logits",
+              "contacts_are_bits_of_pred", "finite_logits"):
+        assert j[k] is True, (k, j)
+    assert j["classes_seen"] >= 4
