@@ -129,25 +129,40 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     const int KT = (int)(rowb / KT_BYTES);
     const int fa = (wm + i) * LDR + 16 * h;              // this lane's fragment row, 16-B half h
     const int fb = (wn + i) * LDR + 16 * h;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        // prefetch the next K-tile into registers (the last iteration re-reads its own tile:
-        // unconditional loads keep the staging registers out of scratch and the loop branch-free)
-        // Issued as inline asm: written as plain loads, LLVM sinks them (at IR level, below any
-        // sched_barrier) to just before the ds_writes at the end of the iteration, and every
-        // K-tile then waits out their full L2/HBM latency.  The asm loads are invisible to the
-        // compiler's s_waitcnt bookkeeping, so the wait before their first use is explicit below
-        // and names every destination register (cdna_hip_programming.md 5.7, form ii).
-        const size_t koff = (size_t)(kt + 1 < KT ? kt + 1 : kt) * KT_BYTES;
+    // The staging loads are issued as inline asm: written as plain loads, LLVM sinks them (at IR
+    // level, below any sched_barrier) to just before the ds_writes at the end of the iteration, and
+    // every K-tile then waits out their full L2/HBM latency.  The asm loads are invisible to the
+    // compiler's s_waitcnt bookkeeping, so the wait before their first use is explicit and names
+    // every destination register (cdna_hip_programming.md 5.7, form ii).  Loads past the last tile
+    // re-read it (unconditional loads keep the registers out of scratch and the loop branch-free).
 #define DCE_GLOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
-        DCE_GLOAD16(ra0, ag[0] + koff); DCE_GLOAD16(rb0, bg[0] + koff);
-        if constexpr (SA >= 2) { DCE_GLOAD16(ra1, ag[1] + koff); DCE_GLOAD16(rb1, bg[1] + koff); }
-        if constexpr (SA == 4) {
-            DCE_GLOAD16(ra2, ag[2] + koff); DCE_GLOAD16(ra3, ag[3] + koff);
-            DCE_GLOAD16(rb2, bg[2] + koff); DCE_GLOAD16(rb3, bg[3] + koff);
-        }
-#undef DCE_GLOAD16
+#define DCE_ISSUE(P, tile)                                                                        \
+    { const size_t koff = (size_t)((tile) < KT ? (tile) : KT - 1) * KT_BYTES;                     \
+      DCE_GLOAD16(P##a0, ag[0] + koff); DCE_GLOAD16(P##b0, bg[0] + koff);                         \
+      if constexpr (SA >= 2) { DCE_GLOAD16(P##a1, ag[1] + koff); DCE_GLOAD16(P##b1, bg[1] + koff); } \
+      if constexpr (SA == 4) { DCE_GLOAD16(P##a2, ag[2] + koff); DCE_GLOAD16(P##a3, ag[3] + koff);    \
+                               DCE_GLOAD16(P##b2, bg[2] + koff); DCE_GLOAD16(P##b3, bg[3] + koff); } }
+    // wait until at most N4 / N2 / N1 (for 4 / 2 / 1 pieces per operand) younger loads are outstanding,
+    // then hand set P to LDS buffer `buf`
+#define DCE_WAIT_WRITE(P, buf, N4, N2, N1)                                                        \
+    { char* ad = As + (buf) * Cfg::A_BYTES + sdst;                                                \
+      char* bd = Bs + (buf) * Cfg::B_BYTES + sdst;                                                \
+      if constexpr (SA == 4) {                                                                    \
+          asm volatile("s_waitcnt vmcnt(" #N4 ")" : "+v"(P##a0), "+v"(P##a1), "+v"(P##a2), "+v"(P##a3), \
+                                                   "+v"(P##b0), "+v"(P##b1), "+v"(P##b2), "+v"(P##b3)); \
+          *reinterpret_cast<v4f*>(ad + 2 * RPP * LDR) = P##a2; *reinterpret_cast<v4f*>(ad + 3 * RPP * LDR) = P##a3; \
+          *reinterpret_cast<v4f*>(bd + 2 * RPP * LDR) = P##b2; *reinterpret_cast<v4f*>(bd + 3 * RPP * LDR) = P##b3; \
+      } else if constexpr (SA == 2) {                                                             \
+          asm volatile("s_waitcnt vmcnt(" #N2 ")" : "+v"(P##a0), "+v"(P##a1), "+v"(P##b0), "+v"(P##b1)); \
+      } else {                                                                                    \
+          asm volatile("s_waitcnt vmcnt(" #N1 ")" : "+v"(P##a0), "+v"(P##b0));                    \
+      }                                                                                           \
+      *reinterpret_cast<v4f*>(ad) = P##a0; *reinterpret_cast<v4f*>(bd) = P##b0;                   \
+      if constexpr (SA >= 2) {                                                                    \
+          *reinterpret_cast<v4f*>(ad + RPP * LDR) = P##a1; *reinterpret_cast<v4f*>(bd + RPP * LDR) = P##b1; \
+      } }
 
+    auto compute = [&](int cur) {
         const char* as = As + cur * Cfg::A_BYTES + fa;
         const char* bs = Bs + cur * Cfg::B_BYTES + fb;
 #pragma unroll
@@ -179,24 +194,20 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                         }
             }
         }
-        char* ad = As + (cur ^ 1) * Cfg::A_BYTES + sdst;
-        char* bd = Bs + (cur ^ 1) * Cfg::B_BYTES + sdst;
-        if constexpr (SA == 4) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(ra2), "+v"(ra3),
-                                                "+v"(rb0), "+v"(rb1), "+v"(rb2), "+v"(rb3));
-            *reinterpret_cast<v4f*>(ad + 2 * RPP * LDR) = ra2; *reinterpret_cast<v4f*>(ad + 3 * RPP * LDR) = ra3;
-            *reinterpret_cast<v4f*>(bd + 2 * RPP * LDR) = rb2; *reinterpret_cast<v4f*>(bd + 3 * RPP * LDR) = rb3;
-        } else if constexpr (SA == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1));
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(rb0));
-        }
-        *reinterpret_cast<v4f*>(ad) = ra0; *reinterpret_cast<v4f*>(bd) = rb0;
-        if constexpr (SA >= 2) {
-            *reinterpret_cast<v4f*>(ad + RPP * LDR) = ra1; *reinterpret_cast<v4f*>(bd + RPP * LDR) = rb1;
-        }
+    };
+
+    // one tile of lookahead.  (Two tiles ahead for the bf16 path, whose K-tile is only 512 MFMA cycles per
+    // wave, measured fc.0 0.0985 vs 0.0957 ms and fc.3 0.021 vs 0.024 ms: a wash -- that path is bound by
+    // LDS bandwidth, 128 B/clk/CU at one ds_read_b128 per MFMA, not by load latency.)
+    for (int kt = 0; kt < KT; ++kt) {
+        DCE_ISSUE(r, kt + 1)
+        compute(kt & 1);
+        DCE_WAIT_WRITE(r, (kt & 1) ^ 1, 0, 0, 0)
         __syncthreads();
     }
+#undef DCE_WAIT_WRITE
+#undef DCE_ISSUE
+#undef DCE_GLOAD16
 
     // ---- epilogue: bias + (ReLU) ; D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -315,7 +326,10 @@ void fc_gemm_small_kernel(const float* __restrict__ Af, const float* __restrict_
     for (int kt = 0; kt < KT; kt += GS_DEPTH) {
         GS_STEP(0, 1, kt) GS_STEP(1, 2, kt + 1) GS_STEP(2, 3, kt + 2) GS_STEP(3, 0, kt + 3)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's trailing (clamped) loads
+    // the ring's trailing (clamped) loads: waited for while their registers are still live (hipcc does
+    // not know loads are in flight into them and would otherwise reuse them for the epilogue)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0a0), "+v"(q0a1), "+v"(q0b0), "+v"(q0b1), "+v"(q1a0), "+v"(q1a1), "+v"(q1b0), "+v"(q1b1),
+                                        "+v"(q2a0), "+v"(q2a1), "+v"(q2b0), "+v"(q2b1), "+v"(q3a0), "+v"(q3a1), "+v"(q3b0), "+v"(q3b1));
 #undef GS_STEP
 #undef GS_LOAD
 #undef GS_LD
