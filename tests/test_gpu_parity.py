@@ -494,3 +494,35 @@ def test_online_mode_bf16_fc():
     assert np.array_equal(np.stack([r[0] for r in rows]), ref["logits"])
     assert np.array_equal(np.stack([r[2] for r in rows]), ref["contacts"])
     m.close()
+
+
+@pytest.mark.parametrize("n", [10, 401])                  # one-window kernel / two-window kernel (odd tail)
+def test_non_finite_windows_stay_contained(n, models, orc):
+    """torch turns any NaN / Inf input sample into all-NaN logits of THAT window (class 0 on CPU) and
+    nothing else.  Both conv kernels carry this per window (ReLU is v_max, which drops NaN): checked on
+    the streaming path (a NaN row poisons exactly the windows that contain it) and on pre-normalised
+    windows, against the oracle for every clean window."""
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    m, o = models(), orc.Oracle(sd)
+    seq = synth.make_sequence(n + 149, 70 + n).astype(np.float32)
+    bad_rows = {5: np.nan, n + 146: np.inf}               # rows of the sequence: windows 0..5 and n-3..n-1
+    for r, v in bad_rows.items():
+        seq[r, 17] = v
+    out = m.infer_sequence(seq)
+    poisoned = np.zeros(n, bool)
+    for r in bad_rows:
+        poisoned[max(0, r - 149): min(n, r + 1)] = True   # windows j with j <= r <= j+149
+    assert np.isnan(out["logits"][poisoned]).all() and not np.isnan(out["logits"][~poisoned]).any()
+    assert (out["pred"][poisoned] == 0).all() and (out["contacts"][poisoned] == 0).all()
+    clean_seq = synth.make_sequence(n + 149, 70 + n).astype(np.float32)
+    ref = o.infer_sequence(clean_seq)
+    tol_ok(out["logits"][~poisoned], ref["logits"][~poisoned], "clean windows next to poisoned ones")
+    # pre-normalised windows: poison windows 1 and n-1 only
+    w = m.zscore_windows(clean_seq)
+    w[1, 3, 0] = -np.inf
+    w[n - 1, 149, 53] = np.nan
+    got = m.predict(w)
+    bad = np.zeros(n, bool); bad[[1, n - 1]] = True
+    assert np.isnan(got["logits"][bad]).all() and not np.isnan(got["logits"][~bad]).any()
+    tol_ok(got["logits"][~bad], ref["logits"][~bad], "clean pre-normalised windows")
