@@ -526,3 +526,23 @@ def test_non_finite_windows_stay_contained(n, models, orc):
     bad = np.zeros(n, bool); bad[[1, n - 1]] = True
     assert np.isnan(got["logits"][bad]).all() and not np.isnan(got["logits"][~bad]).any()
     tol_ok(got["logits"][~bad], ref["logits"][~bad], "clean pre-normalised windows")
+
+
+def test_direct_form_conv_kernel(monkeypatch, golden, case_inputs, orc):
+    """DCE_CONV=direct selects the direct-form (implicit GEMM, 32x32x2 MFMA) conv stack kept for A/B
+    against the Winograd kernels: same goldens, same tolerance, and the two agree with each other to
+    fp32 round-off."""
+    from deep_contact_estimator_amd import contact_cnn
+    g = golden("seq_normal")
+    sd, seq = case_inputs(g)
+    wino = contact_cnn(device=0, max_batch=4096); wino.load_state_dict(sd)
+    monkeypatch.setenv("DCE_CONV", "direct")
+    direct = contact_cnn(device=0, max_batch=4096); direct.load_state_dict(sd)
+    monkeypatch.delenv("DCE_CONV")
+    a, b = wino.infer_sequence(seq.astype(np.float32)), direct.infer_sequence(seq.astype(np.float32))
+    tol_ok(b["logits"], g["logits"], "direct-form conv vs reference golden")
+    tol_ok(b["logits"], a["logits"], "direct-form vs Winograd")
+    assert np.array_equal(b["pred"], g["pred"])
+    rows = [r[0] for r in (direct.online_push(s) for s in seq[:200].astype(np.float32)) if r is not None]
+    assert np.array_equal(np.stack(rows), b["logits"][:51])          # per-push parameters path (no indirect window start)
+    wino.close(); direct.close()
