@@ -12,14 +12,30 @@ pointers, torch's current stream).  With N>1 every rank (one process per GPU) ru
 windows (weak scaling, no data-path collective inside the model) and the (B,16) logits are
 gathered to rank 0 over RCCL each step, asynchronously behind the next step's kernels.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, from HIP events
-recorded on the launch stream inside the timed region (dce_profile_*); `cpu_baseline` is the
-PyTorch-CPU restatement of the reference path (oracle/torch_ref.py, checked against the
-reference's golden vectors) timed on this box's host cores on a bounded sample.
+Order of one run (every rank):
+  1. settle   : the step loop runs untimed until >= --settle-s seconds of GPU time have passed,
+                whatever --warmup says, so the clocks are where a long job holds them;
+  2. warm-up  : W untimed steps;
+  3. timed    : barrier + synchronize, EXACTLY K steps with no events on the stream, synchronize +
+                barrier; max over ranks -> `value`, `ms_per_step`;
+  4. profiled : the same step loop again (max(K,50) steps) with a HIP-event pair around every
+                kernel of every step on the launch stream (dce_profile_*) -> per-kernel average
+                launch durations for `roofline`; its own ms_per_step is reported next to them so
+                the event overhead is visible and never inside `value`;
+  5. rank 0 at N=1: `extra.streaming_1e6` (BASELINE configs[2]: 1e6-window sequence, HBM-resident
+                and PCIe-inclusive), `extra.bf16_fc` (configs[4]) and `cpu_baseline` (SURVEY 8(d)
+                protocol); at N>1: `extra.sharded_1e6` (configs[3] literally: 1e6 windows per rank,
+                halo rows regenerated per rank, ONE gather of the packed results).
+
+Prints ONE JSON line on rank 0.  Roofline fractions are hardware-side: MFMA FLOPs actually issued
+(the Winograd conv stack issues 2/3 of the algorithmic 2*MAC) over the peak of the pipe the
+kernel runs on (fp32 MFMA 157.3 TFLOP/s; bf16 MFMA 2.5 PFLOP/s for the bf16 FC kernels), so no
+fraction can exceed 1; the algorithmic figures are given beside them.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,75 +44,314 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work per window (SURVEY.md 8(d) / BASELINE.md 3): 2*MAC of each layer
-FLOP = {
+METRIC = "inference windows/sec (54-ch, win=150)"
+# algorithmic work per window (SURVEY.md 8(d) / BASELINE.md 3): 2*MAC of each reference layer
+ALGO_FLOP = {
     "conv_stack": 3_110_400 + 3_686_400 + 3_686_400 + 7_372_800,   # 17,856,000
     "fc1_gemm": 2 * 4736 * 2048,                                     # 19,398,656
     "fc2_gemm": 2 * 2048 * 512,                                      #  2,097,152
     "fc3_tail": 2 * 512 * 16,                                        #     16,384
+    "fc23_fused": 2 * 2048 * 512 + 2 * 512 * 16,
 }
-# MFMA FLOPs actually executed per window by the shipped kernels (Winograd F(2,3) conv stack:
-# 4 waves x 3120 v_mfma_f32_16x16x4 x 2048 FLOP per 2 windows; GEMMs execute exactly 2*M*N*K)
-EXEC_FLOP = {"conv_stack": 4 * 3120 * 2048 // 2, "fc1_gemm": 2 * 4736 * 2048, "fc2_gemm": 2 * 2048 * 512,
-             "fc3_tail": 2 * 512 * 16}
+# matrix-pipe FLOPs the shipped kernels actually issue per window.  Winograd F(2,3) conv stack:
+# 4 waves x 3120 v_mfma_f32_16x16x4_f32 x 2048 FLOP per 2-window workgroup (tile padding included);
+# the GEMMs issue exactly 2*M*N*K; fc.6 runs on the VALU (counted as its 2*MAC).
+EXEC_FLOP = dict(ALGO_FLOP, conv_stack=4 * 3120 * 2048 // 2)        # 12,779,520
 # algorithmic HBM bytes per window per kernel (inputs read once + outputs written once)
-BYTES = {
+ALGO_BYTES = {
     "conv_stack": 150 * 54 * 4 + 4736 * 4,
     "fc1_gemm": 4736 * 4 + 2048 * 4,
     "fc2_gemm": 2048 * 4 + 512 * 4,
     "fc3_tail": 512 * 4 + 16 * 4 + 4 + 4,
+    "fc23_fused": 2048 * 4 + 16 * 4 + 4 + 4,
 }
-PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, 256 CU x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(sd, windows_np, gpu_logits, gpu_pred, budget_s=12.0):
-    """The reference path on the host cores: oracle/torch_ref.forward (the op sequence the
-    reference dispatches on CPU) on a bounded sample of the same windows."""
-    import torch
-    from oracle import torch_ref
-    tsd = torch_ref.to_torch(sd)
-    bs = 512
-    x = torch.from_numpy(windows_np[:bs])
-    # PyTorch's default (one thread per logical CPU) oversubscribes these small convs badly on
-    # a many-core host; give the baseline its best thread count from a short sweep.
+def kernel_peak(kernel, precision):
+    """Peak of the pipe the kernel's dominant arithmetic runs on."""
+    if precision == "bf16_fc" and kernel in ("fc1_gemm", "fc2_gemm"):
+        return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA"
+    return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA" if kernel != "fc3_tail" else "fp32 VALU (= fp32 MFMA rate)"
+
+
+def kernel_table(prof, B, precision):
+    out = {}
+    for k, v in prof.items():
+        if v["launches"] == 0:
+            continue
+        avg_s = v["ms"] / v["launches"] * 1e-3
+        peak, pipe = kernel_peak(k, precision)
+        ex = EXEC_FLOP[k] * B / avg_s / 1e12
+        out[k] = {
+            "avg_ms": avg_s * 1e3, "launches": v["launches"], "pipe": pipe, "peak_tflops": peak,
+            "executed_tflops": ex, "frac": ex / peak,
+            "algorithmic_tflops": ALGO_FLOP[k] * B / avg_s / 1e12,
+            "algorithmic_GBs": ALGO_BYTES[k] * B / avg_s / 1e9,
+        }
+    return out
+
+
+def path_roof(precision):
+    """Windows/s if every kernel ran at the peak of its pipe on the FLOPs it issues."""
+    t = sum(EXEC_FLOP[k] / (kernel_peak(k, precision)[0] * 1e12) for k in ("conv_stack", "fc1_gemm", "fc2_gemm", "fc3_tail"))
+    return 1.0 / t
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: SURVEY.md 8(d) / BASELINE.md 4 protocol, on the GPU box's host cores
+# ------------------------------------------------------------------------------------------------
+def cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    best_t, best_rate = 1, 0.0
-    for nt in sorted({t for t in (8, 16, 32, 64, 128, avail) if t <= avail}):
-        torch.set_num_threads(nt)
-        torch_ref.forward(tsd, x[:64])
+    return {"cpu_model": model, "physical_cores": len(phys) or None, "logical_cpus": os.cpu_count(), "usable_cpus": avail}
+
+
+def _median_rate(fn, units, reps=3):
+    """fn() processes `units` windows; -> (median windows/s over reps, every rep's rate)."""
+    rates = []
+    for _ in range(reps):
         t0 = time.perf_counter()
-        out = torch_ref.forward(tsd, x)
-        rate = bs / (time.perf_counter() - t0)
-        if rate > best_rate:
-            best_t, best_rate = nt, rate
-    torch.set_num_threads(best_t)
-    out = torch_ref.forward(tsd, x)                     # parity sample
-    t0 = time.perf_counter()
-    done = 0
-    reps = 0
-    while True:
-        i0 = (reps * bs) % max(windows_np.shape[0] - bs + 1, 1)
-        torch_ref.forward(tsd, torch.from_numpy(windows_np[i0:i0 + bs]))
-        done += bs
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 2000:
-            break
-    ref = out.numpy()
-    diff = float(np.abs(ref - gpu_logits[:bs]).max())
-    agree = int((ref.argmax(1) == gpu_pred[:bs]).sum())
+        fn()
+        rates.append(units / (time.perf_counter() - t0))
+    return statistics.median(rates), rates
+
+
+def cpu_baseline(sd, windows_np, seq_np, gpu_logits, gpu_pred):
+    """The reference path on the host cores (oracle/torch_ref.py = the op sequence the reference
+    dispatches on CPU, pinned to the reference's goldens by tests/test_oracle.py):
+      (i)  model only at B=4096 and B=30;
+      (ii) the reference's loop shape (per-item slice + z-score, stack, forward, argmax, unpack,
+           cat: src/inference_one_seq.py:19-30 over utils/data_handler.py:55-56) at B=1 and B=30;
+      (iii) the C restatement (oracle/dce_oracle.c) on one thread.
+    Every figure is the median of 3 repetitions on a bounded sample.  PyTorch's default (one
+    thread per logical CPU) oversubscribes these small convolutions on a many-core host, so each
+    shape gets the best thread count of a short sweep; `cores` is the count used for `value`."""
+    import torch
+    from oracle import torch_ref, oracle as orc
+    info = cpu_info()
+    avail = info["usable_cpus"]
+    tsd = torch_ref.to_torch(sd)
+    B = min(4096, windows_np.shape[0])
+    x_big = torch.from_numpy(windows_np[:B])
+    x_30 = torch.from_numpy(windows_np[:30])
+    seq = torch.from_numpy(seq_np)
+    sweep = sorted({t for t in (4, 8, 16, 32, 64, 128, avail) if t <= avail})
+
+    def best_threads(fn, units):
+        best_t, best = sweep[0], 0.0
+        for nt in sweep:
+            torch.set_num_threads(nt)
+            fn()                                              # warm this thread count
+            t0 = time.perf_counter()
+            fn()
+            r = units / (time.perf_counter() - t0)
+            if r > best:
+                best_t, best = nt, r
+        torch.set_num_threads(best_t)
+        return best_t
+
+    proto = {}
+    t_all = time.perf_counter()
+    # (i) model only
+    x_sw = x_big[:1024]
+    nt = best_threads(lambda: torch_ref.forward(tsd, x_sw), x_sw.shape[0])
+    ref_out = torch_ref.forward(tsd, x_big)                   # warm at full size; also the parity sample
+    med, rates = _median_rate(lambda: torch_ref.forward(tsd, x_big), B)
+    proto["model_only_B4096"] = {"windows_per_s": med, "threads": nt, "reps": rates, "sample": f"3 x {B} windows"}
+    big_rate, big_threads = med, nt
+    nt = best_threads(lambda: [torch_ref.forward(tsd, x_30) for _ in range(10)], 300)
+    med, rates = _median_rate(lambda: [torch_ref.forward(tsd, x_30) for _ in range(60)], 1800)
+    proto["model_only_B30"] = {"windows_per_s": med, "threads": nt, "reps": rates, "sample": "3 x 60 batches of 30"}
+    # (ii) the reference's loop shape
+    n1, n30 = 240, 1200
+    s1, s30 = seq[:n1 + 149], seq[:n30 + 149]
+    nt = best_threads(lambda: torch_ref.reference_loop(tsd, seq[:60 + 149], 1), 60)
+    med, rates = _median_rate(lambda: torch_ref.reference_loop(tsd, s1, 1), n1)
+    proto["reference_loop_B1"] = {"windows_per_s": med, "threads": nt, "reps": rates, "sample": f"3 x {n1} windows"}
+    nt = best_threads(lambda: torch_ref.reference_loop(tsd, seq[:300 + 149], 30), 300)
+    med, rates = _median_rate(lambda: torch_ref.reference_loop(tsd, s30, 30), n30)
+    proto["reference_loop_B30"] = {"windows_per_s": med, "threads": nt, "reps": rates, "sample": f"3 x {n30} windows"}
+    # (iii) C restatement, one thread
+    orc.set_threads(1)
+    o = orc.Oracle(sd)
+    nc = 96
+    o.forward_windows(windows_np[:2])
+    med, rates = _median_rate(lambda: o.forward_windows(windows_np[:nc]), nc)
+    proto["c_oracle_1thread"] = {"windows_per_s": med, "threads": 1, "reps": rates,
+                                 "sample": f"3 x {nc} windows (fp64-accumulating restatement)"}
+    orc.set_threads(0)
+    cpu_s = time.perf_counter() - t_all
+
+    ref = ref_out.numpy()
+    nchk = min(B, gpu_logits.shape[0])
+    diff = float(np.abs(ref[:nchk] - gpu_logits[:nchk]).max())
+    agree = int((ref[:nchk].argmax(1) == gpu_pred[:nchk]).sum())
     return {
-        "value": done / el, "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{reps} x {bs}-window batches of the bench input through oracle/torch_ref.forward "
-                  f"(PyTorch {torch.__version__} CPU, model only, {el:.1f} s; best of a thread sweep, "
-                  f"{avail} logical CPUs available)",
-        "gpu_vs_cpu_max_abs_logit_diff": diff, "gpu_vs_cpu_argmax_agree": f"{agree}/{bs}",
+        "value": big_rate, "unit": "windows/s", "cores": big_threads, "kind": "port",
+        "sample": f"median of 3 passes over the bench step's {B} windows through oracle/torch_ref.forward "
+                  f"(PyTorch {torch.__version__} CPU, model only, {big_threads} threads = best of a sweep over {sweep}); "
+                  f"whole protocol {cpu_s:.1f} s of CPU work",
+        **info, "protocol": proto,
+        "gpu_vs_cpu_max_abs_logit_diff": diff, "gpu_vs_cpu_argmax_agree": f"{agree}/{nchk}",
         "max_abs_logit": float(np.abs(ref).max()),
     }
+
+
+# ------------------------------------------------------------------------------------------------
+# extras: the other BASELINE configs, driver-measured inside the same JSON line
+# ------------------------------------------------------------------------------------------------
+def run_steps(model, windows, steps):
+    out = None
+    for _ in range(steps):
+        out = model.predict(windows)
+    return out
+
+
+def settle(torch, fn, seconds):
+    """Run fn() in bursts until `seconds` of wall time with the GPU busy have passed."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        n += 20
+        torch.cuda.synchronize()
+    return n, time.perf_counter() - t0
+
+
+def extra_streaming(torch, contact_cnn, sd, dev, n_windows=1_000_000):
+    """BASELINE configs[2]: dce_infer_sequence over a 1e6-window sequence (z-score fused)."""
+    m = contact_cnn(device=dev.index, max_batch=32768)
+    m.load_state_dict(sd).eval()
+    g = torch.Generator(device=dev).manual_seed(3)
+    seq = torch.randn((n_windows + 149, 54), generator=g, device=dev, dtype=torch.float32)
+    m.infer_sequence(seq[:32768 + 149])
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = m.infer_sequence(seq)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    ok_pred = bool((out["logits"].argmax(1).to(torch.int32) == out["pred"]).float().mean().item() > 0.99999)   # ties aside
+    bits = torch.stack([(out["pred"] >> s) & 1 for s in (3, 2, 1, 0)], 1).to(torch.uint8)
+    ok_bits = bool(torch.equal(bits, out["contacts"]))
+    host = seq.cpu().numpy()
+    m.infer_sequence(host[:32768 + 149])
+    htimes = []
+    for _ in range(3):                       # the first call also grows the ctx's staging buffers
+        t0 = time.perf_counter()
+        out_h = m.infer_sequence(host)
+        htimes.append(time.perf_counter() - t0)
+    dth = min(htimes[1:])
+    same = bool(np.array_equal(out_h["contacts"], out["contacts"].cpu().numpy())
+                and np.array_equal(out_h["logits"], out["logits"].cpu().numpy()))
+    m.close()
+    return {
+        "workload": f"BASELINE configs[2]: infer_sequence over {n_windows} windows (T={n_windows + 149}, N(0,1) fp32, "
+                    "device RNG seed 3), z-score fused, max_batch 32768, fp32",
+        "hbm_resident_windows_per_s": n_windows / dt, "hbm_resident_ms": dt * 1e3,
+        "hbm_resident_ms_each": [round(t * 1e3, 2) for t in times],
+        "pcie_inclusive_windows_per_s": n_windows / dth, "pcie_inclusive_ms": dth * 1e3,
+        "pcie_inclusive_ms_each": [round(t * 1e3, 2) for t in htimes],
+        "pcie_note": "numpy (T,54) in, numpy logits/pred/contacts out (216 MB H2D + 72 MB D2H staged chunk by chunk "
+                     "on a second stream); never `value`",
+        "host_path_equals_device_path_bitwise": same,
+        "pred_is_argmax_of_logits": ok_pred, "contacts_are_bits_of_pred": ok_bits,
+    }
+
+
+def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps):
+    """BASELINE configs[4]: fc.0 / fc.3 on bf16 MFMA (fp32 accumulate), conv stack and fc.6 fp32."""
+    m = contact_cnn(device=dev.index, max_batch=B, precision="bf16_fc")
+    m.load_state_dict(sd).eval()
+    settle(torch, lambda: m.predict(windows), 0.5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run_steps(m, windows, steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    m.profile(1)
+    m.profile_read(reset=True)
+    run_steps(m, windows, max(steps, 50))
+    torch.cuda.synchronize()
+    prof = m.profile_read(reset=True)
+    m.profile(0)
+    kern = kernel_table(prof, B, "bf16_fc")
+    lg, lr = out["logits"], ref_out["logits"]
+    flips = int((out["pred"] != ref_out["pred"]).sum().item())
+    res = {
+        "workload": f"BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; "
+                    "conv stack and fc.6 fp32",
+        "windows_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+        "vs_fp32_same_input": {"max_abs_dlogit": float((lg - lr).abs().max().item()),
+                               "max_abs_logit": float(lr.abs().max().item()),
+                               "argmax_flips": flips, "argmax_flip_rate": flips / B},
+        "kernels": kern,
+        "path_roof_windows_per_s": path_roof("bf16_fc"),
+        "path_frac_of_roof": (B * steps / dt) / path_roof("bf16_fc"),
+    }
+    m.close()
+    return res
+
+
+def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per_rank=1_000_000):
+    """BASELINE configs[3] literally: a (world*n + 149, 54) sequence, rank g holds rows
+    [g*n, (g+1)*n + 149) (its 149-row halo regenerated, not communicated), one fused pass per rank,
+    ONE gather of the packed (n,68)-byte results to rank 0."""
+    from deep_contact_estimator_amd.distributed import infer_sequence_sharded, shard_rows
+    m = contact_cnn(device=dev.index, max_batch=32768)
+    m.load_state_dict(sd).eval()
+    n_total = world * n_per_rank
+    r0, r1, _, _ = shard_rows(n_total + 149, rank, world)
+    g = torch.Generator(device=dev)
+    chunk = 1 << 20                                          # row r is a pure function of r: chunk-aligned streams
+    parts = []
+    for a in range(r0 - r0 % chunk, r1, chunk):
+        g.manual_seed(1000 + a // chunk)
+        blk = torch.randn((chunk, 54), generator=g, device=dev, dtype=torch.float32)
+        parts.append(blk[max(r0 - a, 0): min(r1 - a, chunk)])
+    rows = torch.cat(parts)
+    m.infer_sequence(rows[:32768 + 149])
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    res = infer_sequence_sharded(m.infer_sequence, rows, dst=0, n_windows=n_total, row_lo=r0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    m.close()
+    if rank != 0:
+        return None
+    assert res["logits"].shape == (n_total, 16) and res["contacts"].shape == (n_total, 4)
+    return {"workload": f"BASELINE configs[3]: {world} x {n_per_rank} windows, halo-sharded, one gather of the packed "
+                        "logits+contacts (68 B/window) to rank 0",
+            "windows_per_s_incl_gather": n_total / float(t.item()), "ms": float(t.item()) * 1e3,
+            "gathered_MB": n_total * 68 / 1e6}
 
 
 def main():
@@ -105,13 +360,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU per step")
+    ap.add_argument("--settle-s", type=float, default=1.5, help="untimed GPU-busy seconds before warm-up (clock settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--time-every", type=int, default=4,
-                    help="HIP-event pairs around the kernels of every k-th step (each event costs ~4 us of stream time)")
-    ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="skip the per-kernel HIP events (no roofline block); shows their overhead")
+    ap.add_argument("--no-extras", action="store_true", help="skip extra.* (configs[2]/[3]/[4] measurements)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the profiled pass (no roofline block)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc"],
-                    help="fp32 = the headline (exact fp32 MFMA); bf16_fc = BASELINE configs[4]")
+                    help="fp32 = the headline (exact fp32 MFMA); bf16_fc = BASELINE configs[4] as the main workload")
     args = ap.parse_args()
 
     import torch
@@ -144,7 +398,8 @@ def main():
 
     # synthetic input: a per-rank N(0,1) sequence, z-scored per window by the library
     # (contact_dataset.__getitem__), materialised as (B,150,54) in HBM before the timed region
-    seq = torch.from_numpy(synth.make_sequence(B + 149, seed=2 + rank).astype(np.float32)).to(dev)
+    seq_np = synth.make_sequence(B + 149, seed=2 + rank).astype(np.float32)
+    seq = torch.from_numpy(seq_np).to(dev)
     windows = model.zscore_windows(seq, 0, B)
     torch.cuda.synchronize()
 
@@ -153,7 +408,7 @@ def main():
         from deep_contact_estimator_amd.distributed import AsyncRowGather
         gatherer = AsyncRowGather(B, 16, torch.float32, dev, dst=0, depth=2)
 
-    def step(i):
+    def step():
         out = model.predict(windows)
         if gatherer is not None:
             gatherer.submit(out["logits"])
@@ -163,62 +418,49 @@ def main():
         if gatherer is not None:
             gatherer.drain()
 
-    for i in range(args.warmup):
-        out = step(i)
+    # 1. settle, 2. warm-up
+    settle_steps, settle_s = settle(torch, step, args.settle_s)
+    for _ in range(args.warmup):
+        out = step()
     drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    model.profile(0 if args.no_kernel_timing else args.time_every)
-    model.profile_read(reset=True)
-    torch.cuda.synchronize()
+    # 3. timed region: no events, no host work besides the launches
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
+    for _ in range(args.steps):
+        out = step()
     drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    t1 = time.perf_counter()
-    prof = model.profile_read(reset=True)
-    model.profile(0)
-
-    elapsed = t1 - t0
+    elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # 4. profiled pass: HIP events around every kernel of every step (same loop, same stream)
+    prof, prof_ms_per_step, psteps = {}, None, max(args.steps, 50)
+    if not args.no_kernel_timing:
+        model.profile(1)
+        model.profile_read(reset=True)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(psteps):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        prof_ms_per_step = (time.perf_counter() - tp) / psteps * 1e3
+        prof = model.profile_read(reset=True)
+        model.profile(0)
+
+    res = None
     if rank == 0:
         wps = world * B * args.steps / elapsed
-        kernels = {}
-        for k, v in prof.items():
-            if v["launches"] == 0:
-                continue
-            avg_ms = v["ms"] / v["launches"]
-            kernels[k] = {
-                "avg_ms": avg_ms, "launches": v["launches"],
-                "tflops": FLOP[k] * B / (avg_ms * 1e-3) / 1e12,
-                "frac_fp32_mfma_peak": FLOP[k] * B / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "algorithmic_GBs": BYTES[k] * B / (avg_ms * 1e-3) / 1e9,
-                "executed_mfma_tflops": EXEC_FLOP[k] * B / (avg_ms * 1e-3) / 1e12,
-            }
-        if not kernels:
-            print(json.dumps({"metric": "inference windows/sec (54-ch, win=150)", "value": wps, "unit": "windows/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": elapsed / args.steps * 1e3, "note": "--no-kernel-timing"}))
-            return
-        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        kernels = kernel_table(prof, B, args.precision)
         res = {
-            "metric": "inference windows/sec (54-ch, win=150)",
-            "value": wps, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC, "value": wps, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f32 conv + bf16 FC (f32 accumulate)", "data": "synthetic",
@@ -228,27 +470,60 @@ def main():
                             "(dce_forward_windows, fp32 MFMA); synthetic He-init checkpoint seed 1",
                 "batch_per_gpu": B, "global_batch": B * world, "window": 150, "channels": 54,
                 "sharding": "independent windows per rank" + ("; async RCCL gather of (B,16) logits to rank 0 per step" if world > 1 else ""),
+                "settle": {"steps": settle_steps, "seconds": round(settle_s, 3)},
             },
-            "roofline": {
-                "kernel": dom, "bound": "mfma",
-                "achieved": kernels[dom]["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": kernels[dom]["frac_fp32_mfma_peak"], "traffic": traffic,
-                "flops_per_launch": FLOP[dom] * B, "avg_launch_ms": kernels[dom]["avg_ms"],
-                "hbm_informational": {"algorithmic_GBs": kernels[dom]["algorithmic_GBs"],
-                                      "frac_of_8TBs": kernels[dom]["algorithmic_GBs"] / PEAK_HBM_GBS},
-                "executed_mfma_tflops": kernels[dom]["executed_mfma_tflops"],
-                "frac_executed": kernels[dom]["executed_mfma_tflops"] / PEAK_FP32_MFMA_TFLOPS,
-                "note": "achieved/frac use ALGORITHMIC FLOPs (2*MAC of the reference's layers); the conv stack "
-                        "runs Winograd F(2,3) and executes 2/3 of them on the matrix pipe, so its algorithmic "
-                        "fraction can exceed 1 -- frac_executed is the hardware-side fraction",
-            },
-            "kernels": kernels,
-            "path_flops_frac_of_peak": wps / world * sum(FLOP.values()) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         }
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+            kd = kernels[dom]
+            traffic, traffic_src = None, None
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc_path):
+                try:
+                    ent = json.load(open(pmc_path)).get(dom, {})
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_src = (f"profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                   f"profile {ent.get('profile')}; replayed, not measured in this run)")
+                except Exception:
+                    traffic = None
+            res["roofline"] = {
+                "kernel": dom, "bound": "mfma", "achieved": kd["executed_tflops"], "peak": kd["peak_tflops"],
+                "unit": "TFLOP/s", "frac": kd["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "flops_per_launch": EXEC_FLOP[dom] * B, "avg_launch_ms": kd["avg_ms"], "launches_timed": kd["launches"],
+                "algorithmic_flops_per_launch": ALGO_FLOP[dom] * B,
+                "hbm_informational": {"algorithmic_bytes_per_launch": ALGO_BYTES[dom] * B,
+                                      "algorithmic_GBs": kd["algorithmic_GBs"],
+                                      "frac_of_8TBs": kd["algorithmic_GBs"] / PEAK_HBM_GBS},
+                "note": "achieved = matrix-pipe FLOPs issued per launch / average launch duration (HIP events on the launch "
+                        "stream, profiled pass); for this GEMM issued == algorithmic 2*M*N*K",
+            }
+            res["kernels"] = kernels
+            res["profiled_pass"] = {"steps": psteps, "ms_per_step": prof_ms_per_step,
+                                    "sum_kernel_ms": sum(k["avg_ms"] for k in kernels.values())}
+        roof = path_roof(args.precision)
+        res["path"] = {
+            "executed_mfma_flop_per_window": sum(EXEC_FLOP[k] for k in ("conv_stack", "fc1_gemm", "fc2_gemm", "fc3_tail")),
+            "algorithmic_flop_per_window": sum(ALGO_FLOP[k] for k in ("conv_stack", "fc1_gemm", "fc2_gemm", "fc3_tail")),
+            "roof_windows_per_s_per_gpu": roof, "frac_of_roof": wps / world / roof,
+            "note": "roof = every kernel at the peak of its pipe on the FLOPs it issues (Winograd conv stack: 2/3 of 2*MAC)",
+        }
+
+    # 5. the other configs + the CPU baseline (N=1: rank 0 alone; N>1: every rank takes part in the sharded pass)
+    if not args.no_extras:
+        if world > 1:
+            sh = extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend)
+            if rank == 0:
+                res["extra"] = {"sharded_1e6": sh}
+        elif args.precision == "fp32":
+            res["extra"] = {
+                "streaming_1e6": extra_streaming(torch, contact_cnn, sd, dev),
+                "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps),
+            }
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd, windows.cpu().numpy(), out["logits"].cpu().numpy(),
+            res["cpu_baseline"] = cpu_baseline(sd, windows.cpu().numpy(), seq_np, out["logits"].cpu().numpy(),
                                                out["pred"].cpu().numpy())
-            res["speedup_vs_cpu_baseline"] = wps / res["cpu_baseline"]["value"]
+            res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

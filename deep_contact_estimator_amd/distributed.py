@@ -3,9 +3,10 @@
 Windows are independent (no BatchNorm, Dropout off in eval: reference utils/data_handler.py:55-57
 uses only rows [i, i+150)), so rank g of G takes a contiguous range of windows and therefore the
 sequence rows of that range plus a 149-row halo; weights are replicated.  There is no collective
-inside the model.  The one exchange the path has is collecting the results: an RCCL gather of the
-(n_g,16) fp32 logits (and the (n_g,4) u8 contacts) to rank 0 -- point-to-point over xGMI, each
-peer on its own link.  One process per GPU; ``torch.distributed`` backend "nccl" (= RCCL) on the
+inside the model.  The one exchange the path has is collecting the results: ONE RCCL gather of
+(n_g,68)-byte rows -- the (n_g,16) fp32 logits and the (n_g,4) u8 contacts packed side by side --
+to rank 0, point-to-point over xGMI, each peer on its own link.  Shard sizes are a pure function of
+(n, world): nothing but the payload is ever exchanged.  One process per GPU; ``torch.distributed`` backend "nccl" (= RCCL) on the
 GPUs, "gloo" in the CPU tests of this logic.
 """
 from __future__ import annotations
@@ -31,9 +32,43 @@ def shard_rows(T: int, rank: int, world: int) -> tuple[int, int, int, int]:
     return lo, hi + WINDOW - 1, lo, hi
 
 
-def gather_rows(t, group=None, dst: int = 0):
-    """Gather per-rank row blocks of unequal length to `dst`, concatenated in rank order.
-    One size exchange (all_gather of a scalar) + one gather of the padded blocks."""
+def shard_sizes(n_windows: int, world: int) -> list[int]:
+    """Rows every rank contributes: a pure function of (n_windows, world), so no size exchange."""
+    return [hi - lo for lo, hi in (shard_range(n_windows, r, world) for r in range(world))]
+
+
+PACK_COLS = 68      # one result row on the wire: 16 fp32 logits (64 B) + 4 contact bits (4 B)
+
+
+def pack_results(out):
+    """{'logits' (n,16) f32, 'contacts' (n,4) u8[, 'pred']} -> ONE (n,68) uint8 block, so the
+    exchange is a single collective.  'pred' is not sent: it is the 4 contact bits read as a
+    number (decimal2binary is a bijection on 0..15; reference src/inference_one_seq.py:59-62)."""
+    import torch
+    lg = out["logits"].contiguous()
+    n = lg.shape[0]
+    buf = torch.empty((n, PACK_COLS), dtype=torch.uint8, device=lg.device)
+    buf[:, :64] = lg.view(torch.uint8).reshape(n, 64)
+    buf[:, 64:] = out["contacts"]
+    return buf
+
+
+def unpack_results(buf):
+    """Inverse of pack_results (bit-exact) -> {'logits', 'pred' (int32), 'contacts'}."""
+    import torch
+    n = buf.shape[0]
+    logits = buf[:, :64].contiguous().view(torch.float32).reshape(n, 16)
+    contacts = buf[:, 64:].contiguous()
+    c = contacts.to(torch.int32)
+    pred = c[:, 0] * 8 + c[:, 1] * 4 + c[:, 2] * 2 + c[:, 3]
+    return {"logits": logits, "pred": pred, "contacts": contacts}
+
+
+def gather_rows(t, sizes=None, group=None, dst: int = 0):
+    """Gather per-rank row blocks to `dst`, concatenated in rank order, with ONE collective.
+    `sizes[r]` = rows of rank r; for sharded windows it is shard_sizes(n, world), known to every
+    rank without communication.  (sizes=None: every rank passes the same number of rows.)
+    Blocks are padded to the longest one (shards differ by at most one row)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -41,10 +76,10 @@ def gather_rows(t, group=None, dst: int = 0):
     home = t.device
     if dist.get_backend(group) == "gloo":     # CPU transport (tests; no xGMI): exchange host copies
         t = t.cpu()
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        sizes = [t.shape[0]] * world
+    if t.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank} holds {t.shape[0]} rows, shard_sizes says {sizes[rank]}")
     nmax = max(sizes)
     pad = t
     if t.shape[0] < nmax:
@@ -57,18 +92,26 @@ def gather_rows(t, group=None, dst: int = 0):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0).to(home)
 
 
-def infer_sequence_sharded(run, seq, group=None, dst: int = 0):
+def infer_sequence_sharded(run, seq, group=None, dst: int = 0, n_windows: int | None = None, row_lo: int = 0):
     """Run `run(seq_rows) -> {'logits','pred','contacts'}` (e.g. contact_cnn.infer_sequence) on
-    this rank's shard of `seq` ((T,54), identical on every rank or at least valid on its own row
-    range) and gather the results to rank `dst` in window order.  Returns the full dict on `dst`,
-    None elsewhere."""
+    this rank's shard of the sequence and gather the results to rank `dst` in window order with a
+    single collective (logits + contact bits packed per row).  Returns the full dict on `dst`,
+    None elsewhere.
+
+    seq: the whole (T,54) sequence (identical on every rank, or at least valid on its own row
+    range), or -- with `n_windows` = windows of the WHOLE sequence and `row_lo` = global index of
+    seq's first row -- just this rank's rows (halo included), as when every rank generated or loaded
+    only its own slice."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    r0, r1, _, _ = shard_rows(seq.shape[0], rank, world)
-    out = run(seq[r0:r1])
-    res = {k: gather_rows(v, group, dst) for k, v in out.items()}
-    return res if rank == dst else None
+    if n_windows is None:
+        n_windows = max(seq.shape[0] - WINDOW + 1, 0)
+    sizes = shard_sizes(n_windows, world)
+    r0, r1, _, _ = shard_rows(n_windows + WINDOW - 1 if n_windows > 0 else 0, rank, world)
+    out = run(seq[r0 - row_lo:r1 - row_lo])
+    got = gather_rows(pack_results(out), sizes, group, dst)
+    return unpack_results(got) if rank == dst else None
 
 
 def confusion_sharded(run, count, seq, labels, group=None):

@@ -36,6 +36,7 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_default_threads = None
 
 
 def lib():
@@ -46,6 +47,17 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_argmax16.restype = C.c_int32
     return _lib
+
+
+def set_threads(n: int) -> None:
+    """OpenMP threads of the windows loop (oracle_forward_windows / oracle_infer_sequence):
+    n = 1 for the single-thread timing of bench.py's cpu_baseline, n <= 0 restores one per CPU."""
+    global _default_threads
+    lib()
+    gomp = C.CDLL("libgomp.so.1")
+    if _default_threads is None:
+        _default_threads = gomp.omp_get_max_threads()
+    gomp.omp_set_num_threads(int(n) if n > 0 else _default_threads)
 
 
 def _p(a):

@@ -25,12 +25,31 @@ def test_shard_ranges_cover_exactly():
     assert shard_rows(100, 0, 2)[:2] == (0, 0)                       # shorter than one window
 
 
-def _worker(rank, world, port, T, out_path):
+def test_pack_unpack_is_bit_exact():
+    """The single-collective wire format: 16 fp32 logits + 4 contact bits per row, pred re-derived."""
+    import torch
+    from deep_contact_estimator_amd.distributed import pack_results, unpack_results, shard_sizes, PACK_COLS
+    rng = np.random.default_rng(5)
+    lg = rng.standard_normal((37, 16)).astype(np.float32)
+    lg[3, 2] = np.nan; lg[4, 0] = np.inf; lg[5, 1] = -0.0
+    pred = rng.integers(0, 16, 37).astype(np.int32)
+    contacts = ((pred[:, None] & np.array([8, 4, 2, 1])) != 0).astype(np.uint8)
+    buf = pack_results({"logits": torch.from_numpy(lg), "contacts": torch.from_numpy(contacts)})
+    assert buf.shape == (37, PACK_COLS) and buf.dtype == torch.uint8
+    back = unpack_results(buf)
+    assert np.array_equal(back["logits"].numpy().view(np.uint32), lg.view(np.uint32))      # bit pattern, NaN included
+    assert np.array_equal(back["contacts"].numpy(), contacts) and np.array_equal(back["pred"].numpy(), pred)
+    empty = unpack_results(pack_results({"logits": torch.zeros((0, 16)), "contacts": torch.zeros((0, 4), dtype=torch.uint8)}))
+    assert empty["logits"].shape == (0, 16) and empty["pred"].shape == (0,)
+    assert shard_sizes(10, 4) == [3, 3, 2, 2] and shard_sizes(0, 3) == [0, 0, 0] and sum(shard_sizes(8_000_000, 8)) == 8_000_000
+
+
+def _worker(rank, world, port, T, out_path, local_slices=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     from deep_contact_estimator_amd import synth
-    from deep_contact_estimator_amd.distributed import infer_sequence_sharded
+    from deep_contact_estimator_amd.distributed import infer_sequence_sharded, shard_rows
     from oracle import oracle as orc
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -42,7 +61,11 @@ def _worker(rank, world, port, T, out_path):
         r = o.infer_sequence(rows.numpy())
         return {k: torch.from_numpy(v) for k, v in r.items()}
 
-    res = infer_sequence_sharded(run, seq, dst=0)
+    if local_slices:      # every rank holds only its own rows (halo included), as in configs[3]
+        r0, r1, _, _ = shard_rows(T, rank, world)
+        res = infer_sequence_sharded(run, seq[r0:r1].clone(), dst=0, n_windows=T - 149, row_lo=r0)
+    else:
+        res = infer_sequence_sharded(run, seq, dst=0)
     if rank == 0:
         np.savez(out_path, **{k: v.numpy() for k, v in res.items()})
     else:
@@ -51,8 +74,9 @@ def _worker(rank, world, port, T, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("T", [150 + 60, 150 + 2, 151])      # even split, tiny, one rank empty
-def test_two_rank_gather_matches_single_process(T, tmp_path):
+@pytest.mark.parametrize("T,local_slices", [(150 + 60, False), (150 + 2, False), (151, False),   # even split, tiny, one rank empty
+                                            (150 + 61, True), (151, True)])                         # ranks hold only their rows
+def test_two_rank_gather_matches_single_process(T, local_slices, tmp_path):
     import torch.multiprocessing as mp
     from deep_contact_estimator_amd import synth
     from oracle import oracle as orc
@@ -60,7 +84,7 @@ def test_two_rank_gather_matches_single_process(T, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "gathered.npz")
-    mp.spawn(_worker, args=(2, port, T, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, T, out, local_slices), nprocs=2, join=True)
     got = np.load(out)
     ref = orc.Oracle(synth.make_state_dict(1, "uniform")).infer_sequence(
         synth.make_sequence(T, 17).astype(np.float32))

@@ -5,9 +5,9 @@ set -u
 TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
-B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+B="python bench.py --steps 20 --warmup 3 --settle-s 0.2 --no-cpu-baseline --no-extras --no-kernel-timing"
 # long enough for the clocks to settle: the averages then agree with bench.py's HIP-event times to <1 %
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o ${TAG} -- python bench.py --steps 300 --warmup 50 --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o ${TAG} -- python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extras --no-kernel-timing > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- $B > $OUT/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- $B > $OUT/${TAG}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/${TAG}_pmc_sq -o ${TAG} -- $B > $OUT/${TAG}_pmc_sq.log 2>&1
