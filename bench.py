@@ -156,7 +156,9 @@ def cpu_baseline(sd, windows_np, seq_np, gpu_logits, gpu_pred):
     x_big = torch.from_numpy(windows_np[:B])
     x_30 = torch.from_numpy(windows_np[:30])
     seq = torch.from_numpy(seq_np)
-    sweep = sorted({t for t in (4, 8, 16, 32, 64, 128, avail) if t <= avail})
+    # thread counts tried per shape: beyond 64 threads these small ops only lose (and one trial of the
+    # B=1 loop at 256 threads costs tens of seconds), so the sweep stops there
+    sweep = sorted({t for t in (4, 8, 16, 32, 64) if t <= avail}) or [1]
 
     def best_threads(fn, units):
         best_t, best = sweep[0], 0.0
@@ -174,7 +176,7 @@ def cpu_baseline(sd, windows_np, seq_np, gpu_logits, gpu_pred):
     proto = {}
     t_all = time.perf_counter()
     # (i) model only
-    x_sw = x_big[:1024]
+    x_sw = x_big[:512]
     nt = best_threads(lambda: torch_ref.forward(tsd, x_sw), x_sw.shape[0])
     ref_out = torch_ref.forward(tsd, x_big)                   # warm at full size; also the parity sample
     med, rates = _median_rate(lambda: torch_ref.forward(tsd, x_big), B)

@@ -15,6 +15,7 @@ through and the launch is queued on torch's current stream).  No CPU fallback ex
 from __future__ import annotations
 
 import ctypes as C
+import numbers
 from typing import Mapping
 
 import numpy as np
@@ -34,8 +35,8 @@ def _device_index(device) -> int:
     """'cuda', 'cuda:1', torch.device, int -> HIP device ordinal.  'cpu' is refused."""
     if device is None:
         return 0
-    if isinstance(device, int):
-        return device
+    if isinstance(device, numbers.Integral):          # int, numpy integer ids
+        return int(device)
     s = str(device)
     if s.startswith("cpu"):
         raise RuntimeError("deep_contact_estimator_amd runs on MI355X only; there is no CPU path "
@@ -78,6 +79,7 @@ class contact_cnn:
         if getattr(self, "_ctx", None):
             self._lib.dce_destroy(self._ctx)
             self._ctx = C.c_void_p()
+        self._finalized = False             # a later call re-creates the ctx and uploads the weights again
 
     def __del__(self):
         try:

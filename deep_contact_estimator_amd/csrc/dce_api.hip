@@ -40,7 +40,7 @@ struct dce_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t xstream_ev = nullptr;
     hipStream_t xfer_stream = nullptr;     // host-buffer callers: chunk copies overlap the kernels of the
-    std::vector<hipEvent_t> xfer_ev;       // neighbouring chunks (2 events per chunk: staged-in, computed)
+    hipEvent_t ring_ev[3][3] = {};         // neighbouring chunks; per ring slot: staged-in, computed, staged-out
     std::string err;
 
     std::vector<float> host_w[14];         // staged state_dict (host, PyTorch layout)
@@ -58,7 +58,8 @@ struct dce_ctx {
 
     float *feat = nullptr, *h1 = nullptr, *h2 = nullptr;   // scratch, max_batch rows each
 
-    // staging for host-pointer callers
+    // staging for host-pointer callers: a ring of RING_SLOTS chunk-sized slots (run_all), so that
+    // the device footprint is bounded by max_batch, not by the length of the caller's input
     float* d_in = nullptr;   size_t d_in_bytes = 0;
     float* d_logits = nullptr; int32_t* d_pred = nullptr; uint8_t* d_contacts = nullptr;
     size_t d_out_rows = 0;
@@ -109,6 +110,25 @@ int fail(dce_ctx* c, int code, const char* fmt, ...)
         if (e_ != hipSuccess)                                                                  \
             return fail((c), DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
     } while (0)
+
+// Every entry point binds the calling thread to the ctx's device for the duration of the call and
+// puts the caller's device back on return (a single-process multi-GPU host must not find its
+// current device changed by a call into this library).
+struct DeviceGuard {
+    int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DEVICE_GUARD(c)                                                                         \
+    DeviceGuard dev_guard_((c)->device);                                                        \
+    if (dev_guard_.err != hipSuccess)                                                           \
+        return fail((c), DCE_ERR_HIP, "hipSetDevice(%d) failed: %s", (c)->device, hipGetErrorString(dev_guard_.err))
 
 struct Timer {   // records a [begin,end] event pair around one launch when profiling is on
     dce_ctx* c; int slot; hipEvent_t a = nullptr, b = nullptr;
@@ -180,8 +200,10 @@ int ensure_in(dce_ctx* c, size_t bytes)
 int ensure_out(dce_ctx* c, size_t rows)
 {
     if (c->d_out_rows >= rows) return DCE_OK;
-    if (c->d_logits) { hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); }
-    c->d_logits = nullptr; c->d_pred = nullptr; c->d_contacts = nullptr; c->d_out_rows = 0;
+    c->d_out_rows = 0;
+    if (c->d_logits)   { HIP_TRY(c, hipFree(c->d_logits));   c->d_logits = nullptr; }
+    if (c->d_pred)     { HIP_TRY(c, hipFree(c->d_pred));     c->d_pred = nullptr; }
+    if (c->d_contacts) { HIP_TRY(c, hipFree(c->d_contacts)); c->d_contacts = nullptr; }
     HIP_TRY(c, hipMalloc(&c->d_logits, rows * NCLS * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->d_pred, rows * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc(&c->d_contacts, rows * 4));
@@ -193,7 +215,6 @@ int check_ready(dce_ctx* c)
 {
     if (!c) return DCE_ERR_ARG;
     if (!c->finalized) return fail(c, DCE_ERR_STATE, "weights not finalized: call dce_finalize_weights first");
-    HIP_TRY(c, hipSetDevice(c->device));
     return DCE_OK;
 }
 
@@ -219,47 +240,67 @@ int run_all(dce_ctx* c, const float* src, int zscore, int64_t n, int64_t src_flo
         }
         return DCE_OK;
     }
-    int rc = ensure_in(c, (size_t)src_floats * sizeof(float));
+    // ---- host pointers: a ring of RING chunk slots.  Chunk i lives in slot i % RING:
+    //   xfer stream : [wait computed(i-RING)] H2D(i) -> staged-in(i)        [wait computed(i)] D2H(i) -> staged-out(i)
+    //   ctx stream  : [wait staged-in(i), staged-out(i-RING)] kernels(i) -> computed(i)
+    // so the copies of chunks i+1 / i-1 run under the kernels of chunk i and the device footprint is
+    // RING * max_batch rows, whatever n is.  The copies go straight from / to the caller's memory
+    // (pageable or pinned; HIP stages pageable memory itself).
+    constexpr int RING = 3;
+    const int64_t mb = c->max_batch < n ? c->max_batch : n;
+    const int64_t in_slot_floats = zscore ? (mb + WIN - 1) * CH : mb * row_floats;
+    (void)src_floats;
+    int rc = ensure_in(c, (size_t)RING * in_slot_floats * sizeof(float));
     if (rc) return rc;
-    rc = ensure_out(c, (size_t)n);
+    rc = ensure_out(c, (size_t)RING * mb);
     if (rc) return rc;
     if (!c->xfer_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->xfer_stream, hipStreamNonBlocking));
-    while ((int64_t)c->xfer_ev.size() < 2 * nchunks) {
-        hipEvent_t e = nullptr;
-        HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->xfer_ev.push_back(e);
-    }
+    for (auto& slot : c->ring_ev)
+        for (auto& e : slot)
+            if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     hipStream_t xs = c->xfer_stream;
+    enum { EV_IN = 0, EV_DONE = 1, EV_OUT = 2 };
+    // on ANY failure below: nothing may still be copying into the caller's buffers when we return
+    auto bail = [&](int code) { (void)hipStreamSynchronize(xs); (void)hipStreamSynchronize(c->stream); return code; };
+#define RING_TRY(expr)                                                                          \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                          \
+        return bail(fail(c, DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
     auto stage_in = [&](int64_t i) -> int {
-        // a sequence chunk needs rows [i0, i0+nb+149): all but the first bring only their nb new rows
+        // a sequence chunk needs rows [i0, i0+nb+149): its 149-row halo is copied again (32 KB)
+        const int s = (int)(i % RING);
         const int64_t i0 = i * c->max_batch, nb = chunk_rows(i);
-        const int64_t lo = zscore ? (i == 0 ? 0 : (i0 + WIN - 1) * CH) : i0 * row_floats;
-        const int64_t hi = zscore ? (i0 + nb + WIN - 1) * CH : (i0 + nb) * row_floats;
-        HIP_TRY(c, hipMemcpyAsync(c->d_in + lo, src + lo, (size_t)(hi - lo) * sizeof(float), hipMemcpyHostToDevice, xs));
-        HIP_TRY(c, hipEventRecord(c->xfer_ev[2 * i], xs));
+        const int64_t lo = i0 * row_floats;
+        const int64_t cnt = zscore ? (nb + WIN - 1) * CH : nb * row_floats;
+        if (i >= RING) RING_TRY(hipStreamWaitEvent(xs, c->ring_ev[s][EV_DONE], 0));     // slot's previous kernels have read it
+        RING_TRY(hipMemcpyAsync(c->d_in + s * in_slot_floats, src + lo, (size_t)cnt * sizeof(float), hipMemcpyHostToDevice, xs));
+        RING_TRY(hipEventRecord(c->ring_ev[s][EV_IN], xs));
         return DCE_OK;
     };
     auto stage_out = [&](int64_t i) -> int {
+        const int s = (int)(i % RING);
         const int64_t i0 = i * c->max_batch, nb = chunk_rows(i);
-        HIP_TRY(c, hipStreamWaitEvent(xs, c->xfer_ev[2 * i + 1], 0));
-        if (logits)   HIP_TRY(c, hipMemcpyAsync(logits + i0 * NCLS, c->d_logits + i0 * NCLS, (size_t)nb * NCLS * sizeof(float), hipMemcpyDeviceToHost, xs));
-        if (pred)     HIP_TRY(c, hipMemcpyAsync(pred + i0, c->d_pred + i0, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
-        if (contacts) HIP_TRY(c, hipMemcpyAsync(contacts + i0 * 4, c->d_contacts + i0 * 4, (size_t)nb * 4, hipMemcpyDeviceToHost, xs));
+        RING_TRY(hipStreamWaitEvent(xs, c->ring_ev[s][EV_DONE], 0));
+        if (logits)   RING_TRY(hipMemcpyAsync(logits + i0 * NCLS, c->d_logits + s * mb * NCLS, (size_t)nb * NCLS * sizeof(float), hipMemcpyDeviceToHost, xs));
+        if (pred)     RING_TRY(hipMemcpyAsync(pred + i0, c->d_pred + s * mb, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
+        if (contacts) RING_TRY(hipMemcpyAsync(contacts + i0 * 4, c->d_contacts + s * mb * 4, (size_t)nb * 4, hipMemcpyDeviceToHost, xs));
+        RING_TRY(hipEventRecord(c->ring_ev[s][EV_OUT], xs));
         return DCE_OK;
     };
     if ((rc = stage_in(0))) return rc;
     for (int64_t i = 0; i < nchunks; ++i) {
-        const int64_t i0 = i * c->max_batch;
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->xfer_ev[2 * i], 0));
-        rc = run_chunk(c, c->d_in + i0 * row_floats, zscore, chunk_rows(i),
-                       c->d_logits + i0 * NCLS, c->d_pred + i0, c->d_contacts + i0 * 4);
-        if (rc) return rc;
-        HIP_TRY(c, hipEventRecord(c->xfer_ev[2 * i + 1], c->stream));
+        const int s = (int)(i % RING);
+        RING_TRY(hipStreamWaitEvent(c->stream, c->ring_ev[s][EV_IN], 0));
+        if (i >= RING) RING_TRY(hipStreamWaitEvent(c->stream, c->ring_ev[s][EV_OUT], 0));   // slot's previous results have left
+        rc = run_chunk(c, c->d_in + s * in_slot_floats, zscore, chunk_rows(i),
+                       c->d_logits + s * mb * NCLS, c->d_pred + s * mb, c->d_contacts + s * mb * 4);
+        if (rc) return bail(rc);
+        RING_TRY(hipEventRecord(c->ring_ev[s][EV_DONE], c->stream));
         if (i + 1 < nchunks && (rc = stage_in(i + 1))) return rc;
         if (i >= 1 && (rc = stage_out(i - 1))) return rc;
     }
     if ((rc = stage_out(nchunks - 1))) return rc;
-    HIP_TRY(c, hipStreamSynchronize(xs));
+    RING_TRY(hipStreamSynchronize(xs));
+#undef RING_TRY
     return DCE_OK;
 }
 
@@ -297,7 +338,8 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                        \
         fail(nullptr, DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));              \
         dce_destroy(c); return DCE_ERR_HIP; } } while (0)
-    CREATE_TRY(hipSetDevice(device_id));
+    DeviceGuard guard(device_id);                        // the caller's current device is put back on return
+    CREATE_TRY(guard.err);
     CREATE_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     CREATE_TRY(init_conv_stack());
@@ -314,14 +356,14 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
 void dce_destroy(dce_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     if (c->stream != c->own_stream) hipStreamSynchronize(c->stream);   // scratch may still be in use there
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->xstream_ev) hipEventDestroy(c->xstream_ev);
     if (c->xfer_stream) { hipStreamSynchronize(c->xfer_stream); hipStreamDestroy(c->xfer_stream); }
-    for (auto e : c->xfer_ev) hipEventDestroy(e);
+    for (auto& slot : c->ring_ev) for (auto e : slot) if (e) hipEventDestroy(e);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2);
     hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts);
     if (c->online_exec) hipGraphExecDestroy(c->online_exec);
@@ -339,7 +381,7 @@ int dce_set_stream(dce_ctx* c, void* hip_stream, int use_own)
     if (next != c->stream) {
         // the scratch buffers are shared by every call on this ctx: work queued on the new
         // stream must not overtake what is still in flight on the old one
-        HIP_TRY(c, hipSetDevice(c->device));
+        DEVICE_GUARD(c);
         if (!c->xstream_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->xstream_ev, hipEventDisableTiming));
         HIP_TRY(c, hipEventRecord(c->xstream_ev, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(next, c->xstream_ev, 0));
@@ -376,7 +418,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         return fail(c, DCE_ERR_ARG, "unknown precision %d (0 = fp32, 1 = bf16 FC)", precision);
     for (int k = 0; k < 14; ++k)
         if (!c->have[k]) return fail(c, DCE_ERR_STATE, "missing state_dict key '%s'", kKeys[k].name);
-    HIP_TRY(c, hipSetDevice(c->device));
+    DEVICE_GUARD(c);
     // a captured online graph holds the old weight pointers / precision: drop it, the next push re-captures
     if (c->online_exec) { hipGraphExecDestroy(c->online_exec); c->online_exec = nullptr; }
     if (c->online_graph) { hipGraphDestroy(c->online_graph); c->online_graph = nullptr; }
@@ -435,6 +477,7 @@ int dce_forward_windows(dce_ctx* c, const float* windows, int64_t n, int on_devi
 {
     int rc = check_ready(c);
     if (rc) return rc;
+    DEVICE_GUARD(c);
     if (n < 0 || (n > 0 && !windows)) return fail(c, DCE_ERR_ARG, "dce_forward_windows: bad argument");
     if (n == 0) return DCE_OK;
     return run_all(c, windows, 0, n, n * WIN * CH, on_device, logits, pred, contacts);
@@ -445,6 +488,7 @@ int dce_infer_sequence(dce_ctx* c, const float* seq, int64_t T, int window, int 
 {
     int rc = check_ready(c);
     if (rc) return rc;
+    DEVICE_GUARD(c);
     if (window != WIN) return fail(c, DCE_ERR_ARG, "window_size must be %d (the model hard-codes 4736 = 128*37), got %d", WIN, window);
     if (T < 0 || (T > 0 && !seq)) return fail(c, DCE_ERR_ARG, "dce_infer_sequence: bad argument");
     const int64_t n = T - WIN + 1;
@@ -456,7 +500,7 @@ int dce_zscore_windows(dce_ctx* c, const float* seq, int64_t T, int64_t first, i
                        int on_device, float* windows_out)
 {
     if (!c) return DCE_ERR_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
+    DEVICE_GUARD(c);
     if (first < 0 || n < 0 || first + n + WIN - 1 > T || !seq || !windows_out)
         return fail(c, DCE_ERR_ARG, "dce_zscore_windows: windows [%lld,%lld) out of range for T=%lld",
                     (long long)first, (long long)(first + n), (long long)T);
@@ -481,6 +525,7 @@ int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
 {
     int rc = check_ready(c);
     if (rc) return rc;
+    DEVICE_GUARD(c);
     if (n <= 0 || n > c->max_batch || !windows)
         return fail(c, DCE_ERR_ARG, "dce_forward_taps: need 0 < n <= max_batch (%lld)", (long long)c->max_batch);
     if (c->precision != DCE_FP32 && (feat || h1))
@@ -513,7 +558,7 @@ int dce_confusion_counts(dce_ctx* c, const int32_t* pred, const int64_t* labels,
 {
     if (!c) return DCE_ERR_ARG;
     if (n < 0 || !counts || (n > 0 && (!pred || !labels))) return fail(c, DCE_ERR_ARG, "dce_confusion_counts: bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DEVICE_GUARD(c);
     if (n == 0) return DCE_OK;
     if (on_device) {
         HIP_TRY(c, launch_confusion16(pred, labels, n, reinterpret_cast<unsigned long long*>(counts), c->stream));
@@ -549,12 +594,20 @@ namespace {
 // pinned block: [0,16) logits | [16] pred | [17] contacts | [32] completion flag | [40,94) the incoming sample
 constexpr int PIN_FLAG = 32, PIN_SAMPLE = 40, PIN_FLOATS = 96;
 
+#if defined(__x86_64__) || defined(__i386__)
+#define DCE_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define DCE_CPU_RELAX() asm volatile("yield" ::: "memory")
+#else
+#define DCE_CPU_RELAX() do {} while (0)
+#endif
+
 int online_wait(dce_ctx* c, unsigned expect)
 {
     unsigned* flag = reinterpret_cast<unsigned*>(c->h_online_pin + PIN_FLAG);
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != expect; ++spins) {
-        __builtin_ia32_pause();
+        DCE_CPU_RELAX();
         if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));         // something is wrong or very slow: fall back
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != expect)
@@ -609,11 +662,12 @@ int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pre
 {
     int rc = check_ready(c);
     if (rc) return rc;
+    DEVICE_GUARD(c);
     if (!sample) return fail(c, DCE_ERR_ARG, "dce_online_push: NULL sample");
     if (!c->d_ring) {
         HIP_TRY(c, hipMalloc(&c->d_ring, (size_t)ONLINE_ROWS * CH * sizeof(float)));
         HIP_TRY(c, hipMalloc(&c->d_online_state, sizeof(OnlineState)));
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_online_pin), PIN_FLOATS * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_online_pin), PIN_FLOATS * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));   // polled by the host while a kernel writes it: must be coherent (fine-grained), whatever the defaults / HIP_HOST_COHERENT say
         memset(c->h_online_pin, 0, PIN_FLOATS * sizeof(float));
         // constant-parameter (graph) form needs the Winograd kernels' indirect window start
         c->online_mode = (c->winograd && !getenv("DCE_ONLINE_DIRECT")) ? 1 : 0;
@@ -681,7 +735,7 @@ int dce_profile_enable(dce_ctx* c, int on)
 int dce_profile_read(dce_ctx* c, double ms[DCE_PROFILE_SLOTS], int64_t launches[DCE_PROFILE_SLOTS], int reset)
 {
     if (!c) return DCE_ERR_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
+    DEVICE_GUARD(c);
     int rc = drain_spans(c);
     if (rc) return rc;
     for (int s = 0; s < DCE_PROFILE_SLOTS; ++s) {
@@ -695,7 +749,7 @@ int dce_profile_read(dce_ctx* c, double ms[DCE_PROFILE_SLOTS], int64_t launches[
 int dce_sync(dce_ctx* c)
 {
     if (!c) return DCE_ERR_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
+    DEVICE_GUARD(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DCE_OK;
 }

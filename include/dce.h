@@ -21,7 +21,12 @@
  *   - a ctx is bound to ONE device and ONE stream and is not re-entrant.  Multi-GPU is
  *     one ctx per device (one process per GPU in this repo).
  *   - "on_device" flags say whether the caller's data pointers are device (HIP) or host
- *     pointers.  Host pointers are staged through ctx-owned pinned/device buffers.
+ *     pointers.  Host data is staged chunk by chunk (max_batch windows) through a ctx-owned ring
+ *     of three device slots on a second stream, under the neighbouring chunks' kernels; the
+ *     copies go straight from / to the caller's memory (pageable or pinned), the device
+ *     footprint is bounded by max_batch, not by n.  On ANY error return no copy into the
+ *     caller's buffers is still in flight.
+ *   - the calling thread's current HIP device is unchanged on return from every entry point.
  *   - any output pointer may be NULL to skip that output.
  *   - all launches are asynchronous on the ctx stream when on_device != 0; with host
  *     pointers the call returns after the results have landed in host memory.

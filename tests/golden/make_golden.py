@@ -9,9 +9,9 @@ What is imported from the reference (read-only, no bytecode written):
     src/contact_cnn.py        contact_cnn                       (the model)
     utils/data_handler.py     contact_dataset                   (windowing + z-score)
     src/test.py               compute_accuracy, decimal2binary  (loop, argmax, bit unpack)
-src/inference_one_seq.py cannot be imported (it needs the `lcm` module, absent offline); its
-10-line inference() loop (src/inference_one_seq.py:19-30) is the same loop as
-test.compute_accuracy minus the labels, and is exercised through the latter.
+    src/inference_one_seq.py  inference, inference_and_compute_acc, save2mat -- the module needs
+                              `lcm` (absent offline), so it is imported behind an empty stub module
+                              of that name; only save2lcm would ever touch it (loop_case, export_case)
 
 Weights/inputs come from deep_contact_estimator_amd.synth (seeded numpy streams), so tests
 regenerate them bit-identically without torch; the fixtures store checksums to prove it.
@@ -228,6 +228,42 @@ def export_case():
           sorted(k for k in out if k.startswith("save2mat_")))
 
 
+def loop_case():
+    """The reference's OWN loop functions of src/inference_one_seq.py (module imported behind a stub
+    `lcm`, which only save2lcm would touch): inference() (:19-30) and inference_and_compute_acc()
+    (:33-57) on the seq_ar1 inputs with the (T,1) labels mat2numpy_one_seq writes, at the shipped
+    batch_size 1 -- and at batch_size 30, where :54 broadcasts (B,)==(B,1) to (B,B) and the class
+    accuracy it returns is not an accuracy; that number is stored as documentation."""
+    import types
+    sys.modules.setdefault("lcm", types.ModuleType("lcm"))
+    import inference_one_seq as ref_inf
+    wseed, bias, T, sseed, kind = 2, "zero", 150 + 127, 5, "ar1"
+    sd = synth.make_state_dict(wseed, bias)
+    seq = synth.make_sequence(T, sseed, kind)
+    lab = synth.make_labels(T, sseed, two_d=True)
+    model = build_model(sd)
+    out = dict(wseed=wseed, bias=bias, T=T, sseed=sseed, kind=kind,
+               seq_checksum=checksum(seq.astype(np.float32)),
+               w_checksum=np.stack([checksum(sd[k]) for k, _ in synth.STATE_DICT_SHAPES]))
+    with tempfile.TemporaryDirectory() as d:
+        dp, lp = os.path.join(d, "data.npy"), os.path.join(d, "label.npy")
+        np.save(dp, seq)
+        np.save(lp, lab)
+        ds = contact_dataset(data_path=dp, label_path=lp, window_size=150, device="cpu")
+        for B in (1, 30):
+            res = ref_inf.inference(DataLoader(dataset=ds, batch_size=B), model, "cpu")
+            res2, acc, acc_leg = ref_inf.inference_and_compute_acc(DataLoader(dataset=ds, batch_size=B), model, "cpu")
+            assert torch.equal(res, res2) and res.dtype == torch.uint8
+            out[f"contacts_B{B}"] = res.numpy()
+            out[f"acc_B{B}"] = np.float64(acc)
+            out[f"acc_per_leg_B{B}"] = np.asarray(acc_leg, np.float64)
+        out["labels"] = lab
+    assert np.array_equal(out["contacts_B1"], out["contacts_B30"])
+    np.savez_compressed(os.path.join(HERE, "loop_one_seq.npz"), **out)
+    print(f"loop_one_seq: acc B1 {out['acc_B1']:.4f} (elementwise), B30 {out['acc_B30']:.4f} "
+          f"(the reference's (B,)==(B,1) broadcast), per-leg {out['acc_per_leg_B1']}")
+
+
 def ingest_case():
     """Reference utils/mat2numpy.py (imported with a stub `lcm`): mat2numpy_one_seq on a synthetic
     .mat and binary2decimal on all 16 bit patterns."""
@@ -263,4 +299,5 @@ if __name__ == "__main__":
     edge_cases()
     metrics_case()
     export_case()
+    loop_case()
     ingest_case()

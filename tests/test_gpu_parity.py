@@ -132,13 +132,19 @@ def test_chunking_and_determinism(models, orc):
     small = contact_cnn(device=0, max_batch=96)
     small.load_state_dict(synth.make_state_dict(1, "uniform"))
     c = small.infer_sequence(seq)
-    small.close()
     for k in ("logits", "pred", "contacts"):
         assert np.array_equal(a[k], b[k]), k
         assert np.array_equal(a[k], c[k]), k
     # streaming (fused z-score) == materialised windows through forward_windows
     w = big.zscore_windows(seq)
     d = big.predict(w)
+    # host buffers, 11 chunks through the 3-slot staging ring (slots reused 3x), twice on one ctx
+    for _ in range(2):
+        e = small.predict(w)
+        for k in ("logits", "pred", "contacts"):
+            assert np.array_equal(e[k], d[k]), k
+    assert np.array_equal(small.infer_sequence(seq)["logits"], a["logits"])
+    small.close()
     tol_ok(d["logits"], a["logits"], "materialised vs streaming")
     ref = orc.Oracle(synth.make_state_dict(1, "uniform")).infer_sequence(seq)
     tol_ok(a["logits"], ref["logits"], "1000 windows vs oracle")
@@ -546,3 +552,56 @@ def test_direct_form_conv_kernel(monkeypatch, golden, case_inputs, orc):
     rows = [r[0] for r in (direct.online_push(s) for s in seq[:200].astype(np.float32)) if r is not None]
     assert np.array_equal(np.stack(rows), b["logits"][:51])          # per-push parameters path (no indirect window start)
     wino.close(); direct.close()
+
+
+@pytest.mark.parametrize("conv", ["winograd", "direct"])
+def test_forward_windows_bench_batch(conv, monkeypatch, orc):
+    """BASELINE configs[1] exactly as bench.py runs it: the 4096 pre-normalised windows of the bench
+    step (synthetic sequence seed 2, z-scored by the library, checkpoint seed 1) through
+    dce_forward_windows -- EVERY row against the oracle, on both conv kernels."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    B = 4096
+    sd = synth.make_state_dict(1, "uniform")
+    seq = synth.make_sequence(B + 149, seed=2).astype(np.float32)
+    if conv == "direct":
+        monkeypatch.setenv("DCE_CONV", "direct")
+    m = contact_cnn(device=0, max_batch=B)
+    m.load_state_dict(sd).eval()
+    monkeypatch.delenv("DCE_CONV", raising=False)
+    w = m.zscore_windows(seq, 0, B)                       # what bench.py materialises in HBM
+    out = m.predict(w)
+    m.close()
+    ref = orc.Oracle(sd).forward_windows(w)
+    assert out["logits"].shape == (B, 16)
+    tol_ok(out["logits"], ref["logits"], f"all {B} bench rows vs oracle ({conv})")
+    flips = _argmax_contract(out["pred"], out["contacts"], ref["logits"], ref["pred"], ref["contacts"])
+    assert np.array_equal(out["contacts"], orc.decimal2binary(out["pred"]))
+    print(f"bench batch ({conv}): max |dlogit| {np.abs(out['logits'] - ref['logits']).max():.2e}, sub-margin flips {flips}")
+
+
+def test_inference_and_compute_acc_vs_reference_function(golden, case_inputs, models, tmp_path):
+    """a8 pinned on the reference's OWN inference() / inference_and_compute_acc()
+    (src/inference_one_seq.py:19-30,33-57; fixture loop_one_seq.npz) with the (T,1) labels
+    mat2numpy_one_seq writes.  At the shipped batch_size 1 everything is equal.  At batch_size 30
+    the reference's :54 compares (B,) with (B,1) -> (B,B) and returns a "class accuracy" of 1.85;
+    this implementation stays elementwise, i.e. returns the B=1 (correct) number for every B."""
+    from deep_contact_estimator_amd import synth
+    from deep_contact_estimator_amd.data_handler import contact_dataset, WindowLoader
+    from deep_contact_estimator_amd import inference as inf
+    g = golden("loop_one_seq")
+    sd, _ = case_inputs(g)
+    seq64 = synth.make_sequence(int(g["T"]), int(g["sseed"]), str(g["kind"]))
+    lab = synth.make_labels(int(g["T"]), int(g["sseed"]), two_d=True)
+    assert np.array_equal(lab, g["labels"]) and lab.ndim == 2
+    np.save(tmp_path / "d.npy", seq64); np.save(tmp_path / "l.npy", lab)
+    ds = contact_dataset(data_path=str(tmp_path / "d.npy"), label_path=str(tmp_path / "l.npy"),
+                         window_size=150, device="cuda")
+    m = models(int(g["wseed"]), str(g["bias"]))
+    for B in (1, 30):
+        res = inf.inference(WindowLoader(ds, B), m, "cuda")
+        res2, acc, leg = inf.inference_and_compute_acc(WindowLoader(ds, B), m, "cuda")
+        assert np.array_equal(res.cpu().numpy(), g[f"contacts_B{B}"])
+        assert np.array_equal(res2.cpu().numpy(), g[f"contacts_B{B}"])
+        assert np.array_equal(leg, g[f"acc_per_leg_B{B}"]) and np.array_equal(leg, g["acc_per_leg_B1"])
+        assert acc == float(g["acc_B1"])                       # elementwise for every batch size
+    assert float(g["acc_B30"]) > 1.0 and float(g["acc_B30"]) != float(g["acc_B1"])   # the reference's broadcast, documented

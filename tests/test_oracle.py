@@ -94,3 +94,18 @@ def test_torch_restatement_matches_reference(name, golden, case_inputs):
     assert np.array_equal(contacts, g["contacts"])
     logits = torch_ref.forward(tsd, torch.from_numpy(orc.zscore_windows(seq))).numpy()
     tol_ok(logits, g["logits"], "torch_ref logits")
+
+
+def test_oracle_vs_reference_loop_functions(golden, case_inputs):
+    """The contacts the reference's own inference() / inference_and_compute_acc() return
+    (src/inference_one_seq.py:19-30,33-57; fixture loop_one_seq.npz) and its accuracy numbers at
+    the shipped batch_size 1, from the oracle's argmax + the elementwise definition."""
+    from oracle import oracle
+    g = golden("loop_one_seq")
+    sd, seq = case_inputs(g)
+    out = oracle.Oracle(sd).infer_sequence(seq)
+    assert np.array_equal(out["contacts"], g["contacts_B1"]) and np.array_equal(out["contacts"], g["contacts_B30"])
+    gt = g["labels"].reshape(-1)[149:]
+    assert (out["pred"] == gt).mean() == float(g["acc_B1"])
+    assert np.array_equal((out["contacts"] == oracle.decimal2binary(gt)).mean(0), g["acc_per_leg_B1"])
+    assert float(g["acc_B30"]) > 1.0          # (B,)==(B,1) broadcast at :54 -- not an accuracy; kept as documentation
