@@ -50,7 +50,13 @@ constexpr int WINO1_MAX_N = 256;                             // <= this many win
 #define WINO_EXP 0           // bit flags for tools/micro/wino_loop.hip ablations; 0 in the product
 #endif
 #ifndef WINO_PK
-#define WINO_PK 2            // 2: input transform as two hand-written v_pk_add_f32; 1: compiler-chosen packed adds
+// Winograd input transform of one column tile (4 adds per lane):
+//   0: four plain v_add/v_sub_f32 (asm)   2: two hand-written v_pk_add_f32   1: compiler-chosen packed adds
+// Measured in the product kernel (tools/ab_bench.py, 4096 windows, 3 interleaved rounds, r2b): 0 -> 423.5 us,
+// 2 -> 436.3 us per launch.  Beside fp32 MFMAs a packed fp32 op costs more matrix-pipe issue time than the
+// two plain ops it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); the isolated
+// one-wave loop of tools/micro/wino_loop.hip had ranked them the other way round.
+#define WINO_PK 0
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -138,6 +144,15 @@ __device__ __forceinline__ V4 wino_v(const Quad r)
 #if WINO_PK == 2
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v.a) : "v"(r.p), "v"(r.q));
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(v.b) : "v"(r.p), "v"(r.q));
+#elif WINO_PK == 0
+    // four plain VALU ops, written as asm so that the SLP vectoriser cannot re-pack them
+    float v0, v3, v1, v2;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(v0) : "v"(r.p.x), "v"(r.q.x));      // d0 - d2
+    asm("v_sub_f32 %0, %1, %2" : "=v"(v3) : "v"(r.p.y), "v"(r.q.y));      // d1 - d3
+    asm("v_add_f32 %0, %1, %2" : "=v"(v1) : "v"(r.p.y), "v"(r.q.x));      // d1 + d2
+    asm("v_sub_f32 %0, %1, %2" : "=v"(v2) : "v"(r.q.x), "v"(r.p.y));      // d2 - d1
+    v.a = v2f{v0, v3};
+    v.b = v2f{v1, v2};
 #else
     v.a = r.p - r.q;
     v.b = v2f{r.q.x, r.q.x} + v2f{r.p.y, -r.p.y};

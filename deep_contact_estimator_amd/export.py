@@ -10,8 +10,12 @@ is the type's base hash rotated left by one bit.  Message bytes are pinned by go
 produced with the reference's own generated Python codecs (tests/golden/lcm_messages.npz).
 The event-log CONTAINER (liblcm's eventlog.c: sync word 0xEDA1DA01, event number, timestamp in us,
 channel length, data length, channel, data -- all big-endian) is restated from the published LCM
-log format; liblcm is not installed here, so the container is "parity unpinned" (round-trip tested
-only).  The whole log is assembled with vectorised numpy, not one Python call per message.
+log format (lcm-proj/lcm lcm/eventlog.c, identical in every release v1.0.0 - v1.5.x; the reference's
+Dockerfiles clone lcm master without a tag).  liblcm is not installed here, so the container cannot be
+pinned on liblcm's own output: it is pinned on a hand-derived golden event written out from that format
+description (tests/test_export.py::test_event_log_container_hand_derived_golden) plus a round trip --
+"parity pinned to the published format, not to liblcm".  The whole log is assembled with vectorised
+numpy, not one Python call per message.
 """
 from __future__ import annotations
 

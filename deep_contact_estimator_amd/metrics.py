@@ -25,7 +25,14 @@ def confusion16(pred, labels) -> np.ndarray:
 
 
 def _div(a, b):
+    """scikit-learn's zero_division default for precision / Jaccard: 0 when nothing to divide by."""
     return float(a) / float(b) if b else 0.0
+
+
+def _npdiv(a, b):
+    """numpy's int / int as the reference writes it (src/test.py:28,35-45): 0/0 -> nan, x/0 -> inf."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.true_divide(a, b)
 
 
 def leg_confusion(C: np.ndarray, leg: int) -> np.ndarray:
@@ -41,19 +48,19 @@ def leg_confusion(C: np.ndarray, leg: int) -> np.ndarray:
 def metrics_from_confusion16(C) -> dict:
     C = np.asarray(C, dtype=np.int64).reshape(16, 16)
     n = int(C.sum())
-    out = {"num_data": n, "acc": _div(np.trace(C), n)}
+    out = {"num_data": n, "acc": float(_npdiv(np.trace(C), n))}
     # ---- compute_confusion_mat (src/test.py:19-47), including its FN/FP naming as written there
     cm, fn, fp = {}, {}, {}
     for l, name in enumerate(LEG_NAMES):
         cm[name] = leg_confusion(C, l)
     cm["total"] = sum(cm[name] for name in LEG_NAMES)
-    cm["total_ratio"] = cm["total"] / max(int(cm["total"].sum()), 1)
+    cm["total_ratio"] = _npdiv(cm["total"], np.sum(cm["total"]))
     for name in LEG_NAMES + ("total",):
         M = cm[name]
-        fn[name] = _div(M[0, 1], M[0, 0] + M[0, 1])
-        fp[name] = _div(M[1, 0], M[1, 0] + M[1, 1])
+        fn[name] = float(_npdiv(M[0, 1], M[0, 0] + M[0, 1]))     # nan on an empty denominator, like the reference
+        fp[name] = float(_npdiv(M[1, 0], M[1, 0] + M[1, 1]))
     out.update(confusion_mat=cm, fn_rate=fn, fp_rate=fp)
-    out["acc_per_leg"] = np.array([_div(cm[name][0, 0] + cm[name][1, 1], n) for name in LEG_NAMES])
+    out["acc_per_leg"] = np.array([float(_npdiv(cm[name][0, 0] + cm[name][1, 1], n)) for name in LEG_NAMES])
     # ---- compute_precision / compute_jaccard (src/test.py:50-70)
     tp = np.diag(C).astype(np.float64)
     support = C.sum(axis=1).astype(np.float64)          # gt counts
@@ -70,3 +77,32 @@ def metrics_from_confusion16(C) -> dict:
     out["precision_of_all_legs"] = _div(T[1, 1], T[1, 1] + T[0, 1])
     out["jaccard_of_all_legs"] = _div(T[1, 1], T[1, 1] + T[0, 1] + T[1, 0])
     return out
+
+
+def report_lines(mt: dict) -> list[str]:
+    """The report of the reference's src/test.py:142-220, line for line (tools that parse the
+    reference's stdout keep working): the labelled block, then the raw-value block."""
+    cm, fn, fp = mt["confusion_mat"], mt["fn_rate"], mt["fp_rate"]
+    acc_leg = mt["acc_per_leg"]
+    L = ["Test accuracy in terms of class is: %.4f" % mt["acc"]]
+    L += ["Accuracy of leg %d is: %.4f" % (i, acc_leg[i]) for i in range(4)]
+    L += ["Accuracy is: %.4f" % (np.sum(acc_leg) / 4.0), "---------------",
+          "Precision of class is: %.4f" % mt["precision_of_class"]]
+    L += ["Precision of leg %d is: %.4f" % (i, mt["precision_of_legs"][i]) for i in range(4)]
+    L += ["Precision of all legs is: %.4f" % mt["precision_of_all_legs"], "---------------",
+          "jaccard of class is: %.4f" % mt["jaccard_of_class"]]
+    L += ["jaccard of leg %d is: %.4f" % (i, mt["jaccard_of_legs"][i]) for i in range(4)]
+    L += ["jaccard of all legs is: %.4f" % mt["jaccard_of_all_legs"], "---------------"]
+    for nm in ("rf", "lf", "rh", "lh"):
+        L += ["confusion matrix of leg %s is: " % nm, str(cm["leg_" + nm])]
+    L += ["confusion matrix sum is: ", str(cm["total"]), "confusion matrix ratio: ", str(cm["total_ratio"]), "---------------"]
+    L += ["false negative rate of leg %s is: %.4f" % (nm, fn["leg_" + nm]) for nm in ("rf", "lf", "rh", "lh")]
+    L += ["AVG false negative rate is: %.4f" % fn["total"], "---------------"]
+    L += ["false positive rate of leg %s is: %.4f" % (nm, fp["leg_" + nm]) for nm in ("rf", "lf", "rh", "lh")]
+    L += ["AVG false positive rate is: %.4f" % fp["total"], "---------------"]
+    raw = [mt["acc"], *acc_leg, np.sum(acc_leg) / 4.0, None, mt["precision_of_class"], *mt["precision_of_legs"],
+           mt["precision_of_all_legs"], None, mt["jaccard_of_class"], *mt["jaccard_of_legs"], mt["jaccard_of_all_legs"], None,
+           *[fn["leg_" + nm] for nm in ("rf", "lf", "rh", "lh")], fn["total"], None,
+           *[fp["leg_" + nm] for nm in ("rf", "lf", "rh", "lh")], fp["total"]]
+    L += ["---------------" if v is None else str(v) for v in raw]
+    return L

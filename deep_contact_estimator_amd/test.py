@@ -49,47 +49,27 @@ def main(argv=None):
     model.load_state_dict(load_checkpoint(config["model_load_path"]))
     model = model.eval().to(device)
 
+    from . import metrics
     if world > 1:
         # sharded evaluation: each rank one fused pass over its windows, one 2 KB all-reduce
-        from . import metrics
         C = confusion_sharded(lambda rows: model.infer_sequence(rows), model.confusion_counts,
                               test_data.data, test_data.label)
         mt = metrics.metrics_from_confusion16(C.cpu().numpy())
         if rank == 0:
-            _print_metrics(mt, header=True)
+            print("\n".join(metrics.report_lines(mt)))
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
         return mt
 
     test_acc, acc_per_leg, bin_pred_arr, bin_gt_arr, pred_arr, gt_arr = compute_accuracy(test_dataloader, model)
-    print("Test accuracy in terms of class is: %.4f" % test_acc)
-    for leg in range(4):
-        print("Accuracy of leg %d is: %.4f" % (leg, acc_per_leg[leg]))
-    print("Accuracy is: %.4f" % (np.sum(acc_per_leg) / 4.0))
-
-    # precision / Jaccard / confusion matrices (src/test.py:137-139) from ONE 16x16 integer matrix
-    # accumulated on the device (dce_confusion_counts) -- no sklearn, no per-window D2H
-    from . import metrics
-    C = model.confusion_counts(model.infer_sequence(test_data.data)["pred"],
-                               test_data.label[test_data.window_size - 1:])
-    mt = metrics.metrics_from_confusion16(C.cpu().numpy())
-    _print_metrics(mt)
+    # precision / Jaccard / confusion matrices / FN / FP rates (src/test.py:137-139) are closed forms of ONE
+    # 16x16 integer matrix -- built from the class ids the loop above already collected (no second pass,
+    # no scikit-learn); the multi-GPU path accumulates the same matrix on the devices (dce_confusion_counts)
+    mt = metrics.metrics_from_confusion16(metrics.confusion16(pred_arr, gt_arr))
+    mt["acc"], mt["acc_per_leg"] = test_acc, acc_per_leg           # the loop's own numbers head the report
+    print("\n".join(metrics.report_lines(mt)))
     return test_acc, acc_per_leg, bin_pred_arr, bin_gt_arr, pred_arr, gt_arr
-
-
-def _print_metrics(mt, header=False):
-    if header:                                   # the accuracy block, from the same matrix
-        print("Test accuracy in terms of class is: %.4f" % mt["acc"])
-        for leg in range(4):
-            print("Accuracy of leg %d is: %.4f" % (leg, mt["acc_per_leg"][leg]))
-        print("Accuracy is: %.4f" % (np.sum(mt["acc_per_leg"]) / 4.0))
-    print("Precision of class: %.4f, of legs: %s, of all legs: %.4f" % (
-        mt["precision_of_class"], np.round(mt["precision_of_legs"], 4).tolist(), mt["precision_of_all_legs"]))
-    print("Jaccard of class: %.4f, of legs: %s, of all legs: %.4f" % (
-        mt["jaccard_of_class"], np.round(mt["jaccard_of_legs"], 4).tolist(), mt["jaccard_of_all_legs"]))
-    print("Confusion matrix (all legs):\n", mt["confusion_mat"]["total"])
-    print("False negative rate: %s\nFalse positive rate: %s" % (mt["fn_rate"], mt["fp_rate"]))
 
 
 if __name__ == "__main__":

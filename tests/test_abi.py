@@ -105,3 +105,18 @@ def test_metrics_from_confusion_match_reference_sklearn(golden):
         np.testing.assert_allclose(got_j, g[f"{tag}_jaccard"], rtol=1e-12)
         acc = (g["pred"] == g[f"{tag}_labels"]).mean()
         assert abs(m["acc"] - acc) < 1e-15
+        # the printed report has the reference's line structure (src/test.py:142-220): 46 labelled lines
+        # (6 of them matrices), then 32 raw lines
+        rep = metrics.report_lines(m)
+        assert rep[0] == "Test accuracy in terms of class is: %.4f" % acc
+        assert rep[7] == "Precision of class is: %.4f" % g[f"{tag}_precision"][0]
+        assert rep[14] == "jaccard of class is: %.4f" % g[f"{tag}_jaccard"][0]
+        assert rep[21] == "confusion matrix of leg rf is: " and rep[22] == str(g[f"{tag}_cm"][0])
+        assert "AVG false negative rate is: %.4f" % g[f"{tag}_fn"][4] in rep and "AVG false positive rate is: %.4f" % g[f"{tag}_fp"][4] in rep
+        raw = rep[46:]
+        assert len(rep) == 78 and len(raw) == 32 and raw.count("---------------") == 4 and float(raw[0]) == m["acc"] and float(raw[-1]) == m["fp_rate"]["total"]
+    # empty denominators: numpy's nan where the reference divides integers, scikit-learn's 0 for precision / Jaccard
+    C = np.zeros((16, 16), np.int64); C[0, 0] = 5                     # every leg always 0 in gt and pred
+    m = metrics.metrics_from_confusion16(C)
+    assert m["fn_rate"]["leg_rf"] == 0.0 and np.isnan(m["fp_rate"]["leg_rf"]) and m["precision_of_legs"][0] == 0.0
+    assert np.isnan(metrics.metrics_from_confusion16(np.zeros((16, 16), np.int64))["acc"])

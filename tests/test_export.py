@@ -41,6 +41,44 @@ def test_vectorised_log_equals_per_message_encoding(golden):
             assert (num, t, c) == (3 * i + k, ts, chan) and d == data.tobytes()
 
 
+def test_event_log_container_hand_derived_golden():
+    """The event-log container, pinned to a byte string written out BY HAND from the published LCM log
+    format (lcm-proj/lcm, lcm/eventlog.c: lcm_eventlog_write_event writes, big-endian, the int32 sync
+    word 0xEDA1DA01, int64 event number, int64 timestamp [us], int32 channel length, int32 data
+    length, the channel name without a terminator, the data -- unchanged from v1.0.0 through v1.5.x;
+    the reference's Dockerfiles clone lcm master untagged: docker/cuda11_1/Dockerfile:23).  liblcm
+    itself is not in this image, so this is the strongest pin available offline; EventLog.write_event
+    numbers events 0,1,2,... in write order (the log's own counter), which build_log reproduces."""
+    golden_event = bytes.fromhex(
+        "eda1da01"                  # sync word
+        "0000000000000007"          # event number 7
+        "0005af3107a5e240"          # timestamp 1600000000123456 us
+        "00000007"                  # channel length
+        "00000015"                  # data length 21 = 8 fingerprint + 13 body
+        "636f6e74616374"            # "contact"
+        "25c625be5e3a8dec"          # contact_t fingerprint: 0x12e312df2f1d46f6 rotated left by one
+        "04"                        # int8 num_legs
+        "4029000000000000"          # double timestamp 12.5
+        "01000001")                 # int8 contact[4]
+    data = export.encode_contact_t(4, 12.5, [1, 0, 0, 1])
+    assert data == golden_event[35:]
+    assert export.read_log(golden_event) == [(7, 1600000000123456, "contact", data)]
+    # build_log's rows: event k of sample i carries number 3*i + k, sync/lengths/channel exactly as above
+    z = lambda k: np.zeros((3, k))
+    blob = export.build_log(1600000000000000, np.array([0.0, 0.123456, 12.5]), z(12), z(12), z(12), z(12), z(12),
+                            np.array([[1, 0, 0, 1]] * 3), z(3), z(3), z(3), z(4))
+    ev = export.read_log(blob)
+    assert [e[0] for e in ev] == list(range(9)) and [e[2] for e in ev] == ["leg_control_data", "contact", "microstrain"] * 3
+    row = len(blob) // 3
+    second = blob[row:2 * row]                         # sample 1: its 'contact' event sits after the leg event
+    leg_len = 28 + len("leg_control_data") + 8 + 240
+    got = second[leg_len:leg_len + 28 + 7 + 21]
+    want = bytearray(golden_event)
+    want[4:12] = (4).to_bytes(8, "big")                # event number 3*1 + 1
+    want[44:52] = export.encode_contact_t(4, 0.123456, [1, 0, 0, 1])[9:17]    # the message body's own double timestamp
+    assert got == bytes(want)
+
+
 def test_save2mat_and_save2lcm_match_reference(golden, tmp_path):
     sio = pytest.importorskip("scipy.io")
     g = golden("lcm_messages")
