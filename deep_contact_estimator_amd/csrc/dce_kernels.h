@@ -61,6 +61,13 @@ hipError_t launch_fc_gemv(const float* A, const float* W, const float* bias, flo
 hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int out_bf16,
                                int64_t M, int N, int K, int relu, hipStream_t st);
 
+// fc.0 of the bf16-FC mode at chip-filling sizes: 256x128 tiles, LDS-DMA staging, two wave groups one phase
+// apart (fc_gemm_bf16.hip).  launch_fc_gemm_bf16 dispatches to it when fc_gemm_bf16_phased_ok(M, N, K).
+hipError_t init_fc_gemm_bf16();
+bool       fc_gemm_bf16_phased_ok(int64_t M, int N, int K);
+hipError_t launch_fc_gemm_bf16_phased(const void* A, const void* W, const float* bias, void* C, int out_bf16,
+                                      int64_t M, int N, int K, int relu, hipStream_t st);
+
 // logits = h2 * W3^T + b3 ; argmax (first max, NaN-first) ; 4-bit unpack (MSB = leg 0)
 // done_flag (optional, single-block launches only): a system-scope release store of done_seq after the
 // outputs, for a host that polls instead of synchronising the stream (online mode).

@@ -20,6 +20,7 @@
 //    and the 4-bit unpack, MSB = leg 0.
 #include "dce_kernels.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace dce {
 
@@ -370,6 +371,7 @@ hipError_t init_fc_gemm()
     if ((e = grant_lds<2, 2, true, true>()) != hipSuccess) return e;
     if ((e = grant_lds<2, 2, true, false>()) != hipSuccess) return e;
     if ((e = grant_lds<1, 1, true, true>()) != hipSuccess) return e;
+    if ((e = init_fc_gemm_bf16()) != hipSuccess) return e;
     return grant_lds<1, 1, true, false>();
 }
 
@@ -419,6 +421,8 @@ hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, 
 {
     if (M <= 0) return hipSuccess;
     if (N % 128 || K % 64 || M > (1 << 30)) return hipErrorInvalidValue;
+    static const bool phased = !(getenv("DCE_BF16_GEMM") && strcmp(getenv("DCE_BF16_GEMM"), "tile128") == 0);   // A/B switch
+    if (phased && fc_gemm_bf16_phased_ok(M, N, K)) return launch_fc_gemm_bf16_phased(A, W, bias, C, out_bf16, M, N, K, relu, st);
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
     if (big_blocks >= 384)
         return out_bf16 ? launch_gemm_cfg<2, 2, true, true>(A, W, bias, C, M, N, K, relu, st)

@@ -42,7 +42,10 @@ def test_entry_scripts_on_synthetic_config(tmp_path):
     r = subprocess.run([sys.executable, "-m", "deep_contact_estimator_amd.test", "--config_name", str(tpath)],
                        env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "Test accuracy in terms of class is:" in r.stdout and "Jaccard of class:" in r.stdout
+    lines = r.stdout.splitlines()
+    assert "Test accuracy in terms of class is:" in r.stdout and "jaccard of class is:" in r.stdout
+    i0 = next(k for k, l in enumerate(lines) if l.startswith("Test accuracy in terms of class is:"))
+    assert len(lines) - i0 == 78 + 6                       # the reference's report: 46 labelled lines (6 matrices of 2 rows), 32 raw
 
 
 def test_entry_scripts_sharded_over_two_processes(tmp_path):
