@@ -57,6 +57,8 @@ struct dce_ctx {
     const void *fc1w_bf16 = nullptr, *fc2w_bf16 = nullptr;   // DCE_BF16_FC only
 
     float *feat = nullptr, *h1 = nullptr, *h2 = nullptr;   // scratch, max_batch rows each
+    float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
+    bool want_h2 = false;                                  // dce_forward_taps: the fused epilogue also writes h2
 
     // staging for host-pointer callers: a ring of RING_SLOTS chunk-sized slots (run_all), so that
     // the device footprint is bounded by max_batch, not by the length of the caller's input
@@ -181,6 +183,15 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
         auto fc = (c->gemv && n <= FC_GEMV_MAX_M) ? launch_fc_gemv : launch_fc_gemm;
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
+        if (fc23_fused_ok(n)) {
+            // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU
+            // unless a tap asks for it); one small kernel adds them up.  Same summation tree as the tail kernel.
+            { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, c->part, c->max_batch,
+                                                          c->want_h2 ? c->h2 : nullptr, n, c->stream)); }
+            { Timer t(c, 3); HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, n, logits, pred, contacts, c->stream)); }
+            if (c->spans.size() > 4096) return drain_spans(c);
+            return DCE_OK;
+        }
         { Timer t(c, 2); HIP_TRY(c, fc(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
     }
     { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream, c->done_flag, c->done_seq, c->seq_counter_dev)); }
@@ -348,6 +359,7 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     CREATE_TRY(hipMalloc(&c->feat, (size_t)max_batch * FEAT * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h1, (size_t)max_batch * FC1 * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h2, (size_t)max_batch * FC2 * sizeof(float)));
+    CREATE_TRY(hipMalloc(&c->part, (size_t)max_batch * 8 * NCLS * sizeof(float)));
 #undef CREATE_TRY
     *out = c;
     return DCE_OK;
@@ -364,7 +376,7 @@ void dce_destroy(dce_ctx* c)
     if (c->xstream_ev) hipEventDestroy(c->xstream_ev);
     if (c->xfer_stream) { hipStreamSynchronize(c->xfer_stream); hipStreamDestroy(c->xfer_stream); }
     for (auto& slot : c->ring_ev) for (auto e : slot) if (e) hipEventDestroy(e);
-    hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2);
+    hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2); hipFree(c->part);
     hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts);
     if (c->online_exec) hipGraphExecDestroy(c->online_exec);
     if (c->online_graph) hipGraphDestroy(c->online_graph);
@@ -540,7 +552,9 @@ int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
         HIP_TRY(c, hipMemcpyAsync(c->d_in, windows, (size_t)n * WIN * CH * sizeof(float), hipMemcpyHostToDevice, c->stream));
         dsrc = c->d_in; dl = c->d_logits;
     }
+    c->want_h2 = h2 != nullptr;
     rc = run_chunk(c, dsrc, 0, n, dl, nullptr, nullptr);
+    c->want_h2 = false;
     if (rc) return rc;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (feat) HIP_TRY(c, hipMemcpyAsync(feat, c->feat, (size_t)n * FEAT * sizeof(float), kind, c->stream));

@@ -61,14 +61,24 @@ hipError_t launch_fc_gemv(const float* A, const float* W, const float* bias, flo
 hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int out_bf16,
                                int64_t M, int N, int K, int relu, hipStream_t st);
 
-// fc.0 of the bf16-FC mode at chip-filling sizes: 256x128 tiles, LDS-DMA staging, two wave groups one phase
-// apart (fc_gemm_bf16.hip).  launch_fc_gemm_bf16 dispatches to it when fc_gemm_bf16_phased_ok(M, N, K).
-hipError_t init_fc_gemm_bf16();
-bool       fc_gemm_bf16_phased_ok(int64_t M, int N, int K);
-hipError_t launch_fc_gemm_bf16_phased(const void* A, const void* W, const float* bias, void* C, int out_bf16,
-                                      int64_t M, int N, int K, int relu, hipStream_t st);
+// The same GEMMs at chip-filling sizes (fc_gemm_phased.hip): one workgroup per CU, 256x128 or 128x64 tiles,
+// LDS-DMA staging, two wave groups one phase apart; fp32 (bit-identical to the tile kernels: same K order) and
+// bf16.  launch_fc_gemm / launch_fc_gemm_bf16 dispatch here when fc_gemm_phased_ok(M, N, K, bf16).
+hipError_t init_fc_gemm_phased();
+bool       fc_gemm_phased_ok(int64_t M, int N, int K, int bf16);
+hipError_t launch_fc_gemm_phased(const void* A, const void* W, const float* bias, void* C, int bf16, int out_bf16,
+                                 int64_t M, int N, int K, int relu, hipStream_t st);
 
-// logits = h2 * W3^T + b3 ; argmax (first max, NaN-first) ; 4-bit unpack (MSB = leg 0)
+// fc.3 (+ReLU) with fc.6's chunk sums finished in the GEMM epilogue (fp32, chip-filling batches; fc6_chain.h):
+// A = h1 (M,2048), W2 (512,2048), b2; part: [8][part_rows][16] chunk sums out; h2_out: NULL, or (M,512) for taps.
+bool       fc23_fused_ok(int64_t M);
+hipError_t launch_fc23_fused(const float* h1, const float* W2, const float* b2, const float* W3,
+                             float* part, int64_t part_rows, float* h2_out, int64_t M, hipStream_t st);
+// ... and the combine behind it: logits = ordered sum of the 8 chunk sums + b3, argmax, contact bits
+hipError_t launch_fc6_combine(const float* part, int64_t part_rows, const float* b3, int64_t n,
+                              float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st);
+
+// logits = h2 * W3^T + b3 (same summation tree, fc6_chain.h) ; argmax (first max, NaN-first) ; 4-bit unpack (MSB = leg 0)
 // done_flag (optional, single-block launches only): a system-scope release store of done_seq after the
 // outputs, for a host that polls instead of synchronising the stream (online mode).
 //   seq_counter (optional, device memory, with done_flag): publish ++*seq_counter instead of done_seq.

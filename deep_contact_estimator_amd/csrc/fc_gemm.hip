@@ -15,10 +15,13 @@
 //  * blockIdx -> tile map is XCD-aware: the 64 blocks co-resident on one XCD (32 CUs x 2) form
 //    an 8x8 (or 16x4) super-tile, so each A row-panel and W column-panel is fetched into that
 //    XCD's L2 once per 8 (4) consumers.
-//  * fc3_tail_kernel: 16 lanes per window, one class each (K=512 sequential fmaf from LDS-resident
-//    W3), then argmax with torch.max semantics (first maximum; a NaN wins, first NaN first)
-//    and the 4-bit unpack, MSB = leg 0.
+//  * fc3_tail_kernel: fc.6 as the fixed summation tree of fc6_chain.h (8 chunk chains on
+//    v_mfma_f32_16x16x4_f32, combined in order) over h2 rows staged in LDS, then argmax with torch.max
+//    semantics (first maximum; a NaN wins, first NaN first) and the 4-bit unpack, MSB = leg 0.
+//    Chip-filling fp32 batches never come here: their fc.3 GEMM finishes the chunk chains in its
+//    epilogue (fc_gemm_phased.hip) and fc6_combine_kernel adds them up.
 #include "dce_kernels.h"
+#include "fc6_chain.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -354,8 +357,9 @@ static hipError_t grant_lds()
 }
 
 constexpr int TAIL_WINDOWS = 16;       // fc3_tail_kernel: windows per 256-thread block (16 lanes per window)
-constexpr int TAIL_W3_FLOATS = NCLS * (FC2 + 1), TAIL_H2_LD = FC2 + 4;
-constexpr int TAIL_LDS_BYTES = (TAIL_W3_FLOATS + TAIL_WINDOWS * TAIL_H2_LD + TAIL_WINDOWS * NCLS) * (int)sizeof(float);
+constexpr int TAIL_H2_LD = FC2 + 4;     // 516 floats: the 16 rows of a ds_read_b128 start 4 banks apart
+constexpr int TAIL_PART_FLOATS = FC6_NCHUNK * TAIL_WINDOWS * NCLS;
+constexpr int TAIL_LDS_BYTES = (TAIL_WINDOWS * TAIL_H2_LD + TAIL_PART_FLOATS + TAIL_WINDOWS * NCLS) * (int)sizeof(float);
 __global__ void fc3_tail_kernel(const float*, const float*, const float*, int64_t, float*, int32_t*, uint8_t*,
                                 unsigned*, unsigned, unsigned*);
 
@@ -371,7 +375,7 @@ hipError_t init_fc_gemm()
     if ((e = grant_lds<2, 2, true, true>()) != hipSuccess) return e;
     if ((e = grant_lds<2, 2, true, false>()) != hipSuccess) return e;
     if ((e = grant_lds<1, 1, true, true>()) != hipSuccess) return e;
-    if ((e = init_fc_gemm_bf16()) != hipSuccess) return e;
+    if ((e = init_fc_gemm_phased()) != hipSuccess) return e;
     return grant_lds<1, 1, true, false>();
 }
 
@@ -396,6 +400,8 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
 {
     if (M <= 0) return hipSuccess;
     if (N % 128 || K % 32 || M > (1 << 30)) return hipErrorInvalidValue;
+    // chip-filling sizes: one phased workgroup per CU (fc_gemm_phased.hip); same K order, same bits
+    if (fc_gemm_phased_ok(M, N, K, 0)) return launch_fc_gemm_phased(A, W, bias, C, 0, 0, M, N, K, relu, st);
     // 128x128 tiles when they alone fill the chip (512 resident blocks), else 64x64
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
     if (big_blocks >= 384) return launch_gemm_cfg<2, 2, false, false>(A, W, bias, C, M, N, K, relu, st);
@@ -421,8 +427,7 @@ hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, 
 {
     if (M <= 0) return hipSuccess;
     if (N % 128 || K % 64 || M > (1 << 30)) return hipErrorInvalidValue;
-    static const bool phased = !(getenv("DCE_BF16_GEMM") && strcmp(getenv("DCE_BF16_GEMM"), "tile128") == 0);   // A/B switch
-    if (phased && fc_gemm_bf16_phased_ok(M, N, K)) return launch_fc_gemm_bf16_phased(A, W, bias, C, out_bf16, M, N, K, relu, st);
+    if (fc_gemm_phased_ok(M, N, K, 1)) return launch_fc_gemm_phased(A, W, bias, C, 1, out_bf16, M, N, K, relu, st);
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
     if (big_blocks >= 384)
         return out_bf16 ? launch_gemm_cfg<2, 2, true, true>(A, W, bias, C, M, N, K, relu, st)
@@ -441,32 +446,23 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                      int32_t* __restrict__ pred, uint8_t* __restrict__ contacts,
                      unsigned* __restrict__ done_flag, unsigned done_seq, unsigned* __restrict__ seq_counter)
 {
-    // dynamic LDS (66.9 KB): W3 [class][513] | the 16 h2 rows of the current window tile [16][516] | logits [16][16]
-    // (row strides 513 / 516 floats: the per-class W3 reads and the per-window h2 reads are bank-conflict free)
+    // dynamic LDS (43 KB): the 16 h2 rows of the current window tile [16][516] | chunk sums [8][16][16] | logits [16][16]
     extern __shared__ __attribute__((aligned(16))) float tsm[];
-    float* w3s = tsm;
-    float* h2s = tsm + TAIL_W3_FLOATS;
-    float (*lg)[NCLS] = reinterpret_cast<float (*)[NCLS]>(tsm + TAIL_W3_FLOATS + TAIL_WINDOWS * TAIL_H2_LD);
-    const int tid = threadIdx.x;
-    {   // W3 (32 KB) -> LDS: 8 x 16-byte loads per thread, all issued before the first store
-        const float4* W4 = reinterpret_cast<const float4*>(W3);
-        float4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = W4[tid + 256 * i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e4 = tid + 256 * i, cls = e4 / (FC2 / 4), k = 4 * (e4 % (FC2 / 4));
-            float* d = w3s + cls * (FC2 + 1) + k;
-            d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
-        }
-    }
+    float* h2s = tsm;
+    float* part = tsm + TAIL_WINDOWS * TAIL_H2_LD;
+    float (*lg)[NCLS] = reinterpret_cast<float (*)[NCLS]>(part + TAIL_PART_FLOATS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // wave w owns chunks 2w and 2w+1 of every window tile; its W3 operands stay in registers (L2-resident 32 KB)
+    float4 bw[2][4];
+    fc6_load_w3(W3, 2 * wv, lane, bw[0]);
+    fc6_load_w3(W3, 2 * wv + 1, lane, bw[1]);
     const int cls = tid & 15, wl = tid >> 4;
     const float bv = b3[cls];
     for (int64_t base = (int64_t)blockIdx.x * TAIL_WINDOWS; base < n;
          base += (int64_t)gridDim.x * TAIL_WINDOWS) {
-        __syncthreads();                                 // lg / h2s free again
-        {   // the tile's 16 h2 rows -> LDS, coalesced, 8 loads in flight per thread.  (Read from global
-            // inside the chain below they were 32 dependent L2 round trips: 12 of 12.6 us at n = 1.)
+        __syncthreads();                                 // lg / part / h2s free again
+        {   // the tile's 16 h2 rows -> LDS, coalesced, 8 loads in flight per thread
             float4 v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -480,32 +476,25 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                 *reinterpret_cast<float4*>(h2s + (e4 / (FC2 / 4)) * TAIL_H2_LD + 4 * (e4 % (FC2 / 4))) = v[i];
             }
         }
-        __syncthreads();                                 // w3s and h2s ready
-        const int64_t win = base + wl;
-        const float4* hp = reinterpret_cast<const float4*>(h2s + wl * TAIL_H2_LD);   // broadcast to the window's 16 lanes
-        float acc = 0.f;
-#pragma unroll 8
-        for (int k4 = 0; k4 < FC2 / 4; ++k4) {
-            const float4 hv = hp[k4];
-            const float* wp = w3s + cls * (FC2 + 1) + 4 * k4;
-            acc = fmaf(hv.x, wp[0], acc);
-            acc = fmaf(hv.y, wp[1], acc);
-            acc = fmaf(hv.z, wp[2], acc);
-            acc = fmaf(hv.w, wp[3], acc);
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {                 // chunk sums p_c of the 16 windows x 16 classes
+            const int c = 2 * wv + cc;
+            const fc6_f32x4 acc = fc6_chunk_mfma(h2s, TAIL_H2_LD, c * FC6_CHUNK, lane, bw[cc]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(c * TAIL_WINDOWS + 4 * (lane >> 4) + r) * NCLS + (lane & 15)] = acc[r];
         }
-        acc += bv;
+        __syncthreads();
+        const int64_t win = base + wl;
+        float p[FC6_NCHUNK];
+#pragma unroll
+        for (int c = 0; c < FC6_NCHUNK; ++c) p[c] = part[(c * TAIL_WINDOWS + wl) * NCLS + cls];
+        const float acc = fc6_combine(p, bv);
         lg[wl][cls] = acc;
         if (win < n && logits) logits[win * NCLS + cls] = acc;
         __syncthreads();
         if (tid < TAIL_WINDOWS && base + tid < n) {
-            const float* l = lg[tid];
-            int best = 0;
-            bool nan_seen = false;
-            for (int k = 0; k < NCLS; ++k)               // torch.max: a NaN wins, the first one first
-                if (!nan_seen && l[k] != l[k]) { best = k; nan_seen = true; }
-            if (!nan_seen)
-                for (int k = 1; k < NCLS; ++k)
-                    if (l[k] > l[best]) best = k;        // strict >: ties -> lowest index
+            const int best = fc6_argmax16(lg[tid]);
             if (pred) pred[base + tid] = best;
             if (contacts) {
                 uchar4 c;
@@ -524,6 +513,46 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
             __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The last step behind the fused fc.3 + fc.6-chunk GEMM epilogue (fc_gemm_phased.hip): add the 8 chunk sums
+// of every (window, class) in the fixed order, + bias -> logits, argmax, contact bits.
+//   part: [8 chunks][part_rows][16] floats
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void fc6_combine_kernel(const float* __restrict__ part, int64_t part_rows, const float* __restrict__ b3, int64_t n,
+                        float* __restrict__ logits, int32_t* __restrict__ pred, uint8_t* __restrict__ contacts)
+{
+    __shared__ float lg[16][NCLS];
+    const int tid = threadIdx.x, cls = tid & 15, wl = tid >> 4;
+    const int64_t base = (int64_t)blockIdx.x * 16, win = base + wl;
+    const int64_t row = win < n ? win : n - 1;
+    float p[FC6_NCHUNK];
+#pragma unroll
+    for (int c = 0; c < FC6_NCHUNK; ++c) p[c] = part[(c * part_rows + row) * NCLS + cls];
+    const float v = fc6_combine(p, b3[cls]);
+    lg[wl][cls] = v;
+    if (win < n && logits) logits[win * NCLS + cls] = v;
+    __syncthreads();
+    if (tid < 16 && base + tid < n) {
+        const int best = fc6_argmax16(lg[tid]);
+        if (pred) pred[base + tid] = best;
+        if (contacts) {
+            uchar4 c;
+            c.x = (best >> 3) & 1; c.y = (best >> 2) & 1; c.z = (best >> 1) & 1; c.w = best & 1;
+            *reinterpret_cast<uchar4*>(contacts + (base + tid) * 4) = c;
+        }
+    }
+}
+
+hipError_t launch_fc6_combine(const float* part, int64_t part_rows, const float* b3, int64_t n,
+                              float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fc6_combine_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st,
+                       part, part_rows, b3, n, logits, pred, contacts);
+    return hipGetLastError();
 }
 
 hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,

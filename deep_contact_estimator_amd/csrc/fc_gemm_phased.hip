@@ -1,0 +1,383 @@
+// fc_gemm_phased.hip -- the FC-layer GEMMs at chip-filling sizes on gfx950, fp32 and bf16:
+//     C[M,N] = act(A[M,K] W[N,K]^T + bias),  A, W K-contiguous (PyTorch's [out][in]),  fp32 accumulate
+// (reference src/contact_cnn.py:48-54: fc.0 + ReLU, fc.3 + ReLU).
+//   fp32: v_mfma_f32_32x32x2_f32, K walked exactly as fc_gemm.hip / fc_gemv.hip walk it (inside every 8
+//         consecutive k: 0,4,1,5,2,6,3,7) -> the same bits as those kernels;
+//   bf16: v_mfma_f32_32x32x16_bf16 (DCE_BF16_FC, BASELINE configs[4]).
+//
+// Structure: ONE workgroup per CU, 8 waves = two groups of four.  Waves w and w+4 share a SIMD and sit
+// in different groups; the groups run ONE PHASE APART:
+//     phase p   : group 0  math(tile t)   | group 1  load(tile t)      -- workgroup barrier --
+//     phase p+1 : group 0  load(tile t+1) | group 1  math(tile t)      -- workgroup barrier --
+// "load" = read this wave's fragments of one K-tile from LDS into registers and issue its share of the
+// global->LDS loads of tile t+2; "math" = nothing but the tile's MFMAs.  Every SIMD's matrix pipe always has
+// one wave in its math phase, and a barrier costs it one hand-over instead of a stall of the whole block
+// (the tile kernel of fc_gemm.hip leaves two unrelated blocks per CU to cover each other's barriers by
+// chance: 0.87 of the fp32 peak on fc.0; this one is built so that the cover is there by construction).
+//   * operands go global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave-instruction): no staging
+//     VGPRs, no ds_write pass; three LDS buffers, loads run two K-tiles ahead of the math;
+//   * bf16 needs the large tile for another reason: at bf16 rate a 128x128 tile moves 64 B/clk/CU out of
+//     L2 and through ds_write_b128 (79 B/clk/CU); 256x128 per CU asks for 47 B/clk.
+// LDS image: a K-tile is (BM + BN) rows x 128 or 256 B of K; LDS-DMA writes lane-linear (1 KB = 8 or 4 rows
+// per wave-instruction), so the bank swizzle lives in the per-lane GLOBAL address: 16-byte column c of row r
+// is stored at slot c ^ swz(r) (PhCfg::swz); the fragment reads (lane = row, fixed logical column) apply the
+// same XOR and are conflict-free for ds_read_b128's 16-lane groups.
+#include "dce_kernels.h"
+#include "fc6_chain.h"
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+namespace dce {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int PH_NBUF = 3;
+
+// wave tile (32 TM) x (32 TN), waves 4 (M) x 2 (N); ROWB = bytes of K per row per K-tile (128 or 256)
+template <int TM, int TN, int ROWB> struct PhCfg {
+    static constexpr int BM = 4 * 32 * TM, BN = 2 * 32 * TN, ROWS = BM + BN;
+    static constexpr int TILE = ROWS * ROWB, LDS = PH_NBUF * TILE;
+    static constexpr int SLOTS = ROWB / 16, CROWS = 64 / SLOTS;    // 16-byte slots per row; rows per 1 KB chunk
+    static constexpr int NA = BM / CROWS / 8, NW = BN / CROWS / 8; // 1 KB chunks per wave per K-tile: of A, of W
+    static constexpr int KQ = ROWB / 32;                           // 32-byte column pairs (fragment loads per row per tile)
+    static_assert(ROWB == 128 || ROWB == 256, "");
+    static_assert((NA == 4 && NW == 2) || (NA == 2 && NW == 1), "issue_tile is written for 4+2 and 2+1 chunks");
+    static_assert(LDS <= 160 * 1024, "three K-tiles in LDS");
+    // bank swizzle: 16-byte column c of row r is stored at slot c ^ swz(r); conflict-free for ds_read_b128's
+    // lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (lane = row): 8 slots need (r>>1)&7, 16 slots r&15
+    __device__ static constexpr int swz(int r) { return SLOTS == 8 ? (r >> 1) & 7 : r & 15; }
+};
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f)
+{   // round-to-nearest-even; NaN stays NaN (quiet)
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// The 1 KB chunks this wave brings in per K-tile: chunk j lands at lds0 + j*8 KB (+ lane*16); the first NA
+// come from the A panel (wave-uniform base sA), the rest from the W panel (sW); v[j] = per-lane byte offsets.
+// M0 carries the LDS destination; it is compiler-reserved, so it is saved and restored inside the statement.
+#define PH_GLDS(vreg, sreg) "global_load_lds_dwordx4 " vreg ", " sreg "\n\t"
+#define PH_NEXT "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+template <int NA, int NW>
+__device__ __forceinline__ void issue_tile(unsigned lds0, const char* sA, const char* sW, const unsigned (&v)[NA + NW])
+{
+    unsigned keep;
+    if constexpr (NA == 4) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     PH_GLDS("%4", "%2") PH_NEXT PH_GLDS("%5", "%2") PH_NEXT PH_GLDS("%6", "%2") PH_NEXT PH_GLDS("%7", "%2") PH_NEXT
+                     PH_GLDS("%8", "%3") PH_NEXT PH_GLDS("%9", "%3")
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(lds0), "s"(sA), "s"(sW), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5])
+                     : "memory");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     PH_GLDS("%4", "%2") PH_NEXT PH_GLDS("%5", "%2") PH_NEXT PH_GLDS("%6", "%3")
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(lds0), "s"(sA), "s"(sW), "v"(v[0]), "v"(v[1]), "v"(v[2])
+                     : "memory");
+    }
+}
+#undef PH_GLDS
+#undef PH_NEXT
+
+// End of a phase: this wave's LDS-DMA of all but the newest tile has landed (each wave issues NG pieces per
+// tile, so "at most NG outstanding" = everything older is in LDS), its own fragment reads have returned (so
+// the buffer they came from may be refilled after the barrier), then the workgroup barrier.
+template <int NG> __device__ __forceinline__ void phase_end(bool more)
+{
+    static_assert(NG == 6 || NG == 3, "");
+    if (more) {
+        if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else                   asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+// 32-bit LDS byte address of a __shared__ object (what M0 takes for LDS-DMA)
+__device__ __forceinline__ unsigned lds_addr(const void* p)
+{
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
+}
+
+}  // namespace
+
+// FUSE6 (fp32, 128 x 64 tile, N = 512: fc.3): the block's 64 output columns are exactly one chunk of fc.6's
+// summation tree (fc6_chain.h), so the epilogue finishes that chunk -- h2 tile -> LDS -> 16 MFMAs per 16 rows
+// -> chunk sums to `part` ([8][part_rows][16]) -- and h2 itself goes to HBM only when Cv != NULL (taps).
+template <bool BF16, bool OUT_BF16, int TM, int TN, int ROWB, bool FUSE6 = false>
+__global__ __launch_bounds__(512, 2)
+void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
+                           const float* __restrict__ bias, void* __restrict__ Cv,
+                           int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2,
+                           const float* __restrict__ W3 = nullptr, float* __restrict__ part = nullptr, long long part_rows = 0)
+{
+    static_assert(!FUSE6 || (!BF16 && !OUT_BF16 && TM == 1 && TN == 1), "the fused fc.6 epilogue is fc.3's fp32 128x64 tile");
+    using Cfg = PhCfg<TM, TN, ROWB>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NG = Cfg::NA + Cfg::NW, KQ = Cfg::KQ;
+    constexpr int ES = BF16 ? 2 : 4;                     // operand element size
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // ---- XCD-aware tile assignment (speed only): the 32 blocks co-resident on one XCD form an sm x sn super-tile
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, li = bid >> 3;
+    const int sid = (li >> 5) * 8 + xcd;
+    const int within = li & 31;
+    const int sn = 1 << sn_log2, sm = 32 >> sn_log2;
+    const int nsn = ntiles >> sn_log2;
+    const int tm = (sid / nsn) * sm + (within >> sn_log2);
+    const int tn = (sid % nsn) * sn + (within & (sn - 1));
+    if (tm >= mtiles) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2;                            // phase group; waves w and w+4 share a SIMD
+    const int wm = (wid & 3) * 32 * TM, wn = grp * 32 * TN;   // this wave's corner of the block tile
+    const int i = lane & 31, h = lane >> 5;
+
+    // ---- global -> LDS: chunk c = wid + 8 j of the stacked tile; chunks [0, BM/8) are A rows, then W rows
+    const size_t rowb = (size_t)K * ES;
+    unsigned voff[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int c = wid + 8 * j;
+        const int r = Cfg::CROWS * c + lane / Cfg::SLOTS;   // row of the stacked tile
+        const int slot = lane % Cfg::SLOTS;              // 16-byte slot this lane fills
+        const int col = slot ^ Cfg::swz(r);              // logical 16-byte column that lives there
+        int grow = j < Cfg::NA ? r : r - BM;             // row inside the A / W panel
+        if (j < Cfg::NA && m0 + grow >= M) grow = M - 1 - m0;   // rows past M re-read the last one (never stored)
+        voff[j] = (unsigned)(grow * rowb + 16 * col);
+    }
+    const char* sA = static_cast<const char*>(Av) + (size_t)m0 * rowb;
+    const char* sW = static_cast<const char*>(Wv) + (size_t)n0 * rowb;
+    const unsigned lds_wave = lds_addr(smem) + wid * 1024;     // chunk `wid` of buffer 0
+
+    // ---- fragment reads: lane (i, h) reads row (wave corner + 32 a + i), logical 16-byte column 2 kq + h
+    //      fp32: k = 8 kq + 4 h + (0..3) -> four K=2 MFMAs;   bf16: k = 16 kq + 8 h + (0..7) -> one K=16 MFMA
+    const int sw = Cfg::swz(i);                          // wave corners are multiples of 32 rows: swz(row) = swz(i)
+    int fo[KQ];
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) fo[kq] = 16 * ((2 * kq + h) ^ sw);
+    const int arow = (wm + i) * ROWB, brow = (BM + wn + i) * ROWB;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 bw6[4];                                       // FUSE6: this lane's W3 operands of the block's chunk (= column tile tn)
+    if constexpr (FUSE6) fc6_load_w3(W3, tn, lane, bw6);
+
+    const int KT = (int)(rowb / ROWB);                   // >= 3 (checked by the launcher)
+    // prologue: tiles 0 and 1 in flight; tile 0 landed for everybody before the first phase
+    issue_tile<Cfg::NA, Cfg::NW>(lds_wave, sA, sW, voff);
+    issue_tile<Cfg::NA, Cfg::NW>(lds_wave + Cfg::TILE, sA + ROWB, sW + ROWB, voff);
+    phase_end<NG>(true);
+    if (grp == 1) phase_end<NG>(true);                   // group 1 runs one phase behind group 0
+
+    int buf = 0, nbuf = 2;                               // buffer of tile t / of tile t+2
+    for (int t = 0; t < KT; ++t) {
+        // ---- load phase: loads of tile t+2, fragments of tile t
+        const bool more = t + 2 < KT;
+        if (more) {
+            const size_t ko = (size_t)(t + 2) * ROWB;
+            issue_tile<Cfg::NA, Cfg::NW>(lds_wave + nbuf * Cfg::TILE, sA + ko, sW + ko, voff);
+        }
+        const char* tb = smem + buf * Cfg::TILE;
+        float4 af[KQ][TM], bf[KQ][TN];
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[kq][a] = *reinterpret_cast<const float4*>(tb + arow + a * 32 * ROWB + fo[kq]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[kq][b] = *reinterpret_cast<const float4*>(tb + brow + b * 32 * ROWB + fo[kq]);
+        }
+        phase_end<NG>(more);
+        // ---- math phase
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+            if constexpr (BF16) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, af[kq][a]), __builtin_bit_cast(bf16x8, bf[kq][b]), acc[a][b], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            const float av = u == 0 ? af[kq][a].x : u == 1 ? af[kq][a].y : u == 2 ? af[kq][a].z : af[kq][a].w;
+                            const float bv = u == 0 ? bf[kq][b].x : u == 1 ? bf[kq][b].y : u == 2 ? bf[kq][b].z : bf[kq][b].w;
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                        }
+            }
+        }
+        phase_end<NG>(more);
+        buf = buf == 2 ? 0 : buf + 1;
+        nbuf = nbuf == 2 ? 0 : nbuf + 1;
+    }
+    if (grp == 0) phase_end<NG>(false);                  // same number of barriers for both groups
+
+    if constexpr (FUSE6) {
+        // ---- fused epilogue.  Every wave is past its last fragment read (the barrier above), LDS is free.
+        constexpr int HLD = 68;                          // h2 tile [128][68] floats
+        float* ht = reinterpret_cast<float*>(smem);
+        const int col_l = wn + i;
+        const float bv = bias[n0 + col_l];
+        float* C = static_cast<float*>(Cv);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row_l = wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = acc[0][0][r] + bv;
+            v = v < 0.f ? 0.f : v;                       // fc.3's ReLU; keeps NaN like torch
+            ht[row_l * HLD + col_l] = v;
+            if (C && m0 + row_l < M) C[(size_t)(m0 + row_l) * N + n0 + col_l] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const fc6_f32x4 p = fc6_chunk_mfma(ht + 16 * wid * HLD, HLD, 0, lane, bw6);   // wave w: rows 16w .. 16w+15
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * wid + 4 * (lane >> 4) + r;
+            if (row < M) part[((size_t)tn * part_rows + row) * NCLS + (lane & 15)] = p[r];
+        }
+        return;
+    }
+
+    // ---- epilogue: bias + (ReLU); D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    auto store_tile = [&](auto full) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + wn + 32 * b + i;
+            const float bv = bias[col];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float v = acc[a][b][r] + bv;
+                    if (relu) v = v < 0.f ? 0.f : v;              // keeps NaN like torch
+                    if (decltype(full)::value || row < M) {
+                        if constexpr (OUT_BF16) static_cast<unsigned short*>(Cv)[(size_t)row * N + col] = f32_to_bf16(v);
+                        else static_cast<float*>(Cv)[(size_t)row * N + col] = v;
+                    }
+                }
+        }
+    };
+    if (m0 + BM <= M) store_tile(std::true_type{});      // whole tile in range: no per-store predicate
+    else store_tile(std::false_type{});
+}
+
+// tile 2 = 256 x 128 with 128-byte K-tiles; tile 1 = 128 x 64 with 256-byte K-tiles (same 48 KB per K-tile,
+// twice the MFMAs per phase that 128-byte K-tiles would give the small wave tile)
+template <int T> struct PhTile;
+template <> struct PhTile<2> { static constexpr int TM = 2, TN = 2, ROWB = 128; };
+template <> struct PhTile<1> { static constexpr int TM = 1, TN = 1, ROWB = 256; };
+
+template <bool BF16, bool OUT_BF16, int T> static hipError_t grant_phased()
+{
+    using P = PhTile<T>;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<P::TM, P::TN, P::ROWB>::LDS);
+}
+
+hipError_t init_fc_gemm_phased()
+{
+    hipError_t e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<1, 1, 256>::LDS)) != hipSuccess) return e;
+    if ((e = grant_phased<false, false, 2>()) != hipSuccess) return e;
+    if ((e = grant_phased<false, false, 1>()) != hipSuccess) return e;
+    if ((e = grant_phased<true, true, 2>()) != hipSuccess) return e;
+    if ((e = grant_phased<true, false, 2>()) != hipSuccess) return e;
+    if ((e = grant_phased<true, true, 1>()) != hipSuccess) return e;
+    return grant_phased<true, false, 1>();
+}
+
+// Tile choice: 256 x 128 when those tiles alone fill the chip (>= 192 of them), else 128 x 64 when THOSE do;
+// 0 = this shape stays on the tile kernels of fc_gemm.hip.  DCE_GEMM=tile forces 0 (A/B).
+static int phased_tile(int64_t M, int N, int K, int es)
+{
+    static const bool off = getenv("DCE_GEMM") && strcmp(getenv("DCE_GEMM"), "tile") == 0;
+    static const int tmin = getenv("DCE_GEMM_PHASED_MIN") ? atoi(getenv("DCE_GEMM_PHASED_MIN")) : 1;   // 2: only the 256x128 tile
+    if (off || (size_t)K * es % 256 || (size_t)K * es < 3 * 256 || M > (1 << 30)) return 0;
+    if ((size_t)256 * K * es + 128 >= (1ull << 32)) return 0;                     // per-lane offsets are 32-bit
+    for (int t = 2; t >= tmin; --t) {
+        const int bm = 128 * t, bn = 64 * t;
+        if (N % bn) continue;
+        const int nt = N / bn;
+        if ((nt & (nt - 1)) != 0) continue;                                       // super-tile map wants a power of two
+        if (((M + bm - 1) / bm) * nt >= 192) return t;
+    }
+    return 0;
+}
+
+bool fc_gemm_phased_ok(int64_t M, int N, int K, int bf16) { return phased_tile(M, N, K, bf16 ? 2 : 4) != 0; }
+
+template <bool BF16, bool OUT_BF16, int T>
+static hipError_t launch_phased_cfg(const void* A, const void* W, const float* bias, void* C,
+                                    int64_t M, int N, int K, int relu, hipStream_t st)
+{
+    using P = PhTile<T>;
+    using Cfg = PhCfg<P::TM, P::TN, P::ROWB>;
+    const int mtiles = (int)((M + Cfg::BM - 1) / Cfg::BM), ntiles = N / Cfg::BN;
+    int sn_log2 = 2;                                   // super-tile 8 x 4 ...
+    while ((1 << sn_log2) > ntiles) --sn_log2;         // ... or (32/ntiles) x ntiles when N is narrow
+    const int sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
+    const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
+    const int grid = ((nsuper + 7) / 8) * 8 * 32;
+    hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB>), dim3(grid), dim3(512), Cfg::LDS, st,
+                       A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+    return hipGetLastError();
+}
+
+hipError_t launch_fc_gemm_phased(const void* A, const void* W, const float* bias, void* C, int bf16, int out_bf16,
+                                 int64_t M, int N, int K, int relu, hipStream_t st)
+{
+    const int t = phased_tile(M, N, K, bf16 ? 2 : 4);
+    if (t == 0 || (!bf16 && out_bf16)) return hipErrorInvalidValue;
+    if (!bf16) return t == 2 ? launch_phased_cfg<false, false, 2>(A, W, bias, C, M, N, K, relu, st)
+                             : launch_phased_cfg<false, false, 1>(A, W, bias, C, M, N, K, relu, st);
+    if (out_bf16) return t == 2 ? launch_phased_cfg<true, true, 2>(A, W, bias, C, M, N, K, relu, st)
+                                : launch_phased_cfg<true, true, 1>(A, W, bias, C, M, N, K, relu, st);
+    return t == 2 ? launch_phased_cfg<true, false, 2>(A, W, bias, C, M, N, K, relu, st)
+                  : launch_phased_cfg<true, false, 1>(A, W, bias, C, M, N, K, relu, st);
+}
+
+// fc.3 + fc.6 chunk sums in one launch: the 128 x 64 phased tile, when it is the tile fc.3 would get anyway
+bool fc23_fused_ok(int64_t M)
+{
+    static const bool off = getenv("DCE_FC23") && strcmp(getenv("DCE_FC23"), "split") == 0;    // A/B: separate tail kernel
+    return !off && phased_tile(M, FC2, FC1, 4) == 1;
+}
+
+hipError_t launch_fc23_fused(const float* h1, const float* W2, const float* b2, const float* W3,
+                             float* part, int64_t part_rows, float* h2_out, int64_t M, hipStream_t st)
+{
+    using Cfg = PhCfg<1, 1, 256>;
+    static_assert(Cfg::BN == FC6_CHUNK && FC2 / Cfg::BN == FC6_NCHUNK, "one column tile of fc.3 = one chunk of fc.6");
+    const int mtiles = (int)((M + Cfg::BM - 1) / Cfg::BM), ntiles = FC2 / Cfg::BN;
+    const int sn_log2 = 2, sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
+    const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
+    const int grid = ((nsuper + 7) / 8) * 8 * 32;
+    hipLaunchKernelGGL((fc_gemm_phased_kernel<false, false, 1, 1, 256, true>), dim3(grid), dim3(512), Cfg::LDS, st,
+                       static_cast<const void*>(h1), static_cast<const void*>(W2), b2, static_cast<void*>(h2_out),
+                       (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
+    return hipGetLastError();
+}
+
+}  // namespace dce

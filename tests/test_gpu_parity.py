@@ -607,24 +607,31 @@ def test_inference_and_compute_acc_vs_reference_function(golden, case_inputs, mo
     assert float(g["acc_B30"]) > 1.0 and float(g["acc_B30"]) != float(g["acc_B1"])   # the reference's broadcast, documented
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16_fc"])
 @pytest.mark.parametrize("n", [4096, 3000, 8192 + 77])
-def test_bf16_phased_gemm_equals_tile128_kernel(n, monkeypatch):
-    """The phased 256x128 bf16 GEMM (LDS-DMA staging, two wave groups one phase apart; fc_gemm_bf16.hip)
-    issues the same v_mfma_f32_32x32x16_bf16 sequence per output as the 128x128-tile kernel it replaces
-    at chip-filling sizes (DCE_BF16_GEMM=tile128 keeps the old one): logits must be the same BITS, for a
-    full grid, a partial last row tile and more than one round of tiles -- and over repeated runs
-    (the phases order LDS-DMA against fragment reads only through counted waits and barriers)."""
+def test_phased_gemm_equals_tile_kernels(n, precision, monkeypatch):
+    """The phased GEMMs (one workgroup per CU, LDS-DMA staging, two wave groups one phase apart;
+    fc_gemm_phased.hip) issue the same MFMA sequence per output as the tile kernels of fc_gemm.hip they
+    replace at chip-filling sizes (DCE_GEMM=tile keeps those): every FC activation and logit must be the
+    same BITS -- for a full grid, a partial last row tile and more than one round of tiles, in both
+    precisions -- and over repeated runs (the phases order LDS-DMA against fragment reads only through
+    counted waits and barriers, so a race would show up as a run-to-run difference)."""
     from deep_contact_estimator_amd import contact_cnn, synth
     sd = synth.make_state_dict(1, "uniform")
     x = np.random.default_rng(7 + n).standard_normal((n, 150, 54), dtype=np.float32)
-    monkeypatch.setenv("DCE_BF16_GEMM", "tile128")
-    old = contact_cnn(device=0, max_batch=n, precision="bf16_fc"); old.load_state_dict(sd)
+    monkeypatch.setenv("DCE_GEMM", "tile")
+    old = contact_cnn(device=0, max_batch=n, precision=precision); old.load_state_dict(sd)
     ref = old.predict(x)
+    ref_taps = old.forward_taps(x[:4096]) if precision == "fp32" else None
     old.close()
-    monkeypatch.delenv("DCE_BF16_GEMM")
-    new = contact_cnn(device=0, max_batch=n, precision="bf16_fc"); new.load_state_dict(sd)
+    monkeypatch.delenv("DCE_GEMM")
+    new = contact_cnn(device=0, max_batch=n, precision=precision); new.load_state_dict(sd)
     for rep in range(4):
         got = new.predict(x)
         assert np.array_equal(got["logits"], ref["logits"]), (n, rep, np.abs(got["logits"] - ref["logits"]).max())
         assert np.array_equal(got["pred"], ref["pred"])
+    if ref_taps is not None:
+        taps = new.forward_taps(x[:4096])
+        for k in ("h1", "h2", "logits"):
+            assert np.array_equal(taps[k], ref_taps[k]), k
     new.close()
