@@ -177,16 +177,23 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         // (feat and h1 scratch hold bf16 here); fc.6 + argmax stay fp32
         { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream, c->src_row_dev)); }
         { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
+        if (fc23_fused_ok(n, 1)) {
+            { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch,
+                                                          c->want_h2 ? c->h2 : nullptr, n, c->stream)); }
+            { Timer t(c, 3); HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, n, logits, pred, contacts, c->stream)); }
+            if (c->spans.size() > 4096) return drain_spans(c);
+            return DCE_OK;
+        }
         { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, c->stream)); }
     } else {
         { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream, c->src_row_dev)); }
         // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
         auto fc = (c->gemv && n <= FC_GEMV_MAX_M) ? launch_fc_gemv : launch_fc_gemm;
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
-        if (fc23_fused_ok(n)) {
+        if (fc23_fused_ok(n, 0)) {
             // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU
             // unless a tap asks for it); one small kernel adds them up.  Same summation tree as the tail kernel.
-            { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, c->part, c->max_batch,
+            { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch,
                                                           c->want_h2 ? c->h2 : nullptr, n, c->stream)); }
             { Timer t(c, 3); HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, n, logits, pred, contacts, c->stream)); }
             if (c->spans.size() > 4096) return drain_spans(c);

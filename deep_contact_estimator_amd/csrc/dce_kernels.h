@@ -70,9 +70,10 @@ hipError_t launch_fc_gemm_phased(const void* A, const void* W, const float* bias
                                  int64_t M, int N, int K, int relu, hipStream_t st);
 
 // fc.3 (+ReLU) with fc.6's chunk sums finished in the GEMM epilogue (fp32, chip-filling batches; fc6_chain.h):
-// A = h1 (M,2048), W2 (512,2048), b2; part: [8][part_rows][16] chunk sums out; h2_out: NULL, or (M,512) for taps.
-bool       fc23_fused_ok(int64_t M);
-hipError_t launch_fc23_fused(const float* h1, const float* W2, const float* b2, const float* W3,
+// A = h1 (M,2048), W2 (512,2048) -- fp32, or bf16 in the DCE_BF16_FC mode (h2 and everything after it stay fp32);
+// b2; part: [8][part_rows][16] chunk sums out; h2_out: NULL, or (M,512) fp32 for taps.
+bool       fc23_fused_ok(int64_t M, int bf16);
+hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, const float* W3, int bf16,
                              float* part, int64_t part_rows, float* h2_out, int64_t M, hipStream_t st);
 // ... and the combine behind it: logits = ordered sum of the 8 chunk sums + b3, argmax, contact bits
 hipError_t launch_fc6_combine(const float* part, int64_t part_rows, const float* b3, int64_t n,

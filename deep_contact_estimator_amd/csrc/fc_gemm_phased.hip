@@ -120,7 +120,7 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
                            int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2,
                            const float* __restrict__ W3 = nullptr, float* __restrict__ part = nullptr, long long part_rows = 0)
 {
-    static_assert(!FUSE6 || (!BF16 && !OUT_BF16 && TM == 1 && TN == 1), "the fused fc.6 epilogue is fc.3's fp32 128x64 tile");
+    static_assert(!FUSE6 || (!OUT_BF16 && TM == 1 && TN == 1), "the fused fc.6 epilogue is fc.3's 128x64 tile with fp32 output");
     using Cfg = PhCfg<TM, TN, ROWB>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NG = Cfg::NA + Cfg::NW, KQ = Cfg::KQ;
     constexpr int ES = BF16 ? 2 : 4;                     // operand element size
@@ -300,6 +300,8 @@ hipError_t init_fc_gemm_phased()
     hipError_t e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<1, 1, 256>::LDS)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<true, false, 1, 1, 256, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<1, 1, 256>::LDS)) != hipSuccess) return e;
     if ((e = grant_phased<false, false, 2>()) != hipSuccess) return e;
     if ((e = grant_phased<false, false, 1>()) != hipSuccess) return e;
     if ((e = grant_phased<true, true, 2>()) != hipSuccess) return e;
@@ -335,8 +337,12 @@ static hipError_t launch_phased_cfg(const void* A, const void* W, const float* b
     using P = PhTile<T>;
     using Cfg = PhCfg<P::TM, P::TN, P::ROWB>;
     const int mtiles = (int)((M + Cfg::BM - 1) / Cfg::BM), ntiles = N / Cfg::BN;
-    int sn_log2 = 2;                                   // super-tile 8 x 4 ...
-    while ((1 << sn_log2) > ntiles) --sn_log2;         // ... or (32/ntiles) x ntiles when N is narrow
+    // the 32 blocks of one XCD form an sm x sn super-tile: each A panel enters (ntiles/sn) L2s, each W panel
+    // (mtiles/sm).  fc.0 (A = 2 W bytes, 16 x 16 tiles): 4 x 8 -> 2 A + 4 W = 310 MB of fabric reads per launch,
+    // against 388 MB for 8 x 4 or 2 x 16.  DCE_PHASED_SN overrides log2(sn) (A/B).
+    static const int sn_env = getenv("DCE_PHASED_SN") ? atoi(getenv("DCE_PHASED_SN")) : 3;
+    int sn_log2 = sn_env;
+    while ((1 << sn_log2) > ntiles) --sn_log2;         // (32/ntiles) x ntiles when N is narrow
     const int sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
@@ -359,13 +365,13 @@ hipError_t launch_fc_gemm_phased(const void* A, const void* W, const float* bias
 }
 
 // fc.3 + fc.6 chunk sums in one launch: the 128 x 64 phased tile, when it is the tile fc.3 would get anyway
-bool fc23_fused_ok(int64_t M)
+bool fc23_fused_ok(int64_t M, int bf16)
 {
     static const bool off = getenv("DCE_FC23") && strcmp(getenv("DCE_FC23"), "split") == 0;    // A/B: separate tail kernel
-    return !off && phased_tile(M, FC2, FC1, 4) == 1;
+    return !off && phased_tile(M, FC2, FC1, bf16 ? 2 : 4) == 1;
 }
 
-hipError_t launch_fc23_fused(const float* h1, const float* W2, const float* b2, const float* W3,
+hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, const float* W3, int bf16,
                              float* part, int64_t part_rows, float* h2_out, int64_t M, hipStream_t st)
 {
     using Cfg = PhCfg<1, 1, 256>;
@@ -374,9 +380,10 @@ hipError_t launch_fc23_fused(const float* h1, const float* W2, const float* b2, 
     const int sn_log2 = 2, sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
-    hipLaunchKernelGGL((fc_gemm_phased_kernel<false, false, 1, 1, 256, true>), dim3(grid), dim3(512), Cfg::LDS, st,
-                       static_cast<const void*>(h1), static_cast<const void*>(W2), b2, static_cast<void*>(h2_out),
-                       (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
+    if (bf16) hipLaunchKernelGGL((fc_gemm_phased_kernel<true, false, 1, 1, 256, true>), dim3(grid), dim3(512), Cfg::LDS, st,
+                                 h1, W2, b2, static_cast<void*>(h2_out), (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
+    else      hipLaunchKernelGGL((fc_gemm_phased_kernel<false, false, 1, 1, 256, true>), dim3(grid), dim3(512), Cfg::LDS, st,
+                                 h1, W2, b2, static_cast<void*>(h2_out), (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
     return hipGetLastError();
 }
 

@@ -120,3 +120,51 @@ def test_metrics_from_confusion_match_reference_sklearn(golden):
     m = metrics.metrics_from_confusion16(C)
     assert m["fn_rate"]["leg_rf"] == 0.0 and np.isnan(m["fp_rate"]["leg_rf"]) and m["precision_of_legs"][0] == 0.0
     assert np.isnan(metrics.metrics_from_confusion16(np.zeros((16, 16), np.int64))["acc"])
+
+
+def test_asm_staging_loads_are_not_touched_before_their_wait(tmp_path):
+    """The tile / small / GEMV kernels issue their staging loads as inline asm (hipcc would sink plain
+    loads) and wait for them with an explicit s_waitcnt that names the destination registers.  Those
+    loads are invisible to hipcc's own s_waitcnt bookkeeping, so a compiler-inserted move, spill or reuse of
+    a destination register between issue and wait would read stale data (cdna_hip_programming.md 5.7 item 1).
+    Guard it across compiler upgrades: in the generated gfx950 assembly no instruction outside the asm
+    blocks may name a register of an in-flight asm load before the next asm s_waitcnt vmcnt."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    checked = 0
+    for src in ("fc_gemm.hip", "fc_gemv.hip"):
+        out = tmp_path / (src + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out),
+                        os.path.join(ROOT, "deep_contact_estimator_amd", "csrc", src)], check=True, capture_output=True)
+        in_asm, pending = False, []            # pending: list of (lo, hi, line) register ranges with a load in flight
+        for ln, line in enumerate(open(out), 1):
+            t = line.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True; continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False; continue
+            if not t or t.startswith((";", ".", "_Z")) or t.endswith(":"):
+                if t.endswith(":") and not t.startswith(".LBB"):
+                    pending = []               # next function
+                continue
+            if in_asm:
+                m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", t)
+                if m:
+                    pending.append((int(m.group(1)), int(m.group(2)), ln)); checked += 1
+                elif t.startswith("s_waitcnt") and "vmcnt" in t:
+                    pending = []
+                continue
+            if not pending:
+                continue
+            regs = set()
+            for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t):
+                regs.update(range(int(a), int(b) + 1))
+            regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", t))
+            for lo, hi, at in pending:
+                hit = [r for r in regs if lo <= r <= hi]
+                assert not hit, f"{src}:{ln}: `{t}` touches v{hit} while the asm load of line {at} is in flight"
+    assert checked >= 16, checked                # the pattern is still there to be guarded
