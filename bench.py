@@ -286,11 +286,11 @@ def extra_streaming(torch, contact_cnn, sd, dev, n_windows=1_000_000):
     }
 
 
-def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps):
+def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s=1.5):
     """BASELINE configs[4]: fc.0 / fc.3 on bf16 MFMA (fp32 accumulate), conv stack and fc.6 fp32."""
     m = contact_cnn(device=dev.index, max_batch=B, precision="bf16_fc")
     m.load_state_dict(sd).eval()
-    settle(torch, lambda: m.predict(windows), 0.5)
+    settle(torch, lambda: m.predict(windows), settle_s)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = run_steps(m, windows, steps)
@@ -519,7 +519,7 @@ def main():
         elif args.precision == "fp32":
             res["extra"] = {
                 "streaming_1e6": extra_streaming(torch, contact_cnn, sd, dev),
-                "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps),
+                "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s),
             }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
