@@ -49,6 +49,11 @@ constexpr int WINO1_MAX_N = 256;                             // <= this many win
 #ifndef WINO_EXP
 #define WINO_EXP 0           // bit flags for tools/micro/wino_loop.hip ablations; 0 in the product
 #endif
+#ifndef WINO_INTERLEAVE
+#define WINO_INTERLEAVE 0    // 1: deal the input-transform ops of tile i+1 out between the MFMAs of tile i.  Measured (r2k, product
+                             // kernel, 3 interleaved rounds): 442.4 us vs 427.0 us bunched -- an op between two MFMAs costs more than
+                             // the same op in a bunch ahead of eight back-to-back MFMAs; kept as an experiment switch only
+#endif
 #ifndef WINO_PK
 // Winograd input transform of one column tile (4 adds per lane):
 //   0: four plain v_add/v_sub_f32 (asm)   2: two hand-written v_pk_add_f32   1: compiler-chosen packed adds
@@ -180,6 +185,34 @@ __device__ __forceinline__ void wino_step(const float* __restrict__ xs, const fl
 #else
         const Quad rawc = load_quad2(pc);                  // tile i+2
 #endif
+#if WINO_INTERLEAVE
+        // The four transform ops of tile i+1 are dealt out between the MFMAs of tile i (one per MFMA gap,
+        // order pinned by sched_barrier) instead of being issued in a bunch ahead of them: a bunch of ~9
+        // non-MFMA instructions is longer than the 32-cycle shadow of the MFMA before it.
+        V4 vnxt;
+        float t0, t3, t1, t2;
+        const float v[4] = {vcur.a.x, vcur.b.x, vcur.b.y, vcur.a.y};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 c0 = FIRST ? (c == 1 ? bias[0] : zero) : acc[0][nt][c];
+            acc[0][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], v[c], c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == 0) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(t0) : "v"(rawb.p.x), "v"(rawb.q.x));      // d0 - d2
+            if (c == 1) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(t3) : "v"(rawb.p.y), "v"(rawb.q.y));      // d1 - d3
+            if (c == 2) asm volatile("v_add_f32 %0, %1, %2" : "=v"(t1) : "v"(rawb.p.y), "v"(rawb.q.x));      // d1 + d2
+            if (c == 3) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(t2) : "v"(rawb.q.x), "v"(rawb.p.y));      // d2 - d1
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MT == 2) {
+                const f32x4 c1 = FIRST ? (c == 1 ? bias[1] : zero) : acc[1][nt][c];
+                acc[1][nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], v[c], c1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        vnxt.a = v2f{t0, t3};
+        vnxt.b = v2f{t1, t2};
+#else
         const V4 vnxt = wino_v(rawb);                      // tile i+1
         __builtin_amdgcn_sched_barrier(0);
         const float v[4] = {vcur.a.x, vcur.b.x, vcur.b.y, vcur.a.y};
@@ -194,6 +227,7 @@ __device__ __forceinline__ void wino_step(const float* __restrict__ xs, const fl
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#endif
         vcur = vnxt;
         rawb = rawc;
     }
