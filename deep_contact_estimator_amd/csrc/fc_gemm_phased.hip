@@ -367,8 +367,15 @@ hipError_t launch_fc_gemm_phased(const void* A, const void* W, const float* bias
 // fc.3 + fc.6 chunk sums in one launch: the 128 x 64 phased tile, when it is the tile fc.3 would get anyway
 bool fc23_fused_ok(int64_t M, int bf16)
 {
-    static const bool off = getenv("DCE_FC23") && strcmp(getenv("DCE_FC23"), "split") == 0;    // A/B: separate tail kernel
-    return !off && phased_tile(M, FC2, FC1, bf16 ? 2 : 4) == 1;
+    // Fused only where fc.3 gets the 128 x 64 tile anyway (one round of tiles, 3072..~12000 windows).  Longer chunks
+    // take the 256 x 128 tile + the stand-alone tail: forcing the small tile there (DCE_FC23=always) measured 0.8 %
+    // slower end to end on the 1e6-window sequence (3.849 vs 3.879 M windows/s) -- twice the phase hand-overs cost
+    // more than h2's HBM round trip.  DCE_FC23=split: never fused (A/B).
+    static const int mode = [] { const char* e = getenv("DCE_FC23"); return !e ? 0 : strcmp(e, "split") == 0 ? 1 : strcmp(e, "always") == 0 ? 2 : 0; }();
+    if (mode == 1) return false;
+    const int t = phased_tile(M, FC2, FC1, bf16 ? 2 : 4);
+    if (t == 1) return true;
+    return mode == 2 && t == 2 && ((M + 127) / 128) * FC6_NCHUNK >= 192;
 }
 
 hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, const float* W3, int bf16,
