@@ -402,6 +402,10 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
     if (N % 128 || K % 32 || M > (1 << 30)) return hipErrorInvalidValue;
     // chip-filling sizes: one phased workgroup per CU (fc_gemm_phased.hip); same K order, same bits
     if (fc_gemm_phased_ok(M, N, K, 0)) return launch_fc_gemm_phased(A, W, bias, C, 0, 0, M, N, K, relu, st);
+    // (In between, a no-LDS kernel -- one 16x16 / 32x32 output tile per wave on v_mfma_f32_16x16x4_f32, operands streamed
+    //  from L2 straight into MFMA registers, bit-identical -- was built and measured in round 2: 1.4x - 3.2x SLOWER than the
+    //  tile kernels below at 64 .. 2048 windows (fc.0 at 512 windows 518 vs 162 us: fragment-shaped 16-B-per-row loads keep
+    //  the texture path busy; profiles/r2l_latency_*.txt).  The LDS-tiled kernels stay.)
     // 128x128 tiles when they alone fill the chip (512 resident blocks), else 64x64
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
     if (big_blocks >= 384) return launch_gemm_cfg<2, 2, false, false>(A, W, bias, C, M, N, K, relu, st);

@@ -10,7 +10,7 @@ m = contact_cnn(device=0, max_batch=4096); m.load_state_dict(synth.make_state_di
 seq = torch.from_numpy(synth.make_sequence(4096 + 149, 2).astype(np.float32)).cuda()
 x = m.zscore_windows(seq)
 res = {}
-for B in (1, 2, 30, 128, 512, 4096):
+for B in (1, 2, 30, 64, 128, 256, 512, 1024, 2048, 3000, 4096):
     xb = x[:B].contiguous()
     for _ in range(20): m.predict(xb)
     torch.cuda.synchronize()
