@@ -61,8 +61,8 @@ EXEC_FLOP = dict(ALGO_FLOP, conv_stack=4 * 3120 * 2048 // 2)        # 12,779,520
 ALGO_BYTES = {
     "conv_stack": 150 * 54 * 4 + 4736 * 4,
     "fc1_gemm": 4736 * 4 + 2048 * 4,
-    "fc2_gemm": 2048 * 4 + 512 * 4,
-    "fc3_tail": 512 * 4 + 16 * 4 + 4 + 4,
+    "fc2_gemm": 2048 * 4 + 8 * 16 * 4,          # h1 in, fc.6's 8 x 16 chunk sums out (h2 stays on chip at this batch size)
+    "fc3_tail": 8 * 16 * 4 + 16 * 4 + 4 + 4,    # the chunk sums in; logits, pred, contacts out
     "fc23_fused": 2048 * 4 + 16 * 4 + 4 + 4,
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, 256 CU x 2.4 GHz

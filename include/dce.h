@@ -138,7 +138,7 @@ int  dce_confusion_counts(dce_ctx* ctx, const int32_t* pred, const int64_t* labe
  * 0 while the ring is still filling, < 0 on error.  dce_online_reset empties the ring.
  * Latency path: no H2D/D2H copies and no stream synchronisation -- the sample is read by the first
  * kernel from pinned host memory, the estimate is written by the last kernel to pinned host memory
- * followed by a sequence number the call polls (~89 us per push on MI355X). */
+ * followed by a sequence number the call polls (~85-90 us per push on MI355X). */
 int  dce_online_reset(dce_ctx* ctx);
 int  dce_online_push(dce_ctx* ctx, const float* sample, float* logits, int32_t* pred, uint8_t* contacts);
 
@@ -147,7 +147,8 @@ int  dce_online_push(dce_ctx* ctx, const float* sample, float* logits, int32_t* 
  * (k = 1: every one; an event costs ~4 us of stream time, so a sparse sample keeps the timed
  * region honest), on = 0 stops.  dce_profile_read synchronises and returns the accumulated
  * milliseconds and launch counts since the last reset:
- * slot 0 = conv stack, 1 = fc1 GEMM, 2 = fc2 GEMM, 3 = fc3+argmax tail. */
+ * slot 0 = conv stack, 1 = fc.0 GEMM, 2 = fc.3 GEMM (with fc.6's chunk sums in its epilogue at chip-filling
+ * batches), 3 = fc.6 + argmax + contact bits (combine kernel behind the fused epilogue, tail kernel otherwise). */
 #define DCE_PROFILE_SLOTS 4
 int  dce_profile_enable(dce_ctx* ctx, int on);
 int  dce_profile_read(dce_ctx* ctx, double ms[DCE_PROFILE_SLOTS], int64_t launches[DCE_PROFILE_SLOTS], int reset);

@@ -17,8 +17,10 @@ B = 4096
 ALGO = {
     "conv_stack": 51344 * B + 4 * (96768 + 384),
     "fc1_gemm(128x128)": (18944 + 8192) * B + 4 * (2048 * 4736 + 2048),
-    "fc2_gemm(64x64)": (8192 + 2048) * B + 4 * (512 * 2048 + 512),
-    "fc3_tail": (2048 + 64 + 4 + 4) * B + 4 * (16 * 512 + 16),
+    # fc.3 with fc.6's chunk sums in its epilogue: h1 in, 8 x 16 chunk sums out (h2 stays on chip), W2 + W3 once
+    "fc2_gemm(64x64)": (8192 + 8 * 64) * B + 4 * (512 * 2048 + 512 + 16 * 512),
+    # combine: the chunk sums in, logits + pred + contacts out
+    "fc3_tail": (8 * 64 + 64 + 4 + 4) * B + 4 * 16,
 }
 NAMES = {"conv_stack": "conv_stack", "fc1_gemm(128x128)": "fc1_gemm", "fc2_gemm(64x64)": "fc2_gemm", "fc3_tail": "fc3_tail"}
 
