@@ -18,6 +18,8 @@
 //     VGPRs, no ds_write pass; three LDS buffers, loads run two K-tiles ahead of the math;
 //   * bf16 needs the large tile for another reason: at bf16 rate a 128x128 tile moves 64 B/clk/CU out of
 //     L2 and through ds_write_b128 (79 B/clk/CU); 256x128 per CU asks for 47 B/clk.
+// (s_setprio(1) around the math phase measured +-0 on both precisions, r2 A/B: the load-phase wave's handful of
+// instructions never starves the math wave.)
 // LDS image: a K-tile is (BM + BN) rows x 128 or 256 B of K; LDS-DMA writes lane-linear (1 KB = 8 or 4 rows
 // per wave-instruction), so the bank swizzle lives in the per-lane GLOBAL address: 16-byte column c of row r
 // is stored at slot c ^ swz(r) (PhCfg::swz); the fragment reads (lane = row, fixed logical column) apply the
