@@ -386,8 +386,14 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # DCE_FORCE_DIST=1: run the N>1 flow (process group, per-step gather, extra.sharded_1e6) in a world of ONE rank --
+    # the only form in which RCCL itself can be exercised on a single-GPU box (tests/test_cli_gpu.py)
+    multi = world > 1 or bool(os.environ.get("DCE_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29581")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -406,7 +412,7 @@ def main():
     torch.cuda.synchronize()
 
     gatherer = None
-    if world > 1:
+    if multi:
         from deep_contact_estimator_amd.distributed import AsyncRowGather
         gatherer = AsyncRowGather(B, 16, torch.float32, dev, dst=0, depth=2)
 
@@ -426,7 +432,7 @@ def main():
         out = step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     # 3. timed region: no events, no host work besides the launches
     t0 = time.perf_counter()
@@ -434,10 +440,10 @@ def main():
         out = step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -471,7 +477,7 @@ def main():
                             "HBM-resident -> fused conv stack + fc1/fc2/fc3 -> logits+argmax+contact bits "
                             "(dce_forward_windows, fp32 MFMA); synthetic He-init checkpoint seed 1",
                 "batch_per_gpu": B, "global_batch": B * world, "window": 150, "channels": 54,
-                "sharding": "independent windows per rank" + ("; async RCCL gather of (B,16) logits to rank 0 per step" if world > 1 else ""),
+                "sharding": "independent windows per rank" + ("; async RCCL gather of (B,16) logits to rank 0 per step" if multi else ""),
                 "settle": {"steps": settle_steps, "seconds": round(settle_s, 3)},
             },
         }
@@ -512,7 +518,7 @@ def main():
 
     # 5. the other configs + the CPU baseline (N=1: rank 0 alone; N>1: every rank takes part in the sharded pass)
     if not args.no_extras:
-        if world > 1:
+        if multi:
             sh = extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend)
             if rank == 0:
                 res["extra"] = {"sharded_1e6": sh}
@@ -527,7 +533,7 @@ def main():
                                                out["pred"].cpu().numpy())
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

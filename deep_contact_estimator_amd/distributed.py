@@ -146,7 +146,7 @@ def init_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("DCE_FORCE_DIST"):      # DCE_FORCE_DIST: a one-rank group (RCCL smoke test on one GPU)
         import torch
         import torch.distributed as dist
         # DCE_DIST_BACKEND=gloo: functional test of the multi-process path on a box with fewer GPUs

@@ -129,3 +129,62 @@ def test_config3_full_size_shards_equal_single_call():
               "contacts_are_bits_of_pred", "finite_logits"):
         assert j[k] is True, (k, j)
     assert j["classes_seen"] >= 4
+
+
+def test_rccl_single_rank_degenerate(tmp_path):
+    """RCCL itself (backend "nccl"), in the only form one GPU allows: a world of ONE rank.  Exercises what the
+    8-GPU run will execute first -- init_process_group("nccl", device_id=...), the packed gather of
+    infer_sequence_sharded, bench.py's AsyncRowGather (async gather handles on device tensors), the all-reduce of
+    the confusion counts, barrier, destroy -- against the single-process results."""
+    code = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DCE_ROOT"])
+from deep_contact_estimator_amd import contact_cnn, synth
+from deep_contact_estimator_amd.distributed import init_from_env, infer_sequence_sharded, AsyncRowGather, confusion_sharded
+rank, world, local = init_from_env()
+assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl"
+dev = torch.device("cuda", local)
+m = contact_cnn(device=local, max_batch=512); m.load_state_dict(synth.make_state_dict(1, "uniform"))
+seq = torch.from_numpy(synth.make_sequence(150 + 700, 9).astype(np.float32)).to(dev)
+one = m.infer_sequence(seq)
+got = infer_sequence_sharded(m.infer_sequence, seq, dst=0)
+ok = all(torch.equal(got[k], one[k]) for k in ("logits", "pred", "contacts"))
+g = AsyncRowGather(701, 16, torch.float32, dev, dst=0, depth=2)
+for _ in range(5):
+    g.submit(one["logits"])
+g.drain()
+ok = ok and torch.equal(g.latest()[0], one["logits"])
+labels = torch.from_numpy(synth.make_labels(150 + 700, 9).reshape(-1)).to(dev)
+C = confusion_sharded(m.infer_sequence, m.confusion_counts, seq, labels)
+ok = ok and int(C.sum().item()) == 701
+t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier(); dist.destroy_process_group()
+print(json.dumps({"ok": bool(ok), "max": float(t.item())}))
+'''
+    script = tmp_path / "rccl1.py"
+    script.write_text(code)
+    env = dict(os.environ, PYTHONPATH=ROOT, DCE_ROOT=ROOT, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
+    env.update(WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    # init_from_env only joins a group when WORLD_SIZE > 1; force the one-rank group through the same call
+    env["DCE_FORCE_DIST"] = "1"
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    import json
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["ok"] is True and j["max"] == 1.5
+
+
+def test_bench_multi_gpu_flow_on_rccl_single_rank():
+    """bench.py's N>1 flow on real RCCL in a world of one rank (DCE_FORCE_DIST=1): nccl process group with
+    device_id, the asynchronous per-step gather of the logits, barrier + all-reduce(MAX) timing, and
+    extra.sharded_1e6 (configs[3]: 1e6 windows, the one packed gather) -- the code the driver's --gpus 8 run executes."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, DCE_FORCE_DIST="1", MASTER_PORT="29583")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--settle-s", "0.2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and "RCCL gather" in j["config"]["sharding"] and j["value"] > 1e6
+    sh = j["extra"]["sharded_1e6"]
+    assert sh["windows_per_s_incl_gather"] > 1e6 and abs(sh["gathered_MB"] - 68.0) < 1e-9
