@@ -188,6 +188,16 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
     phase_end<NG>(true);
     if (grp == 1) phase_end<NG>(true);                   // group 1 runs one phase behind group 0
 
+    // Ordering of LDS-DMA against fragment reads.  Number the phases p = 0, 1, 2, ...; a barrier ends each.
+    //   group 0: load(t) in phase 2t,   math(t) in phase 2t+1        group 1: load(t) in 2t+1, math(t) in 2t+2
+    // Tile t+2 goes to buffer (t+2) % 3 = the buffer of tile t-1.  Each wave issues its six pieces of tile t+2 at the
+    // start of ITS load(t): group 0 in phase 2t, group 1 in phase 2t+1.
+    //   WAR: the last reader of tile t-1 is group 1's load(t-1), phase 2t-1; it ends with lgkmcnt(0) + barrier, so
+    //        every fragment read of that buffer has RETURNED before phase 2t starts.
+    //   RAW: the first reader of tile t+2 is group 0's load(t+2), phase 2t+4.  A wave's "vmcnt(6)" at a phase end
+    //        means all but its six newest pieces have landed: group 0's pieces of t+2 are retired at the end of phase
+    //        2t+2 (it issued t+3 at the start of that phase), group 1's at the end of phase 2t+3 -- both followed by
+    //        a barrier before phase 2t+4.  Once nothing is left to issue (t+2 >= KT) the waits become vmcnt(0).
     int buf = 0, nbuf = 2;                               // buffer of tile t / of tile t+2
     for (int t = 0; t < KT; ++t) {
         // ---- load phase: loads of tile t+2, fragments of tile t
