@@ -115,7 +115,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p)
 // FUSE6 (fp32, 128 x 64 tile, N = 512: fc.3): the block's 64 output columns are exactly one chunk of fc.6's
 // summation tree (fc6_chain.h), so the epilogue finishes that chunk -- h2 tile -> LDS -> 16 MFMAs per 16 rows
 // -> chunk sums to `part` ([8][part_rows][16]) -- and h2 itself goes to HBM only when Cv != NULL (taps).
-template <bool BF16, bool OUT_BF16, int TM, int TN, int ROWB, bool FUSE6 = false>
+template <bool BF16, bool OUT_BF16, int TM, int TN, int ROWB, bool FUSE6, bool LOCKSTEP>
 __global__ __launch_bounds__(512, 2)
 void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                            const float* __restrict__ bias, void* __restrict__ Cv,
@@ -181,7 +181,79 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
     float4 bw6[4];                                       // FUSE6: this lane's W3 operands of the block's chunk (= column tile tn)
     if constexpr (FUSE6) fc6_load_w3(W3, tn, lane, bw6);
 
-    const int KT = (int)(rowb / ROWB);                   // >= 3 (checked by the launcher)
+    const int KT = (int)(rowb / ROWB);                   // >= 4 (checked by the launcher)
+
+    // fragments of one K-tile: KQ x (TM + TN) x 16 bytes per lane
+    auto load_frags = [&](int b, float4 (&af)[KQ][TM], float4 (&bf)[KQ][TN]) {
+        const char* tb = smem + b * Cfg::TILE;
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[kq][a] = *reinterpret_cast<const float4*>(tb + arow + a * 32 * ROWB + fo[kq]);
+#pragma unroll
+            for (int c = 0; c < TN; ++c) bf[kq][c] = *reinterpret_cast<const float4*>(tb + brow + c * 32 * ROWB + fo[kq]);
+        }
+    };
+    auto math = [&](const float4 (&af)[KQ][TM], const float4 (&bf)[KQ][TN]) {
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+            if constexpr (BF16) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, af[kq][a]), __builtin_bit_cast(bf16x8, bf[kq][b]), acc[a][b], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            const float av = u == 0 ? af[kq][a].x : u == 1 ? af[kq][a].y : u == 2 ? af[kq][a].z : af[kq][a].w;
+                            const float bv = u == 0 ? bf[kq][b].x : u == 1 ? bf[kq][b].y : u == 2 ? bf[kq][b].z : bf[kq][b].w;
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                        }
+            }
+        }
+    };
+
+    if constexpr (LOCKSTEP) {
+        // ---- the lockstep schedule: all eight waves in step, ONE barrier per K-tile, nothing but MFMAs between two
+        // barriers on the critical path: each wave keeps TWO register sets of fragments -- while it multiplies tile t
+        // out of one set it reads tile t+1's fragments from LDS into the other and issues its share of the global->LDS
+        // loads of tile t+3.  The two waves of a SIMD share the matrix pipe during the whole tile.
+        //   buffer of tile t+3 = buffer of tile t: its fragments were read during tile t-1 and returned (lgkmcnt(0))
+        //   before the barrier that ended tile t-1.  Tile t+1 is read during tile t: every wave waited for its pieces
+        //   of t+1 ("vmcnt(NG)": all but the newest tile landed; the newest then was t+2) before the barrier that ended
+        //   tile t-1.
+        float4 afA[KQ][TM], bfA[KQ][TN], afB[KQ][TM], bfB[KQ][TN];
+        issue_tile<Cfg::NA, Cfg::NW>(lds_wave, sA, sW, voff);
+        issue_tile<Cfg::NA, Cfg::NW>(lds_wave + Cfg::TILE, sA + ROWB, sW + ROWB, voff);
+        issue_tile<Cfg::NA, Cfg::NW>(lds_wave + 2 * Cfg::TILE, sA + 2 * ROWB, sW + 2 * ROWB, voff);
+        if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");    // tile 0 landed for everybody
+        else                   asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        load_frags(0, afA, bfA);
+        phase_end<NG>(true);                             // tile 1 landed; tile 0's fragments are in registers
+        auto step = [&](int t, const float4 (&afC)[KQ][TM], const float4 (&bfC)[KQ][TN], float4 (&afN)[KQ][TM], float4 (&bfN)[KQ][TN]) {
+            const bool more = t + 3 < KT;
+            if (more) {
+                const size_t ko = (size_t)(t + 3) * ROWB;
+                issue_tile<Cfg::NA, Cfg::NW>(lds_wave + (t % 3) * Cfg::TILE, sA + ko, sW + ko, voff);
+            }
+            if (t + 1 < KT) load_frags((t + 1) % 3, afN, bfN);
+            __builtin_amdgcn_sched_barrier(0);           // the LDS reads go out ahead of the MFMAs, not behind them
+            math(afC, bfC);
+            phase_end<NG>(more);
+        };
+        int t = 0;
+        for (; t + 2 <= KT; t += 2) {
+            step(t, afA, bfA, afB, bfB);
+            step(t + 1, afB, bfB, afA, bfA);
+        }
+        if (t < KT) step(t, afA, bfA, afB, bfB);
+    } else {
     // prologue: tiles 0 and 1 in flight; tile 0 landed for everybody before the first phase
     issue_tile<Cfg::NA, Cfg::NW>(lds_wave, sA, sW, voff);
     issue_tile<Cfg::NA, Cfg::NW>(lds_wave + Cfg::TILE, sA + ROWB, sW + ROWB, voff);
@@ -206,44 +278,17 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
             const size_t ko = (size_t)(t + 2) * ROWB;
             issue_tile<Cfg::NA, Cfg::NW>(lds_wave + nbuf * Cfg::TILE, sA + ko, sW + ko, voff);
         }
-        const char* tb = smem + buf * Cfg::TILE;
         float4 af[KQ][TM], bf[KQ][TN];
-#pragma unroll
-        for (int kq = 0; kq < KQ; ++kq) {
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[kq][a] = *reinterpret_cast<const float4*>(tb + arow + a * 32 * ROWB + fo[kq]);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bf[kq][b] = *reinterpret_cast<const float4*>(tb + brow + b * 32 * ROWB + fo[kq]);
-        }
+        load_frags(buf, af, bf);
         phase_end<NG>(more);
         // ---- math phase
-#pragma unroll
-        for (int kq = 0; kq < KQ; ++kq) {
-            if constexpr (BF16) {
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, af[kq][a]), __builtin_bit_cast(bf16x8, bf[kq][b]), acc[a][b], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int b = 0; b < TN; ++b) {
-                            const float av = u == 0 ? af[kq][a].x : u == 1 ? af[kq][a].y : u == 2 ? af[kq][a].z : af[kq][a].w;
-                            const float bv = u == 0 ? bf[kq][b].x : u == 1 ? bf[kq][b].y : u == 2 ? bf[kq][b].z : bf[kq][b].w;
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
-                        }
-            }
-        }
+        math(af, bf);
         phase_end<NG>(more);
         buf = buf == 2 ? 0 : buf + 1;
         nbuf = nbuf == 2 ? 0 : nbuf + 1;
     }
     if (grp == 0) phase_end<NG>(false);                  // same number of barriers for both groups
+    }
 
     if constexpr (FUSE6) {
         // ---- fused epilogue.  Every wave is past its last fragment read (the barrier above), LDS is free.
@@ -300,20 +345,39 @@ template <int T> struct PhTile;
 template <> struct PhTile<2> { static constexpr int TM = 2, TN = 2, ROWB = 128; };
 template <> struct PhTile<1> { static constexpr int TM = 1, TN = 1, ROWB = 256; };
 
+// Schedule: the two-groups-one-phase-apart loop ships for both precisions; DCE_GEMM=lockstep selects the other loop
+// (kept as a tested A/B variant).  Measured (r2q, interleaved rounds of the bench step):
+//   fp32: phased 569.9 us (fc.0) / 73.3 (fc.3), lockstep 589.3 / 77.3.  With all eight waves in step, both waves of
+//         every SIMD stand at the one barrier together; one phase apart, half of them are always early.
+//   bf16: phased 69-71 us (fc.0), lockstep 74-75.  End to end the two trade places with the board's clock governor:
+//         in 3-second runs on one box the step was 5 % FASTER with the slower lockstep GEMM (7.89 vs 7.52 M windows/s:
+//         after the denser phased GEMM the fp32 conv stack ran 452 instead of 423 us), in 6000-step runs on another
+//         box the conv stack ran 419 us behind either and phased won by 0.8 % (8.13 vs 8.06 M).  The kernel-level
+//         result is the stable one; it decides.
+static bool use_lockstep(bool /*bf16*/)
+{
+    static const bool v = getenv("DCE_GEMM") && strcmp(getenv("DCE_GEMM"), "lockstep") == 0;
+    return v;
+}
+
 template <bool BF16, bool OUT_BF16, int T> static hipError_t grant_phased()
 {
     using P = PhTile<T>;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<P::TM, P::TN, P::ROWB>::LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<P::TM, P::TN, P::ROWB>::LDS);
 }
 
 hipError_t init_fc_gemm_phased()
 {
     hipError_t e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<1, 1, 256>::LDS)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<true, false, 1, 1, 256, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<1, 1, 256>::LDS)) != hipSuccess) return e;
+    for (const void* k : {reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true, true>),
+                          reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true, false>),
+                          reinterpret_cast<const void*>(&fc_gemm_phased_kernel<true, false, 1, 1, 256, true, true>),
+                          reinterpret_cast<const void*>(&fc_gemm_phased_kernel<true, false, 1, 1, 256, true, false>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<1, 1, 256>::LDS)) != hipSuccess) return e;
     if ((e = grant_phased<false, false, 2>()) != hipSuccess) return e;
     if ((e = grant_phased<false, false, 1>()) != hipSuccess) return e;
     if ((e = grant_phased<true, true, 2>()) != hipSuccess) return e;
@@ -358,8 +422,12 @@ static hipError_t launch_phased_cfg(const void* A, const void* W, const float* b
     const int sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
-    hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB>), dim3(grid), dim3(512), Cfg::LDS, st,
-                       A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+    if (use_lockstep(BF16))
+        hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, true>), dim3(grid), dim3(512), Cfg::LDS, st,
+                           A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, nullptr, nullptr, 0ll);
+    else
+        hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, false>), dim3(grid), dim3(512), Cfg::LDS, st,
+                           A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, nullptr, nullptr, 0ll);
     return hipGetLastError();
 }
 
@@ -399,10 +467,13 @@ hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, co
     const int sn_log2 = 2, sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
-    if (bf16) hipLaunchKernelGGL((fc_gemm_phased_kernel<true, false, 1, 1, 256, true>), dim3(grid), dim3(512), Cfg::LDS, st,
-                                 h1, W2, b2, static_cast<void*>(h2_out), (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
-    else      hipLaunchKernelGGL((fc_gemm_phased_kernel<false, false, 1, 1, 256, true>), dim3(grid), dim3(512), Cfg::LDS, st,
-                                 h1, W2, b2, static_cast<void*>(h2_out), (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
+    void* h2v = static_cast<void*>(h2_out);
+    const long long pr = (long long)part_rows;
+#define FC23_LAUNCH(BF, LS) hipLaunchKernelGGL((fc_gemm_phased_kernel<BF, false, 1, 1, 256, true, LS>), dim3(grid), dim3(512), Cfg::LDS, st, \
+                                               h1, W2, b2, h2v, (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, pr)
+    if (bf16) { if (use_lockstep(true)) FC23_LAUNCH(true, true); else FC23_LAUNCH(true, false); }
+    else      { if (use_lockstep(false)) FC23_LAUNCH(false, true); else FC23_LAUNCH(false, false); }
+#undef FC23_LAUNCH
     return hipGetLastError();
 }
 

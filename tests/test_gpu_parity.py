@@ -625,13 +625,16 @@ def test_phased_gemm_equals_tile_kernels(n, precision, monkeypatch):
     ref_taps = old.forward_taps(x[:4096]) if precision == "fp32" else None
     old.close()
     monkeypatch.delenv("DCE_GEMM")
-    new = contact_cnn(device=0, max_batch=n, precision=precision); new.load_state_dict(sd)
-    for rep in range(4):
-        got = new.predict(x)
-        assert np.array_equal(got["logits"], ref["logits"]), (n, rep, np.abs(got["logits"] - ref["logits"]).max())
-        assert np.array_equal(got["pred"], ref["pred"])
-    if ref_taps is not None:
-        taps = new.forward_taps(x[:4096])
-        for k in ("h1", "h2", "logits"):
-            assert np.array_equal(taps[k], ref_taps[k]), k
-    new.close()
+    for sched in ("phased", "lockstep"):                     # both schedules of fc_gemm_phased.hip (phased ships; lockstep is the A/B variant)
+        monkeypatch.setenv("DCE_GEMM", sched)
+        new = contact_cnn(device=0, max_batch=n, precision=precision); new.load_state_dict(sd)
+        for rep in range(3):
+            got = new.predict(x)
+            assert np.array_equal(got["logits"], ref["logits"]), (n, sched, rep, np.abs(got["logits"] - ref["logits"]).max())
+            assert np.array_equal(got["pred"], ref["pred"])
+        if ref_taps is not None:
+            taps = new.forward_taps(x[:4096])
+            for k in ("h1", "h2", "logits"):
+                assert np.array_equal(taps[k], ref_taps[k]), (sched, k)
+        new.close()
+    monkeypatch.delenv("DCE_GEMM")
