@@ -30,7 +30,20 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef PH_TRACE
+#define PH_TRACE 0
+#endif
+
+
 namespace dce {
+
+#if PH_TRACE
+// debug build (-DPH_TRACE=1): s_memtime at four points of every phase pair, first 64 K-tiles, every wave of block 0
+__device__ unsigned long long g_ph_trace[8 * 64 * 4];
+#define PH_MARK(k) do { if (blockIdx.x == 0 && (tid & 63) == 0 && t < 64) g_ph_trace[(wid * 64 + t) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PH_MARK(k) do {} while (0)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -184,14 +197,26 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
     const int KT = (int)(rowb / ROWB);                   // >= 4 (checked by the launcher)
 
     // fragments of one K-tile: KQ x (TM + TN) x 16 bytes per lane
+    // LDS byte offsets of this lane's fragment columns, one set per buffer, made opaque so that they STAY in
+    // registers: recomputed inside the loop they are VALU instructions of the load phase, and a VALU instruction
+    // of the wave that shares a SIMD with a wave streaming MFMAs waits for that wave's next MFMA to issue
+    unsigned pa[PH_NBUF][KQ], pb[PH_NBUF][KQ];
+#pragma unroll
+    for (int b = 0; b < PH_NBUF; ++b)
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+            pa[b][kq] = b * Cfg::TILE + arow + fo[kq];
+            pb[b][kq] = b * Cfg::TILE + brow + fo[kq];
+            asm volatile("" : "+v"(pa[b][kq]), "+v"(pb[b][kq]));
+        }
+    // fragments of one K-tile: KQ x (TM + TN) x 16 bytes per lane; `b` must be a compile-time constant at every call
     auto load_frags = [&](int b, float4 (&af)[KQ][TM], float4 (&bf)[KQ][TN]) {
-        const char* tb = smem + b * Cfg::TILE;
 #pragma unroll
         for (int kq = 0; kq < KQ; ++kq) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[kq][a] = *reinterpret_cast<const float4*>(tb + arow + a * 32 * ROWB + fo[kq]);
+            for (int a = 0; a < TM; ++a) af[kq][a] = *reinterpret_cast<const float4*>(smem + pa[b][kq] + a * 32 * ROWB);
 #pragma unroll
-            for (int c = 0; c < TN; ++c) bf[kq][c] = *reinterpret_cast<const float4*>(tb + brow + c * 32 * ROWB + fo[kq]);
+            for (int c = 0; c < TN; ++c) bf[kq][c] = *reinterpret_cast<const float4*>(smem + pb[b][kq] + c * 32 * ROWB);
         }
     };
     auto math = [&](const float4 (&af)[KQ][TM], const float4 (&bf)[KQ][TN]) {
@@ -242,7 +267,7 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
                 const size_t ko = (size_t)(t + 3) * ROWB;
                 issue_tile<Cfg::NA, Cfg::NW>(lds_wave + (t % 3) * Cfg::TILE, sA + ko, sW + ko, voff);
             }
-            if (t + 1 < KT) load_frags((t + 1) % 3, afN, bfN);
+            if (t + 1 < KT) { const int nb = (t + 1) % 3; if (nb == 0) load_frags(0, afN, bfN); else if (nb == 1) load_frags(1, afN, bfN); else load_frags(2, afN, bfN); }
             __builtin_amdgcn_sched_barrier(0);           // the LDS reads go out ahead of the MFMAs, not behind them
             math(afC, bfC);
             phase_end<NG>(more);
@@ -270,8 +295,9 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
     //        means all but its six newest pieces have landed: group 0's pieces of t+2 are retired at the end of phase
     //        2t+2 (it issued t+3 at the start of that phase), group 1's at the end of phase 2t+3 -- both followed by
     //        a barrier before phase 2t+4.  Once nothing is left to issue (t+2 >= KT) the waits become vmcnt(0).
-    int buf = 0, nbuf = 2;                               // buffer of tile t / of tile t+2
-    for (int t = 0; t < KT; ++t) {
+    // (the loop is unrolled by three so that the buffer of every tile is a compile-time constant)
+    auto ktile = [&](int t, auto bufc) {
+        constexpr int buf = decltype(bufc)::value, nbuf = (buf + 2) % 3;     // buffer of tile t / of tile t+2
         // ---- load phase: loads of tile t+2, fragments of tile t
         const bool more = t + 2 < KT;
         if (more) {
@@ -279,13 +305,20 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
             issue_tile<Cfg::NA, Cfg::NW>(lds_wave + nbuf * Cfg::TILE, sA + ko, sW + ko, voff);
         }
         float4 af[KQ][TM], bf[KQ][TN];
+        PH_MARK(0);
         load_frags(buf, af, bf);
+        PH_MARK(1);
         phase_end<NG>(more);
         // ---- math phase
+        PH_MARK(2);
         math(af, bf);
+        PH_MARK(3);
         phase_end<NG>(more);
-        buf = buf == 2 ? 0 : buf + 1;
-        nbuf = nbuf == 2 ? 0 : nbuf + 1;
+    };
+    for (int t = 0; t < KT; t += 3) {
+        ktile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < KT) ktile(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < KT) ktile(t + 2, std::integral_constant<int, 2>{});
     }
     if (grp == 0) phase_end<NG>(false);                  // same number of barriers for both groups
     }
@@ -478,3 +511,10 @@ hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, co
 }
 
 }  // namespace dce
+
+#if PH_TRACE
+extern "C" int dce_debug_phase_trace_read(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dce::g_ph_trace), sizeof(unsigned long long) * 8 * 64 * 4);
+}
+#endif
