@@ -146,6 +146,9 @@ __device__ __forceinline__ Quad load_quad2(const float* __restrict__ ptr)
 __device__ __forceinline__ V4 wino_v(const Quad r)
 {
     V4 v;
+#if WINO_EXP & 8
+    v.a = r.p; v.b = r.q; return v;                      // timing probe: no transform VALU (WRONG results)
+#endif
 #if WINO_PK == 2
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v.a) : "v"(r.p), "v"(r.q));
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(v.b) : "v"(r.p), "v"(r.q));
