@@ -380,9 +380,10 @@ template <> struct PhTile<1> { static constexpr int TM = 1, TN = 1, ROWB = 256; 
 
 // Schedule: the two-groups-one-phase-apart loop ships for both precisions; DCE_GEMM=lockstep selects the other loop
 // (kept as a tested A/B variant).  Measured (r2q, interleaved rounds of the bench step):
-//   fp32: phased 569.9 us (fc.0) / 73.3 (fc.3), lockstep 589.3 / 77.3.  With all eight waves in step, both waves of
-//         every SIMD stand at the one barrier together; one phase apart, half of them are always early.
-//   bf16: phased 69-71 us (fc.0), lockstep 74-75.  End to end the two trade places with the board's clock governor:
+//   fp32: phased 529 us (fc.0) / 65 (fc.3), lockstep 600 / 82.  With all eight waves in step, both waves of every
+//         SIMD stand at the one barrier together -- and each wave's fragment reads sit inside its own MFMA stream;
+//         one phase apart, half of the waves are always early and a math phase is nothing but MFMAs.
+//   bf16: phased 68-71 us (fc.0), lockstep 74-75.  End to end the two trade places with the board's clock governor:
 //         in 3-second runs on one box the step was 5 % FASTER with the slower lockstep GEMM (7.89 vs 7.52 M windows/s:
 //         after the denser phased GEMM the fp32 conv stack ran 452 instead of 423 us), in 6000-step runs on another
 //         box the conv stack ran 419 us behind either and phased won by 0.8 % (8.13 vs 8.06 M).  The kernel-level
