@@ -47,7 +47,11 @@ static_assert(NW * 4 * 216 <= 8 * RS1 && (WRED_ROW * RS1) % 2 == 0, "z-score scr
 constexpr int MT = 2, NTW = 5;                               // row / column tiles per wave
 constexpr int WINO1_MAX_N = 256;                             // <= this many windows: conv_wino1_kernel (one window per workgroup)
 #ifndef WINO_EXP
-#define WINO_EXP 0           // bit flags for tools/micro/wino_loop.hip ablations; 0 in the product
+#define WINO_EXP 0           // bit flags for ablations / timing probes (tools/micro/wino_loop.hip); 0 in the product:
+                             //   2 no LDS reads, 4 one weight line, 8 no input-transform VALU, 16 no output-transform VALU
+#endif
+#ifndef WINO_PEEL
+#define WINO_PEEL 0
 #endif
 #ifndef WINO_INTERLEAVE
 #define WINO_INTERLEAVE 0    // 1: deal the input-transform ops of tile i+1 out between the MFMAs of tile i.  Measured (r2k, product
@@ -265,6 +269,18 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
     Quad rawb = load_quad2(xrow + boff[1]);               // raw of tile (0,1)
     // (peeling the first K-step pair would save these 160 moves per layer but costs more VGPRs
     //  than the 256 available at two workgroups per CU: measured 56 dwords of spill)
+#if WINO_PEEL
+    // the first K-step pair outside the loop, its first half with the accumulators taken from the literal 0 / the
+    // bias as the MFMAs' C operand: no 160 accumulator-init moves per layer
+    {
+        const A8 a_odd = load_a8<MT>(ap, 1);
+        wino_step<RS, true, MT, NTW>(xrow, xrow + 4 * RS, boff, a_even, vcur, rawb, acc, bias);
+        a_even = load_a8<MT>(ap, 2);
+        wino_step<RS, false, MT, NTW>(xrow + 4 * RS, xrow + 8 * RS, boff, a_odd, vcur, rawb, acc, bias);
+    }
+#pragma unroll 1
+    for (int s = 2; s < STEPS; s += 2) {
+#else
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -276,6 +292,7 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
         }
 #pragma unroll 1
     for (int s = 0; s < STEPS; s += 2) {
+#endif
         const int s2 = s + 2 < STEPS ? s + 2 : s;         // last iteration: harmless re-reads
         const A8 a_odd = load_a8<MT>(ap, s + 1);
         wino_step<RS, false, MT, NTW>(xrow + s * 4 * RS, xrow + (s + 1) * 4 * RS, boff, a_even, vcur, rawb, acc, bias);
@@ -355,8 +372,12 @@ __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const 
                     const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
                     const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
                     float* d = act + (co0 + 16 * mt + 4 * q + r) * RS + w * WSEG + 1 + 2 * m;
+#if WINO_EXP & 16
+                    d[0] = m0; d[1] = m1; asm volatile("" :: "v"(m2), "v"(m3));     // timing probe: no output-transform VALU (WRONG results)
+#else
                     d[0] = fmaxf((m0 + m1) + m2, 0.f);
                     d[1] = (T % 2 == 0 || 2 * m + 1 < T) ? fmaxf((m1 - m2) - m3, 0.f) : 0.f;   // index T+1 is a zero pad
+#endif
                 }
         }
     }
@@ -381,8 +402,12 @@ __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, 
                     const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
                     const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
                     // max(relu(y0), relu(y1)) = max(y0, y1, 0)
+#if WINO_EXP & 16
+                    act[(co0 + 16 * mt + 4 * q + r) * RS2 + w * WS2 + 1 + m] = m0; asm volatile("" :: "v"(m1), "v"(m2), "v"(m3));
+#else
                     act[(co0 + 16 * mt + 4 * q + r) * RS2 + w * WS2 + 1 + m] =
                         fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+#endif
                 }
         }
     }
@@ -395,21 +420,30 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
                                                 bool nan0, bool nan1)
 {
     const int j = lane & 15, q = lane >> 4;
+    // one 64-bit address per column tile; the 8 (row tile, r) outputs of a lane sit at compile-time offsets from it
+    // (global_store immediates): every VALU instruction outside the MFMA loops is paid for by the MFMA stream of
+    // the workgroup sharing the SIMDs
+    const float nanv = __builtin_nanf("");
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = 16 * nt + j;
         const int w = (NWIN > 1 && n >= TP2) ? 1 : 0;
         const int m = n - w * TP2;
         if (n < NWIN * TP2 && m < 37 && w < nvalid) {
+            FT* base = feat + (win0 + w) * FEAT + (co0 + 4 * q) * 37 + m;
+            const bool bad = w ? nan1 : nan0;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
                     const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
+#if WINO_EXP & 16
+                    const float v = m0; asm volatile("" :: "v"(m1), "v"(m2), "v"(m3));
+#else
                     const float v = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
-                    put_feat(feat + (win0 + w) * FEAT + (co0 + 16 * mt + 4 * q + r) * 37 + m,
-                             (w ? nan1 : nan0) ? __builtin_nanf("") : v);
+#endif
+                    put_feat(base + (16 * mt + r) * 37, bad ? nanv : v);
                 }
         }
     }

@@ -46,3 +46,32 @@ for k in np.unique(key)[:2]:
     print(f"CU key {k}: {len(idx)} blocks")
     for b in idx[:12]:
         print("   blk", b, "slot", wave[b], "start", t[b, 0] - t0, "phases", d[b].tolist())
+
+# ---- how the two co-resident workgroups of a CU overlap: time in (both MFMA) / (one MFMA) / (neither)
+def intervals(b):
+    # MFMA phases are d[1], d[3], d[5], d[7] -> [t1,t2], [t3,t4], [t5,t6], [t7,t8]
+    return [(t[b, 1], t[b, 2]), (t[b, 3], t[b, 4]), (t[b, 5], t[b, 6]), (t[b, 7], t[b, 8])]
+both = one = none = 0
+key8 = key * 8 + (np.arange(nb) % 8)      # HW_ID repeats on every XCD; workgroup b runs on XCD b % 8
+for k in np.unique(key8):
+    idx = np.where(key8 == k)[0]
+    if len(idx) < 4:
+        continue
+    ev = []
+    for b in idx:
+        for (a0, a1) in intervals(b):
+            ev.append((a0, +1)); ev.append((a1, -1))
+    lo, hi = t[idx, 0].min(), t[idx, 9].max()
+    # only spans where the kernel is running on this CU (trace holds several launches: split on big gaps)
+    ev.sort()
+    cur, last = 0, None
+    for (tt, dlt) in ev:
+        if last is not None and tt - last < 2_000_000:
+            span = tt - last
+            if cur >= 2: both += span
+            elif cur == 1: one += span
+            else: none += span
+        cur += dlt; last = tt
+tot = both + one + none
+print("groups", len(np.unique(key8)), "blocks per group", np.bincount(np.unique(key8, return_inverse=True)[1]).tolist()[:8])
+print(f"CU time with MFMA phases of: two workgroups {both / tot:.3f}, one {one / tot:.3f}, none {none / tot:.3f}")
