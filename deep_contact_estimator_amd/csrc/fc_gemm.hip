@@ -295,10 +295,17 @@ void fc_gemm_small_kernel(const float* __restrict__ Af, const float* __restrict_
 
     // ring slot of tile t = t % 4; four named register quads (a0, a1, b0, b1) per slot
     v4f q0a0, q0a1, q0b0, q0b1, q1a0, q1a1, q1b0, q1b1, q2a0, q2a1, q2b0, q2b1, q3a0, q3a1, q3b0, q3b1;
-#define GS_LD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
+    // wave-uniform 64-bit base (SGPRs, advanced by SALU) + constant 32-bit lane offsets: the K walk issues no VALU
+    // instruction (a VALU instruction here breaks the back-to-back MFMA stream of the block sharing the SIMDs --
+    // fc_gemm_phased.hip measured ~34 matrix-pipe cycles per add)
+    const char* sAb = A + (size_t)m0 * rowb;
+    const char* sWb = W + (size_t)n0 * rowb;
+    const unsigned oa0 = (unsigned)((size_t)(r0 - m0) * rowb + 16 * sk4), oa1 = (unsigned)((size_t)(r1 - m0) * rowb + 16 * sk4);
+    const unsigned ob0 = (unsigned)((size_t)srow * rowb + 16 * sk4), ob1 = (unsigned)((size_t)(srow + RPP) * rowb + 16 * sk4);
+#define GS_LD(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase))
 #define GS_LOAD(S, tile)                                                                          \
     { const size_t ko = (size_t)((tile) < KT ? (tile) : KT - 1) * KT_BYTES;                       \
-      GS_LD(q##S##a0, ag0 + ko); GS_LD(q##S##a1, ag1 + ko); GS_LD(q##S##b0, bg0 + ko); GS_LD(q##S##b1, bg1 + ko); }
+      GS_LD(q##S##a0, oa0, sAb + ko); GS_LD(q##S##a1, oa1, sAb + ko); GS_LD(q##S##b0, ob0, sWb + ko); GS_LD(q##S##b1, ob1, sWb + ko); }
     GS_LOAD(1, 1) GS_LOAD(2, 2) GS_LOAD(3, 3)
     __syncthreads();
 
