@@ -420,11 +420,13 @@ hipError_t init_fc_gemm_phased()
     return grant_phased<true, false, 1>();
 }
 
-// Tile choice: 256 x 128 when those tiles alone fill the chip (>= 192 of them), else 128 x 64 when THOSE do;
+// Tile choice: 256 x 128 when those tiles alone fill the chip (>= 192 of them), else 128 x 64 from 128 tiles up;
 // 0 = this shape stays on the tile kernels of fc_gemm.hip.  DCE_GEMM=tile forces 0 (A/B).
 static int phased_tile(int64_t M, int N, int K, int es)
 {
     static const bool off = getenv("DCE_GEMM") && strcmp(getenv("DCE_GEMM"), "tile") == 0;
+    static const int min_tiles = getenv("DCE_PHASED_MIN_TILES") ? atoi(getenv("DCE_PHASED_MIN_TILES")) : 192;
+    static const int min_tiles1 = getenv("DCE_PHASED_MIN_TILES1") ? atoi(getenv("DCE_PHASED_MIN_TILES1")) : 128;
     static const int tmin = getenv("DCE_GEMM_PHASED_MIN") ? atoi(getenv("DCE_GEMM_PHASED_MIN")) : 1;   // 2: only the 256x128 tile
     if (off || (size_t)K * es % 256 || (size_t)K * es < 3 * 256 || M > (1 << 30)) return 0;
     if ((size_t)256 * K * es + 128 >= (1ull << 32)) return 0;                     // per-lane offsets are 32-bit
@@ -433,7 +435,9 @@ static int phased_tile(int64_t M, int N, int K, int es)
         if (N % bn) continue;
         const int nt = N / bn;
         if ((nt & (nt - 1)) != 0) continue;                                       // super-tile map wants a power of two
-        if (((M + bm - 1) / bm) * nt >= 192) return t;
+        // 256 x 128 tiles must fill the chip; the 128 x 64 tile still beats the tile kernels on half of it
+        // (fc.0 at 512 windows: 128 tiles, 139 vs 160 us; at 64 tiles it loses, 135 vs 95 us)
+        if (((M + bm - 1) / bm) * nt >= (t == 2 ? min_tiles : min_tiles1)) return t;
     }
     return 0;
 }
