@@ -48,7 +48,8 @@ constexpr int MT = 2, NTW = 5;                               // row / column til
 constexpr int WINO1_MAX_N = 256;                             // <= this many windows: conv_wino1_kernel (one window per workgroup)
 #ifndef WINO_EXP
 #define WINO_EXP 0           // bit flags for ablations / timing probes (tools/micro/wino_loop.hip); 0 in the product:
-                             //   2 no LDS reads, 4 one weight line, 8 no input-transform VALU, 16 no output-transform VALU
+                             //   2 no LDS reads, 4 one weight line, 8 no input-transform VALU, 16 no output-transform VALU,
+                             //   32 no NaN/Inf scan in the prologue, 64 every workgroup loads windows 0,1 (L2-hot source)
 #endif
 #ifndef WINO_PEEL
 #define WINO_PEEL 0
@@ -481,19 +482,31 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
     {
         float x[NW][38];
         const int64_t wstride = ZS ? CH : (int64_t)WIN * CH;
+        TRACE_MARK(11);
+#if WINO_EXP & 64
+        load_windows<ZS, NW>(src, wstride, nvalid, act + WRED_ROW * RS1, x, tid);     // probe: every workgroup reads windows 0, 1 (L2-hot)
+#else
         load_windows<ZS, NW>(src + win0 * wstride, wstride, nvalid, act + WRED_ROW * RS1, x, tid);
+#endif
         // ReLU runs as v_max_f32 (which drops NaN), so NaN / Inf semantics are carried per WINDOW:
         // torch turns any non-finite input sample into all-NaN logits (every fc.0 output sums over
         // every feature); here such a window gets all-NaN features at the end instead.
         bool bad0 = false, bad1 = false;
+#if !(WINO_EXP & 32)
 #pragma unroll
         for (int m = 0; m < 38; ++m) {
             bad0 |= !(fabsf(x[0][m]) <= 3.0e38f);
             bad1 |= !(fabsf(x[1][m]) <= 3.0e38f);
         }
+#endif
+#if DCE_TRACE
+        asm volatile("" :: "v"(bad0), "v"(bad1));
+#endif
+        TRACE_MARK(12);
         __syncthreads();                         // flags were zeroed at kernel entry; also orders the
         if (bad0) nanflag[0] = 1;                // z-score scratch reads before the pad zeroing of
         if (bad1) nanflag[1] = 1;                // rows 56.. below
+        TRACE_MARK(13);
         if (tid < 4 * CH) {
             const int c = tid % CH, g = tid / CH;
 #pragma unroll
@@ -512,6 +525,7 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
         }
         for (int i = tid; i < 2 * RS1; i += 256) act[CH * RS1 + i] = 0.f;
     }
+    TRACE_MARK(14);
     __syncthreads();
     TRACE_MARK(1);
     const bool nan0 = __builtin_amdgcn_readfirstlane(nanflag[0]) != 0;

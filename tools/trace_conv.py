@@ -31,6 +31,11 @@ d = np.diff(t, axis=1)
 print("phase durations (cycles): mean / p10 / p90")
 for i, nme in enumerate(names):
     print(f"  {nme:9s} {d[:, i].mean():9.0f} {np.percentile(d[:, i], 10):9.0f} {np.percentile(d[:, i], 90):9.0f}")
+if buf[:, 11].any():
+    sub = buf[:, [0, 11, 12, 13, 14, 1]].astype(np.int64)
+    ds = np.diff(sub, axis=1)
+    for i, nme in enumerate(["bias copy", "loads + NaN scan", "barrier", "LDS transpose stores", "barrier"]):
+        print(f"    prologue / {nme:22s} {ds[:, i].mean():9.0f} {np.percentile(ds[:, i], 10):9.0f} {np.percentile(ds[:, i], 90):9.0f}")
 tot = t[:, 9] - t[:, 0]
 print("block total", tot.mean(), "kernel span", t[:, 9].max() - t0)
 mf = d[:, [1, 3, 5, 7]].sum(axis=1)
