@@ -188,7 +188,8 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
     } else {
         { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream, c->src_row_dev)); }
         // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
-        auto fc = (c->gemv && n <= FC_GEMV_MAX_M) ? launch_fc_gemv : launch_fc_gemm;
+        // (from 9 windows up launch_fc_gemm picks the MFMA chain kernel of fc_gemm_chain.hip instead)
+        auto fc = (c->gemv && n <= FC_GEMV_MAX_M && !fc_gemm_chain_ok(n, FC1, FEAT)) ? launch_fc_gemv : launch_fc_gemm;
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
         if (fc23_fused_ok(n, 0)) {
             // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU

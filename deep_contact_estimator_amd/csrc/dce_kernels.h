@@ -56,6 +56,14 @@ constexpr int FC_GEMV_MAX_M = 32;
 hipError_t launch_fc_gemv(const float* A, const float* W, const float* bias, float* C,
                           int64_t M, int N, int K, int relu, hipStream_t st);
 
+// The same layers for 9 .. a few hundred windows (fc_gemm_chain.hip): one 16x16 output tile per wave on
+// v_mfma_f32_16x16x4_f32, one wave per SIMD -- bound by the length of an output's fma chain, not by throughput.
+// Bit-identical to the other fp32 FC kernels (same K order).  N % 32 == 0, K % 128 == 0.
+hipError_t init_fc_gemm_chain();
+bool       fc_gemm_chain_ok(int64_t M, int N, int K);
+hipError_t launch_fc_gemm_chain(const float* A, const float* W, const float* bias, float* C,
+                                int64_t M, int N, int K, int relu, hipStream_t st);
+
 // Same GEMM on bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate): A[M,K], W[N,K] bf16,
 // C fp32 or bf16 (out_bf16).  N % 128 == 0, K % 64 == 0.  DCE_BF16_FC precision only.
 hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int out_bf16,
