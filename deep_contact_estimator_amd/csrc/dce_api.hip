@@ -191,7 +191,7 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         // (from 9 windows up launch_fc_gemm picks the MFMA chain kernel of fc_gemm_chain.hip instead)
         auto fc = (c->gemv && n <= FC_GEMV_MAX_M && !fc_gemm_chain_ok(n, FC1, FEAT)) ? launch_fc_gemv : launch_fc_gemm;
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
-        if (fc23_fused_ok(n, 0)) {
+        if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1)) {
             // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU
             // unless a tap asks for it); one small kernel adds them up.  Same summation tree as the tail kernel.
             { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch,

@@ -409,9 +409,9 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
     if (M <= 0) return hipSuccess;
     if (N % 128 || K % 32 || M > (1 << 30)) return hipErrorInvalidValue;
     // chip-filling sizes: one phased workgroup per CU (fc_gemm_phased.hip); same K order, same bits
-    if (fc_gemm_phased_ok(M, N, K, 0)) return launch_fc_gemm_phased(A, W, bias, C, 0, 0, M, N, K, relu, st);
     // a few dozen to a few hundred windows: chain-latency kernel, one 16x16 tile per wave (fc_gemm_chain.hip)
     if (fc_gemm_chain_ok(M, N, K)) return launch_fc_gemm_chain(A, W, bias, C, M, N, K, relu, st);
+    if (fc_gemm_phased_ok(M, N, K, 0)) return launch_fc_gemm_phased(A, W, bias, C, 0, 0, M, N, K, relu, st);
     // (In between, a no-LDS kernel -- one 16x16 / 32x32 output tile per wave on v_mfma_f32_16x16x4_f32, operands streamed
     //  from L2 straight into MFMA registers, bit-identical -- was built and measured in round 2: 1.4x - 3.2x SLOWER than the
     //  tile kernels below at 64 .. 2048 windows (fc.0 at 512 windows 518 vs 162 us: fragment-shaped 16-B-per-row loads keep

@@ -11,8 +11,11 @@
 // So: one 16x16 output tile per wave, ONE wave per SIMD (a second wave on the SIMD would halve each chain's speed), a
 // workgroup of four waves = a 32 x 32 block of C, operands streamed through registers (a ring of K chunks in flight, as in
 // the GEMV kernel) into a double-buffered LDS image.  fc.0 for up to 128 windows is 1024 chains on 1024 SIMDs: 17 us of
-// chain, where the GEMV kernel takes 39 us at 30 windows (it is LDS-bound: every fma reads both operands from LDS; an MFMA
-// reads 512 B for 1024 of them) and the 64x64 tile GEMM 93 us at 64 .. 256 windows.
+// chain, 30.5 us per launch measured (profiles/r2z_latency.txt), where the GEMV kernel takes 39 us at 30 windows (it is
+// LDS-bound: every fma reads both operands from LDS; an MFMA reads 512 B for 1024 of them) and the 64x64 tile GEMM 93 us at
+// 64 .. 256 windows.  What is left above the chain is the staging work that issues in order with it (timing probes: no LDS
+// stores 23.1 us, no ring refills 24.7 us, neither 22.3 us); staging in four waves of their own (8 waves per workgroup,
+// 128 KB LDS) measured slower (33.8 us), ds_write2_b32 stores without the register shuffles too (4-way conflicts, 32.6 us).
 //
 // K order = that of every other FC kernel of the library (0,4,1,5,2,6,3,7 inside each 8 consecutive k, chunks ascending,
 // start from 0, bias added last): v_mfma_f32_16x16x4_f32 accumulates its four k in lane-group order, so the first MFMA of a
@@ -194,12 +197,17 @@ hipError_t init_fc_gemm_chain()
                                hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES);
 }
 
-// window counts served by this kernel: [DCE_CHAIN_MIN (9), DCE_CHAIN_MAX (256)]; 0 as DCE_CHAIN_MAX switches it off
+// window counts served by this kernel: fc.0 (K = 4736) [DCE_CHAIN_MIN (9), DCE_CHAIN_MAX (640)], fc.3 (K = 2048)
+// [DCE_CHAIN_MIN, DCE_CHAIN_MAX3 (2048)]; 0 as a maximum switches it off for that layer.  Measured (r2z): two
+// workgroups fit a CU, a "round" of 512 workgroups takes ~45 us for fc.0 and ~12 us for fc.3, so fc.0 (64 workgroups per
+// 32 windows) beats the 137 us of one round of 128x64 phased tiles up to 2.5 rounds, and fc.3 (16 per 32 windows) beats
+// the fused 64x... phased kernel (71 us incl. combine) up to 2048 windows (47 + 7.5 us with the tail kernel).
 bool fc_gemm_chain_ok(int64_t M, int N, int K)
 {
     static const int64_t lo = getenv("DCE_CHAIN_MIN") ? atoll(getenv("DCE_CHAIN_MIN")) : 9;
-    static const int64_t hi = getenv("DCE_CHAIN_MAX") ? atoll(getenv("DCE_CHAIN_MAX")) : 256;
-    return M >= lo && M <= hi && N % 32 == 0 && (K == FEAT || K == FC1);
+    static const int64_t hi = getenv("DCE_CHAIN_MAX") ? atoll(getenv("DCE_CHAIN_MAX")) : 640;
+    static const int64_t hi3 = getenv("DCE_CHAIN_MAX3") ? atoll(getenv("DCE_CHAIN_MAX3")) : 2048;
+    return M >= lo && M <= (K == FEAT ? hi : hi3) && N % 32 == 0 && (K == FEAT || K == FC1);
 }
 
 hipError_t launch_fc_gemm_chain(const float* A, const float* W, const float* bias, float* C,

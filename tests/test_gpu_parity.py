@@ -102,24 +102,28 @@ def test_forward_windows_vs_oracle(n, models, orc):
     tol_ok(m(x), ref["logits"], "__call__")
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 8, 9, 16, 17, 30, 32, 100, 256])
-def test_small_batch_kernels_are_bit_identical(n, models):
-    """<= 32 windows (batch_size 1 and 30 of the reference's configs) take the weight-streaming GEMV kernels (csrc/fc_gemv.hip); they walk K in the
-    order the MFMA GEMM does, so every FC activation and logit must equal, bit for bit, the rows the
-    same windows get inside a large batch (MFMA tiles).  Likewise <= 256 windows take the
-    one-window-per-workgroup conv kernel (conv_wino1_kernel): same per-accumulator K order, so the
-    features are the bits of the two-window kernel."""
-    rng = np.random.default_rng(900 + n)
-    x = rng.standard_normal((300, 150, 54), dtype=np.float32)
-    m = models()
-    big, small = m.forward_taps(x), m.forward_taps(x[:n])
+@pytest.fixture(scope="module")
+def big_batch_taps(models):
+    """3000 windows through the chip-filling kernels (two-window conv kernel, phased 256x128 fc.0, fused phased fc.3 +
+    fc.6 chunk sums): the bits every smaller batch has to reproduce."""
+    x = np.random.default_rng(900).standard_normal((3000, 150, 54), dtype=np.float32)
+    return x, models(max_batch=4096).forward_taps(x)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 8, 9, 16, 17, 30, 31, 32, 33, 63, 64, 65, 100, 128, 129, 255, 256, 257, 300,
+                               512, 640, 641, 1000, 1024, 2048, 2049])
+def test_small_batch_kernels_are_bit_identical(n, models, big_batch_taps):
+    """<= 8 windows (batch_size 1 of the reference's configs) take the weight-streaming GEMV kernel (csrc/fc_gemv.hip);
+    from 9 windows (batch_size 30) the MFMA chain kernel (csrc/fc_gemm_chain.hip: one 16x16 tile per wave on
+    v_mfma_f32_16x16x4_f32, operands permuted in LDS) runs fc.0 up to 640 and fc.3 up to 2048 windows, with the 64x64 /
+    128x64 tile kernels behind it; all walk K in the order the chip-filling GEMMs do, so every FC activation and logit
+    must equal, bit for bit, the rows the same windows get inside a batch of 3000.  Likewise <= 256 windows take the
+    one-window-per-workgroup conv kernel (conv_wino1_kernel): same per-accumulator K order, so the features are the
+    bits of the two-window kernel (257: its odd tail)."""
+    x, big = big_batch_taps
+    small = models(max_batch=4096).forward_taps(x[:n])
     for k in ("feat", "h1", "h2", "logits"):
         assert np.array_equal(small[k], big[k][:n]), k
-    # 33 windows are back on the GEMM (64x64 tiles), 257 on the two-window conv kernel with an odd
-    # tail: same bits again
-    for k in (33, 257):
-        more = m.forward_taps(x[:k])
-        assert np.array_equal(more["feat"], big["feat"][:k]) and np.array_equal(more["logits"], big["logits"][:k])
 
 
 def test_chunking_and_determinism(models, orc):
