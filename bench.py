@@ -286,6 +286,27 @@ def extra_streaming(torch, contact_cnn, sd, dev, n_windows=1_000_000):
     }
 
 
+def extra_small_batches(torch, model, windows, sizes=(1, 30, 64, 256, 512, 1024)):
+    """BASELINE configs[0]'s shapes on the GPU: the reference ships batch_size 1 (inference_one_seq_params.yaml) and 30
+    (test_params.yaml); per-call latency of model.predict on a device-resident batch, fp32, and the mid-size batches
+    between them and the bench step.  (cpu_baseline.protocol holds the CPU loops at the same two batch sizes.)"""
+    res = {}
+    for b in sizes:
+        xb = windows[:b].contiguous()
+        for _ in range(20):
+            model.predict(xb)
+        torch.cuda.synchronize()
+        n = 200
+        t0 = time.perf_counter()
+        for _ in range(n):
+            model.predict(xb)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        res[str(b)] = {"us_per_call": dt * 1e6, "windows_per_s": b / dt}
+    return {"workload": "model.predict on b pre-normalised device-resident windows, fp32 (GEMV <= 8, MFMA chain kernel 9..640/2048, "
+                        "one-window conv kernel <= 256 windows)", "batches": res}
+
+
 def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s=1.5):
     """BASELINE configs[4]: fc.0 / fc.3 on bf16 MFMA (fp32 accumulate), conv stack and fc.6 fp32."""
     m = contact_cnn(device=dev.index, max_batch=B, precision="bf16_fc")
@@ -524,6 +545,7 @@ def main():
                 res["extra"] = {"sharded_1e6": sh}
         elif args.precision == "fp32":
             res["extra"] = {
+                "small_batches": extra_small_batches(torch, model, windows),
                 "streaming_1e6": extra_streaming(torch, contact_cnn, sd, dev),
                 "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s),
             }
