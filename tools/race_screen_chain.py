@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Race screen for the MFMA chain kernel (fc_gemm_chain.hip: a register ring of asm loads, a double-buffered LDS image,
+one barrier per chunk): repeated runs at the window counts it serves must return the same bits every time -- and the bits
+of a run with the kernel switched off (DCE_CHAIN_MAX=0, DCE_CHAIN_MAX3=0: GEMV / tile kernels) -- also while a second
+stream keeps the memory system busy (uneven load shifts the landing times of the ring's loads)."""
+import json, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SIZES = [9, 30, 33, 64, 255, 256, 300, 640, 1024, 2048]
+
+
+def child(reps):
+    import torch
+    from deep_contact_estimator_amd import contact_cnn, synth
+    m = contact_cnn(device=0, max_batch=2048); m.load_state_dict(synth.make_state_dict(1, "uniform"))
+    noise_src = torch.empty(64 << 20, dtype=torch.uint8, device="cuda"); noise_dst = torch.empty_like(noise_src)
+    side = torch.cuda.Stream()
+    out = {}
+    for n in SIZES:
+        x = torch.randn((n, 150, 54), generator=torch.Generator(device="cuda").manual_seed(n), device="cuda")
+        ref = m.predict(x)["logits"].clone()
+        bad = 0
+        for r in range(reps):
+            if r % 2:
+                with torch.cuda.stream(side):
+                    noise_dst.copy_(noise_src, non_blocking=True)
+            bad += int(not torch.equal(m.predict(x)["logits"], ref))
+        torch.cuda.synchronize()
+        out[str(n)] = {"mismatching_runs": bad, "sha": __import__("hashlib").sha1(ref.cpu().numpy().tobytes()).hexdigest()}
+    print("RESULT " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "child":
+        child(int(sys.argv[2])); sys.exit(0)
+    reps = int(os.environ.get("REPS", 300))
+    res = {}
+    for tag, env in (("chain", {}), ("off", {"DCE_CHAIN_MAX": "0", "DCE_CHAIN_MAX3": "0"})):
+        p = subprocess.run([sys.executable, __file__, "child", str(reps if tag == "chain" else 2)], env=dict(os.environ, **env),
+                           capture_output=True, text=True)
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+        assert p.returncode == 0 and line, p.stderr[-2000:]
+        res[tag] = json.loads(line[-1][7:])
+    total = sum(v["mismatching_runs"] for v in res["chain"].values())
+    same = all(res["chain"][k]["sha"] == res["off"][k]["sha"] for k in res["chain"])
+    print(json.dumps({"sizes": SIZES, "reps_per_size": reps, "mismatching_runs": total, "bits_equal_kernel_off": same}))
+    sys.exit(0 if total == 0 and same else 1)
