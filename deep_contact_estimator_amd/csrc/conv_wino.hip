@@ -54,6 +54,9 @@ constexpr int WINO1_MAX_N = 256;                             // <= this many win
 #ifndef WINO_PEEL
 #define WINO_PEEL 0
 #endif
+#ifndef WINO1_PF
+#define WINO1_PF 8           // one-window kernels: weight prefetch depth, K-steps
+#endif
 #ifndef WINO_INTERLEAVE
 #define WINO_INTERLEAVE 0    // 1: deal the input-transform ops of tile i+1 out between the MFMAs of tile i.  Measured (r2k, product
                              // kernel, 3 interleaved rounds): 442.4 us vs 427.0 us bunched -- an op between two MFMAs costs more than
@@ -602,6 +605,7 @@ void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
     const int j = lane & 15, q = lane >> 4;
     const int64_t win0 = blockIdx.x;
     if (win0 >= n) return;
+    TRACE_MARK(0);
 
     for (int i = tid; i < 384; i += 256) {
         const int l = i < 64 ? 0 : (i < 128 ? 1 : (i < 256 ? 2 : 3));
@@ -611,9 +615,6 @@ void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
     int* nanflag = reinterpret_cast<int*>(act + WACT_FLOATS + 384);
     if (tid == 0) nanflag[0] = 0;
     // conv1's first PF K-steps of weights are requested before the window itself
-#ifndef WINO1_PF
-#define WINO1_PF 8
-#endif
     constexpr int PF = WINO1_PF;                          // weight prefetch depth, K-steps
     A8 ring[PF];
     const float4* ap1 = reinterpret_cast<const float4*>(pk.ww[0]) + (wv >> 1) * (14 * 128) + 2 * lane + (wv & 1);
@@ -640,6 +641,7 @@ void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
         for (int i = tid; i < 2 * RS1; i += 256) act[CH * RS1 + i] = 0.f;                          // channels 54, 55
     }
     __syncthreads();
+    TRACE_MARK(1);
     const bool nan0 = __builtin_amdgcn_readfirstlane(nanflag[0]) != 0;
     const float* bias_lds = act + WACT_FLOATS;
     const float* xrow1 = act + q * RS1;
@@ -653,10 +655,13 @@ void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
         const int co0 = 16 * wv;
         col_offsets<TP1, WS1, 5, 1>(0, j, boff);
         wino_mfma_deep<RS1, 14, 1, 5, PF, 1, 0>(xrow1, boff, ap1, ap2, ring, bias_lds, co0, lane, acc);
+        TRACE_MARK(2);
         __syncthreads();
         wino_store_plain<RS1, WS1, TP1, 150, 1, 5, 1>(act, acc, co0, 0, lane);
         __syncthreads();
+        TRACE_MARK(3);
         wino_mfma_deep<RS1, 16, 1, 5, PF, 2, 14 % PF>(xrow1, boff, ap2, ap3, ring, bias_lds + 64, co0, lane, acc);
+        TRACE_MARK(4);
         __syncthreads();
         wino_store_pool_stage2<1, 5, 1>(act, acc, co0, 0, lane);
         for (int i = tid; i < 128 * 3; i += 256) {       // stage-2 pads: index 0, 76, 77
@@ -670,12 +675,135 @@ void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
         const int co2 = 32 * wv;
         col_offsets<TP2, WS2, 3, 1>(0, j, boff);
         __syncthreads();
+        TRACE_MARK(5);
         wino_mfma_deep<RS2, 16, 2, 3, PF, 2, 30 % PF>(xrow2, boff, ap3, ap4, ring, bias_lds + 128, co2, lane, acc);
+        TRACE_MARK(6);
         __syncthreads();
         wino_store_plain<RS2, WS2, TP2, 75, 2, 3, 1>(act, acc, co2, 0, lane);
         __syncthreads();
+        TRACE_MARK(7);
         wino_mfma_deep<RS2, 32, 2, 3, PF, 2, 46 % PF>(xrow2, boff, ap4, nullptr, ring, bias_lds + 256, co2, lane, acc);
+        TRACE_MARK(8);
         wino_store_feat<float, 2, 3, 1>(feat, win0, 1, acc, co2, lane, nan0, false);
+        TRACE_MARK(9);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same one-window kernel on EIGHT waves (two per SIMD).  A workgroup that is alone on its CU runs its MFMA
+// phases at 67 % (stage 1) / 78 % (stage 2) of the pipe rate with one wave per SIMD (tools/trace_conv1.py: 75.7k cycles
+// for 56.1k of matrix-pipe work) -- the wave's own transform VALU, LDS reads and waits issue in order with its MFMAs.
+// A second wave on the SIMD fills those gaps (tools/micro/wino_loop.hip: 91 -> 100 %).  Tiling, so that the two waves
+// of a SIMD (w and w+4) together carry what one carried before:
+//   stage 1: wave (row tile w&3, column group w>>2): column tiles {0,1,2} / {3,4}
+//   stage 2: wave = row tile w (16 of the 128 output channels) x all 3 column tiles
+// (row-tile PAIRS x column groups {0,1} / {2} would halve stage 2's transform VALU per MFMA, but the software pipeline
+//  of wino_step needs at least two column tiles per wave)
+// Same LDS layout, same per-accumulator K order: bit-identical features.
+// ------------------------------------------------------------------------------------------
+template <int NTW1>
+__device__ __forceinline__ void wino1x8_stage1(float* __restrict__ act, const float* __restrict__ bias_lds,
+                                               const float4* ap1, const float4* ap2, const float4* ap3, A8 (&ring)[WINO1_PF],
+                                               int rt, int nt0, int lane, int tid)
+{
+    constexpr int PF = WINO1_PF;
+    const int j = lane & 15, q = lane >> 4;
+    const float* xrow1 = act + q * RS1;
+    f32x4 acc[1][NTW1][4];
+    int boff[NTW1];
+    const int co0 = 16 * rt;
+    col_offsets<TP1, WS1, NTW1, 1>(nt0, j, boff);
+    wino_mfma_deep<RS1, 14, 1, NTW1, PF, 1, 0>(xrow1, boff, ap1, ap2, ring, bias_lds, co0, lane, acc);
+    TRACE_MARK(2);
+    __syncthreads();
+    wino_store_plain<RS1, WS1, TP1, 150, 1, NTW1, 1>(act, acc, co0, nt0, lane);
+    __syncthreads();
+    TRACE_MARK(3);
+    wino_mfma_deep<RS1, 16, 1, NTW1, PF, 1, 14 % PF>(xrow1, boff, ap2, ap3, ring, bias_lds + 64, co0, lane, acc);
+    TRACE_MARK(4);
+    __syncthreads();
+    wino_store_pool_stage2<1, NTW1, 1>(act, acc, co0, nt0, lane);
+    for (int i = tid; i < 128 * 3; i += 512) {           // stage-2 pads: index 0, 76, 77
+        const int c = i / 3, k = i % 3;
+        act[c * RS2 + (k == 0 ? 0 : 75 + k)] = 0.f;
+    }
+}
+
+template <bool ZS>
+__global__ __launch_bounds__(512)
+void conv_wino1x8_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat,
+                         const long long* __restrict__ src_row)
+{
+    extern __shared__ __attribute__((aligned(16))) float act[];
+    if (src_row) src += *src_row * CH;                    // online graph: the window start lives in device memory
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t win0 = blockIdx.x;
+    if (win0 >= n) return;
+    TRACE_MARK(0);
+
+    for (int i = tid; i < 384; i += 512) {
+        const int l = i < 64 ? 0 : (i < 128 ? 1 : (i < 256 ? 2 : 3));
+        const int o = i < 64 ? i : (i < 128 ? i - 64 : (i < 256 ? i - 128 : i - 256));
+        act[WACT_FLOATS + i] = pk.b[l][o];
+    }
+    int* nanflag = reinterpret_cast<int*>(act + WACT_FLOATS + 384);
+    if (tid == 0) nanflag[0] = 0;
+    constexpr int PF = WINO1_PF;                          // weight prefetch depth, K-steps
+    A8 ring[PF];
+    const int rt = wv & 3;                                // stage 1: row tile; the packed weights hold row-tile PAIRS
+    const float4* ap1 = reinterpret_cast<const float4*>(pk.ww[0]) + (rt >> 1) * (14 * 128) + 2 * lane + (rt & 1);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = load_a8<1>(ap1, i);
+    {
+        float x[1][38];
+        const int64_t wstride = ZS ? CH : (int64_t)WIN * CH;
+        // (the load helper maps threads 0..215 to (row group, channel); the other threads' loads are never stored)
+        load_windows<ZS, 1>(src + win0 * wstride, wstride, 1, act + WRED_ROW * RS1, x, tid < 256 ? tid : 255);
+        bool bad0 = false;
+#pragma unroll
+        for (int m = 0; m < 38; ++m) bad0 |= !(fabsf(x[0][m]) <= 3.0e38f);
+        __syncthreads();
+        if (bad0 && tid < 4 * CH) nanflag[0] = 1;
+        if (tid < 4 * CH) {
+            const int c = tid % CH, g = tid / CH;
+#pragma unroll
+            for (int m = 0; m < 38; ++m) {
+                const int t = 4 * m + g;
+                if (t < WIN) act[c * RS1 + 1 + t] = x[0][m];
+            }
+        }
+        for (int i = tid; i < 64 * 2; i += 512) act[(i >> 1) * RS1 + (i & 1) * (WS1 - 1)] = 0.f;   // x[-1], x[150]
+        for (int i = tid; i < 2 * RS1; i += 512) act[CH * RS1 + i] = 0.f;                          // channels 54, 55
+    }
+    __syncthreads();
+    TRACE_MARK(1);
+    const bool nan0 = __builtin_amdgcn_readfirstlane(nanflag[0]) != 0;
+    const float* bias_lds = act + WACT_FLOATS;
+    const float4* ap2 = reinterpret_cast<const float4*>(pk.ww[1]) + (rt >> 1) * (16 * 128) + 2 * lane + (rt & 1);
+    const float4* ap3 = reinterpret_cast<const float4*>(pk.ww[2]) + (wv >> 1) * (16 * 128) + 2 * lane + (wv & 1);
+    const float4* ap4 = reinterpret_cast<const float4*>(pk.ww[3]) + (wv >> 1) * (32 * 128) + 2 * lane + (wv & 1);
+    if (wv < 4) wino1x8_stage1<3>(act, bias_lds, ap1, ap2, ap3, ring, rt, 0, lane, tid);
+    else        wino1x8_stage1<2>(act, bias_lds, ap1, ap2, ap3, ring, rt, 3, lane, tid);
+    {   // ---- stage 2: wave = row tile wv (16 output channels) x 3 column tiles
+        const int j = lane & 15, q = lane >> 4;
+        const float* xrow2 = act + q * RS2;
+        f32x4 acc[1][3][4];
+        int boff[3];
+        const int co2 = 16 * wv;
+        col_offsets<TP2, WS2, 3, 1>(0, j, boff);
+        __syncthreads();
+        TRACE_MARK(5);
+        wino_mfma_deep<RS2, 16, 1, 3, PF, 1, 30 % PF>(xrow2, boff, ap3, ap4, ring, bias_lds + 128, co2, lane, acc);
+        TRACE_MARK(6);
+        __syncthreads();
+        wino_store_plain<RS2, WS2, TP2, 75, 1, 3, 1>(act, acc, co2, 0, lane);
+        __syncthreads();
+        TRACE_MARK(7);
+        wino_mfma_deep<RS2, 32, 1, 3, PF, 1, 46 % PF>(xrow2, boff, ap4, nullptr, ring, bias_lds + 256, co2, lane, acc);
+        TRACE_MARK(8);
+        wino_store_feat<float, 1, 3, 1>(feat, win0, 1, acc, co2, lane, nan0, false);
+        TRACE_MARK(9);
     }
 }
 
@@ -701,7 +829,8 @@ hipError_t init_conv_wino()
     if ((e = grant_wino_lds<false, float>()) != hipSuccess) return e;
     if ((e = grant_wino_lds<true, unsigned short>()) != hipSuccess) return e;
     if ((e = grant_wino_lds<false, unsigned short>()) != hipSuccess) return e;
-    for (const void* k : {reinterpret_cast<const void*>(&conv_wino1_kernel<true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false>)})
+    for (const void* k : {reinterpret_cast<const void*>(&conv_wino1_kernel<true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false>),
+                          reinterpret_cast<const void*>(&conv_wino1x8_kernel<true>), reinterpret_cast<const void*>(&conv_wino1x8_kernel<false>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -716,9 +845,15 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
 #endif
     const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
     static const int64_t wino1_max = getenv("DCE_WINO1_MAX") ? atoll(getenv("DCE_WINO1_MAX")) : WINO1_MAX_N;
-    if (!feat_bf16 && n <= wino1_max && !DCE_TRACE) {
+    if (!feat_bf16 && n <= wino1_max && (!DCE_TRACE || getenv("DCE_TRACE_WINO1"))) {
         // at most one workgroup per CU: one window each finishes in 56 % of a two-window workgroup's time
         float* f = static_cast<float*>(feat);
+        static const bool w8 = !(getenv("DCE_WINO1_WAVES") && atoi(getenv("DCE_WINO1_WAVES")) == 4);
+        if (w8) {
+            if (zscore) hipLaunchKernelGGL((conv_wino1x8_kernel<true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row);
+            else        hipLaunchKernelGGL((conv_wino1x8_kernel<false>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row);
+            return hipGetLastError();
+        }
         if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row);
         else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row);
         return hipGetLastError();
