@@ -184,13 +184,16 @@ template <int RS, bool FIRST, int MT = dce::MT, int NTW = dce::NTW>
 __device__ __forceinline__ void wino_step(const float* __restrict__ xs, const float* __restrict__ xn,
                                           const int (&boff)[NTW], const A8 a,
                                           V4& vcur, Quad& rawb, f32x4 (&acc)[MT][NTW][4],
-                                          const f32x4 (&bias)[MT])
+                                          const f32x4 (&bias)[MT], const float* __restrict__ xnn = nullptr)
 {
     const float a0[4] = {a.m0.x, a.m0.y, a.m0.z, a.m0.w};
     const float a1[4] = {a.m1.x, a.m1.y, a.m1.z, a.m1.w};
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        const float* pc = nt + 2 < NTW ? xs + boff[nt + 2] : xn + boff[nt + 2 - NTW];
+        // tile i+2 of the (K-step, column tile) sequence: this K-step, the next one, or -- one column tile per wave --
+        // the one after that (xnn)
+        const float* pc = nt + 2 < NTW ? xs + boff[nt + 2]
+                        : nt + 2 < 2 * NTW ? xn + boff[(nt + 2 - NTW) % NTW] : xnn + boff[(nt + 2 - 2 * NTW) % NTW];
 #if WINO_EXP & 2
         const Quad rawc = rawb; (void)pc;                  // experiment: no LDS reads
 #else
@@ -324,7 +327,7 @@ __device__ __forceinline__ void wino_mfma_deep(const float* __restrict__ xrow, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[mt][r] = bias_lds[co0 + 16 * mt + 4 * (lane >> 4) + r];
     V4 vcur = wino_v(load_quad2(xrow + boff[0]));
-    Quad rawb = load_quad2(xrow + boff[1]);
+    Quad rawb = load_quad2(NTW > 1 ? xrow + boff[NTW > 1 ? 1 : 0] : xrow + 4 * RS + boff[0]);      // tile 1 of the sequence
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -339,8 +342,9 @@ __device__ __forceinline__ void wino_mfma_deep(const float* __restrict__ xrow, c
         const A8 a = ring[(BASE + s) % PF];
         if (s + PF < STEPS) ring[(BASE + s) % PF] = load_a8<MT>(ap, s + PF);
         else if (ap_next)   ring[(BASE + s) % PF] = load_a8<MTN>(ap_next, s + PF - STEPS);
-        const int sn = s + 1 < STEPS ? s + 1 : s;          // last step: harmless re-read
-        wino_step<RS, false, MT, NTW>(xrow + s * 4 * RS, xrow + sn * 4 * RS, boff, a, vcur, rawb, acc, bias);
+        const int sn = s + 1 < STEPS ? s + 1 : s;          // last steps: harmless re-reads
+        const int snn = s + 2 < STEPS ? s + 2 : STEPS - 1;
+        wino_step<RS, false, MT, NTW>(xrow + s * 4 * RS, xrow + sn * 4 * RS, boff, a, vcur, rawb, acc, bias, xrow + snn * 4 * RS);
     }
 }
 
@@ -807,6 +811,195 @@ void conv_wino1x8_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// A SEGMENT of a window per workgroup (<= 128 windows: two CUs per window; <= 64: four).  The layers are local in time,
+// so a window can be cut with halos and no exchange: segment sg of NSEG computes the features j = a4..b4 of every
+// channel (conv4 pairs a4..b4; pair m of a layer = its outputs 2m, 2m+1) from the rows that reach them,
+//     conv3 pairs  a3..b3 = a4-1 .. b4+1          (clipped to 0..37)
+//     conv2 pairs  a2..b2 = 2 a3 - 1 .. 2 b3 + 2  (the pooled positions conv3 reads; clipped to 0..74)
+//     conv1 pairs  a1..b1 = a2-1 .. b2+1          (clipped to 0..74)
+// halves: 42 / 41 / 20 / 19 pairs -> 3 column tiles in stage 1 and 2 in stage 2 instead of 5 and 3 (63 % of a window's
+// MFMAs per workgroup); quarters: <= 26 / 24 / 11 / 10 pairs -> 2 and 1 column tiles (37 %).  Columns past a range
+// compute on a copy of its last pair and are never stored; the window's true edges keep their zero pads wherever they
+// fall into a segment (t = -1; t = 150, 151 in stage 1; t = 75, 76 in stage 2).  Every output is still one accumulator's
+// chain over the same K order: bit-identical features.  (The z-score needs the whole window's statistics, so every
+// segment loads all 150 rows; only the rows of its own range go to LDS.)
+// LDS coordinates: local index L of a row holds x[tb + L]; stage 1: tb1 = 2 a1 - 1, stage 2: tb2 = 2 a3 - 1.
+// Waves (eight, two per SIMD; w and w+4 share one): stage 1 = (row tile w&3, column group w>>2), stage 2 = row tile w x NT2
+// column tiles.
+// ------------------------------------------------------------------------------------------
+constexpr int RS1H = 98, RS2H = 70;                          // row strides (floats) of the two stages (halves: 86 / 42 used)
+constexpr int HACT_FLOATS = 128 * RS2H;                      // 8960 (>= 64 * RS1H = 6272)
+constexpr int HLDS_FLOATS = HACT_FLOATS + 384 + 2 + 864 + 2; // + biases + NaN flag (+pad) + fp64 z-score scratch (8-B aligned)
+constexpr int WINOH_MAX_N = 128, WINOQ_MAX_N = 64;
+
+// stage 1 of a segment for one wave: row tile rt x NTW column tiles starting at column tile nt0 (column n <-> pair a + n)
+template <int NTW>
+__device__ __forceinline__ void seg_stage1(float* __restrict__ act, const float* __restrict__ bias_lds,
+                                           const float4* ap1, const float4* ap2, const float4* ap3, A8 (&ring)[WINO1_PF],
+                                           int rt, int nt0, int lane, int tid, int a1, int b1, int a2, int b2, int tb1, int tb2)
+{
+    constexpr int PF = WINO1_PF;
+    const int j = lane & 15, q = lane >> 4;
+    f32x4 acc[1][NTW][4];
+    int boff[NTW];
+    const int co0 = 16 * rt;
+    const float* xrow1 = act + q * RS1H;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) { const int m = a1 + 16 * (nt0 + nt) + j; boff[nt] = 2 * (m < b1 ? m : b1) - 1 - tb1; }
+    wino_mfma_deep<RS1H, 14, 1, NTW, PF, 1, 0>(xrow1, boff, ap1, ap2, ring, bias_lds, co0, lane, acc);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int m = a1 + 16 * (nt0 + nt) + j;
+        if (m <= b1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m0 = acc[0][nt][0][r], m1 = acc[0][nt][1][r], m2 = acc[0][nt][2][r], m3 = acc[0][nt][3][r];
+                float* d = act + (co0 + 4 * q + r) * RS1H + 2 * m - tb1;
+                d[0] = fmaxf((m0 + m1) + m2, 0.f);
+                d[1] = fmaxf((m1 - m2) - m3, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) { const int m = a2 + 16 * (nt0 + nt) + j; boff[nt] = 2 * (m < b2 ? m : b2) - 1 - tb1; }
+    wino_mfma_deep<RS1H, 16, 1, NTW, PF, 1, 14 % PF>(xrow1, boff, ap2, ap3, ring, bias_lds + 64, co0, lane, acc);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int m = a2 + 16 * (nt0 + nt) + j;
+        if (m <= b2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m0 = acc[0][nt][0][r], m1 = acc[0][nt][1][r], m2 = acc[0][nt][2][r], m3 = acc[0][nt][3][r];
+                act[(co0 + 4 * q + r) * RS2H + m - tb2] = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+            }
+        }
+    }
+    // stage-2 edges where they fall into the segment: x[-1], x[75], x[76], all 128 rows (nobody else writes them)
+    for (int i = tid; i < 128 * 3; i += 512) {
+        const int c = i / 3, k = i % 3, L = (k == 0 ? -1 : 74 + k) - tb2;
+        if (L >= 0 && L < RS2H) act[c * RS2H + L] = 0.f;
+    }
+}
+
+template <bool ZS, int NSEG, int NT1, int NT2>
+__global__ __launch_bounds__(512)
+void conv_wino_seg_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat,
+                          const long long* __restrict__ src_row)
+{
+    static_assert((NSEG == 2 && NT1 == 3 && NT2 == 2) || (NSEG == 4 && NT1 == 2 && NT2 == 1), "column tiles per segment count");
+    extern __shared__ __attribute__((aligned(16))) float act[];
+    if (src_row) src += *src_row * CH;                    // online graph: the window start lives in device memory
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const int64_t win0 = blockIdx.x / NSEG;
+    const int sg = blockIdx.x % NSEG;
+    if (win0 >= n) return;
+    // the segment's pair ranges (wave-uniform integers)
+    const int a4 = NSEG == 2 ? (sg ? 19 : 0) : (sg == 0 ? 0 : 1 + 9 * sg), b4 = NSEG == 2 ? (sg ? 36 : 18) : 9 + 9 * sg;
+    const int a3 = a4 > 0 ? a4 - 1 : 0, b3 = b4 + 1 < 37 ? b4 + 1 : 37;
+    const int a2 = 2 * a3 - 1 > 0 ? 2 * a3 - 1 : 0, b2 = 2 * b3 + 2 < 74 ? 2 * b3 + 2 : 74;
+    const int a1 = a2 > 0 ? a2 - 1 : 0, b1 = b2 + 1 < 74 ? b2 + 1 : 74;
+    const int tb1 = 2 * a1 - 1, tb2 = 2 * a3 - 1;
+
+    for (int i = tid; i < 384; i += 512) {
+        const int l = i < 64 ? 0 : (i < 128 ? 1 : (i < 256 ? 2 : 3));
+        const int o = i < 64 ? i : (i < 128 ? i - 64 : (i < 256 ? i - 128 : i - 256));
+        act[HACT_FLOATS + i] = pk.b[l][o];
+    }
+    int* nanflag = reinterpret_cast<int*>(act + HACT_FLOATS + 384);
+    if (tid == 0) nanflag[0] = 0;
+    constexpr int PF = WINO1_PF;
+    A8 ring[PF];
+    const int rt = wv & 3;
+    const float4* ap1 = reinterpret_cast<const float4*>(pk.ww[0]) + (rt >> 1) * (14 * 128) + 2 * lane + (rt & 1);
+    const float4* ap2 = reinterpret_cast<const float4*>(pk.ww[1]) + (rt >> 1) * (16 * 128) + 2 * lane + (rt & 1);
+    const float4* ap3 = reinterpret_cast<const float4*>(pk.ww[2]) + (wv >> 1) * (16 * 128) + 2 * lane + (wv & 1);
+    const float4* ap4 = reinterpret_cast<const float4*>(pk.ww[3]) + (wv >> 1) * (32 * 128) + 2 * lane + (wv & 1);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = load_a8<1>(ap1, i);
+    {
+        float x[1][38];
+        const int64_t wstride = ZS ? CH : (int64_t)WIN * CH;
+        load_windows<ZS, 1>(src + win0 * wstride, wstride, 1, act + HACT_FLOATS + 388, x, tid < 256 ? tid : 255);
+        bool bad0 = false;
+#pragma unroll
+        for (int m = 0; m < 38; ++m) bad0 |= !(fabsf(x[0][m]) <= 3.0e38f);
+        __syncthreads();
+        if (bad0 && tid < 4 * CH) nanflag[0] = 1;
+        if (tid < 4 * CH) {
+            const int c = tid % CH, g = tid / CH;
+#pragma unroll
+            for (int m = 0; m < 38; ++m) {
+                const int t = 4 * m + g, L = t - tb1;
+                if (t < WIN && L >= 0 && L < RS1H) act[c * RS1H + L] = x[0][m];
+            }
+        }
+        // the window's true edges where they fall into the segment: x[-1], x[150], x[151]; filler channels 54, 55
+        for (int i = tid; i < 64 * 3; i += 512) {
+            const int c = i / 3, k = i % 3, L = (k == 0 ? -1 : 149 + k) - tb1;
+            if (L >= 0 && L < RS1H) act[c * RS1H + L] = 0.f;
+        }
+        for (int i = tid; i < 2 * RS1H; i += 512) act[CH * RS1H + i] = 0.f;
+    }
+    __syncthreads();
+    const bool nan0 = __builtin_amdgcn_readfirstlane(nanflag[0]) != 0;
+    const float* bias_lds = act + HACT_FLOATS;
+
+    // ---- stage 1: conv1, conv2; wave (row tile w&3, column group w>>2): halves = column tiles {0,1} / {2}, quarters = {0} / {1}
+    //      (waves w and w+4 share a SIMD: every SIMD carries NT1 column tiles of one row tile)
+    if constexpr (NSEG == 4) seg_stage1<1>(act, bias_lds, ap1, ap2, ap3, ring, rt, wv >> 2, lane, tid, a1, b1, a2, b2, tb1, tb2);
+    else if (wv < 4)         seg_stage1<2>(act, bias_lds, ap1, ap2, ap3, ring, rt, 0, lane, tid, a1, b1, a2, b2, tb1, tb2);
+    else                     seg_stage1<1>(act, bias_lds, ap1, ap2, ap3, ring, rt, 2, lane, tid, a1, b1, a2, b2, tb1, tb2);
+    // ---- stage 2 (all eight waves): conv3, conv4 for row tile wv x NT2 column tiles
+    {
+        f32x4 acc[1][NT2][4];
+        int boff[NT2];
+        const int co2 = 16 * wv;
+        const float* xrow2 = act + q * RS2H;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) { const int m = a3 + 16 * nt + j; boff[nt] = 2 * (m < b3 ? m : b3) - 1 - tb2; }
+        __syncthreads();
+        wino_mfma_deep<RS2H, 16, 1, NT2, PF, 1, 30 % PF>(xrow2, boff, ap3, ap4, ring, bias_lds + 128, co2, lane, acc);
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const int m = a3 + 16 * nt + j;
+            if (m <= b3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m0 = acc[0][nt][0][r], m1 = acc[0][nt][1][r], m2 = acc[0][nt][2][r], m3 = acc[0][nt][3][r];
+                    float* d = act + (co2 + 4 * q + r) * RS2H + 2 * m - tb2;
+                    d[0] = fmaxf((m0 + m1) + m2, 0.f);
+                    d[1] = 2 * m + 1 < 75 ? fmaxf((m1 - m2) - m3, 0.f) : 0.f;        // x[75] is a zero pad
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) { const int m = a4 + 16 * nt + j; boff[nt] = 2 * (m < b4 ? m : b4) - 1 - tb2; }
+        wino_mfma_deep<RS2H, 32, 1, NT2, PF, 1, 46 % PF>(xrow2, boff, ap4, nullptr, ring, bias_lds + 256, co2, lane, acc);
+        const float nanv = __builtin_nanf("");
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const int m = a4 + 16 * nt + j;
+            if (m <= b4) {
+                float* base = feat + win0 * FEAT + (co2 + 4 * q) * 37 + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m0 = acc[0][nt][0][r], m1 = acc[0][nt][1][r], m2 = acc[0][nt][2][r], m3 = acc[0][nt][3][r];
+                    const float v = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+                    base[r * 37] = nan0 ? nanv : v;
+                }
+            }
+        }
+    }
+}
+
 #if DCE_TRACE
 }  // namespace dce
 extern "C" int dce_debug_trace_read_wino(unsigned long long* out, int nblocks)
@@ -832,6 +1025,9 @@ hipError_t init_conv_wino()
     for (const void* k : {reinterpret_cast<const void*>(&conv_wino1_kernel<true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false>),
                           reinterpret_cast<const void*>(&conv_wino1x8_kernel<true>), reinterpret_cast<const void*>(&conv_wino1x8_kernel<false>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
+    for (const void* k : {reinterpret_cast<const void*>(&conv_wino_seg_kernel<true, 2, 3, 2>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 2, 3, 2>),
+                          reinterpret_cast<const void*>(&conv_wino_seg_kernel<true, 4, 2, 1>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 4, 2, 1>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -848,6 +1044,20 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
     if (!feat_bf16 && n <= wino1_max && (!DCE_TRACE || getenv("DCE_TRACE_WINO1"))) {
         // at most one workgroup per CU: one window each finishes in 56 % of a two-window workgroup's time
         float* f = static_cast<float*>(feat);
+        // two / four CUs per window while that leaves no CU without one
+        static const int64_t half_max = getenv("DCE_WINOH_MAX") ? atoll(getenv("DCE_WINOH_MAX")) : WINOH_MAX_N;
+        static const int64_t quarter_max = getenv("DCE_WINOQ_MAX") ? atoll(getenv("DCE_WINOQ_MAX")) : WINOQ_MAX_N;
+        const size_t hl = HLDS_FLOATS * sizeof(float);
+        if (n <= quarter_max) {
+            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 4, 2, 1>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, src_row);
+            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, src_row);
+            return hipGetLastError();
+        }
+        if (n <= half_max) {
+            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row);
+            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row);
+            return hipGetLastError();
+        }
         static const bool w8 = !(getenv("DCE_WINO1_WAVES") && atoi(getenv("DCE_WINO1_WAVES")) == 4);
         if (w8) {
             if (zscore) hipLaunchKernelGGL((conv_wino1x8_kernel<true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row);

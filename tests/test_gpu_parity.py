@@ -117,9 +117,10 @@ def test_small_batch_kernels_are_bit_identical(n, models, big_batch_taps):
     from 9 windows (batch_size 30) the MFMA chain kernel (csrc/fc_gemm_chain.hip: one 16x16 tile per wave on
     v_mfma_f32_16x16x4_f32, operands permuted in LDS) runs fc.0 up to 640 and fc.3 up to 2048 windows, with the 64x64 /
     128x64 tile kernels behind it; all walk K in the order the chip-filling GEMMs do, so every FC activation and logit
-    must equal, bit for bit, the rows the same windows get inside a batch of 3000.  Likewise <= 256 windows take the
-    one-window-per-workgroup conv kernel (conv_wino1_kernel): same per-accumulator K order, so the features are the
-    bits of the two-window kernel (257: its odd tail)."""
+    must equal, bit for bit, the rows the same windows get inside a batch of 3000.  Likewise the conv stack: <= 64 windows
+    run four workgroups per window (quarter segments with halos, conv_wino_seg_kernel), <= 128 two, <= 256 one
+    (conv_wino1x8_kernel): same per-accumulator K order, so the features are the bits of the two-window kernel
+    (257: its odd tail)."""
     x, big = big_batch_taps
     small = models(max_batch=4096).forward_taps(x[:n])
     for k in ("feat", "h1", "h2", "logits"):
@@ -506,10 +507,10 @@ def test_online_mode_bf16_fc():
     m.close()
 
 
-@pytest.mark.parametrize("n", [10, 401])                  # one-window kernel / two-window kernel (odd tail)
+@pytest.mark.parametrize("n", [10, 100, 200, 401])        # quarter- / half- / one-window kernels, two-window kernel (odd tail)
 def test_non_finite_windows_stay_contained(n, models, orc):
     """torch turns any NaN / Inf input sample into all-NaN logits of THAT window (class 0 on CPU) and
-    nothing else.  Both conv kernels carry this per window (ReLU is v_max, which drops NaN): checked on
+    nothing else.  All conv kernels carry this per window (ReLU is v_max, which drops NaN): checked on
     the streaming path (a NaN row poisons exactly the windows that contain it) and on pre-normalised
     windows, against the oracle for every clean window."""
     from deep_contact_estimator_amd import synth
