@@ -188,3 +188,30 @@ def test_bench_multi_gpu_flow_on_rccl_single_rank():
     assert j["n_gpus"] == 1 and "RCCL gather" in j["config"]["sharding"] and j["value"] > 1e6
     sh = j["extra"]["sharded_1e6"]
     assert sh["windows_per_s_incl_gather"] > 1e6 and abs(sh["gathered_MB"] - 68.0) < 1e-9
+
+
+def test_bench_default_line_contract():
+    """The line the driver records: `python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the
+    contract's keys, the roofline and cpu_baseline objects, and every other BASELINE config measured under `extra`."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2"],
+                       env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 2 and j["higher_is_better"] is True
+    assert j["unit"] == "windows/s" and j["dtype"] == "f32" and j["vs_baseline"] is None and "workload" in j["config"]
+    assert abs(j["value"] - 4096 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6 and j["value"] > 1e6
+    rf = j["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert 0.5 < rf["frac"] < 1.0 and "traffic" in rf
+    cb = j["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["sample"]
+    ex = j["extra"]
+    assert ex["streaming_1e6"]["hbm_resident_windows_per_s"] > 1e6 and ex["bf16_fc"]["windows_per_s"] > 1e6
+    sb = ex["small_batches"]["batches"]
+    assert set(sb) >= {"1", "30"} and 0 < sb["1"]["us_per_call"] < sb["30"]["us_per_call"] < 500
