@@ -430,6 +430,13 @@ static int phased_tile(int64_t M, int N, int K, int es)
     static const int tmin = getenv("DCE_GEMM_PHASED_MIN") ? atoi(getenv("DCE_GEMM_PHASED_MIN")) : 1;   // 2: only the 256x128 tile
     if (off || (size_t)K * es % 256 || (size_t)K * es < 3 * 256 || M > (1 << 30)) return 0;
     if ((size_t)256 * K * es + 128 >= (1ull << 32)) return 0;                     // per-lane offsets are 32-bit
+    // One workgroup per CU: a launch takes ceil(tiles / 256) rounds, and a round of 256 x 128 tiles lasts 3.83 rounds of
+    // 128 x 64 tiles (fc.0: 525 vs 137 us).  Between the powers of two the small tile's finer rounds win: 3000 windows
+    // are 192 big tiles = one round, 525 us, or 768 small ones = three rounds, 411 us.  (DCE_PHASED_COST=0: the first
+    // tile size, from the large one down, that fills its minimum -- the rule before this cost model.)
+    static const bool cost_model = !(getenv("DCE_PHASED_COST") && atoi(getenv("DCE_PHASED_COST")) == 0);
+    int best = 0;
+    double best_cost = 0.0;
     for (int t = 2; t >= tmin; --t) {
         const int bm = 128 * t, bn = 64 * t;
         if (N % bn) continue;
@@ -437,9 +444,13 @@ static int phased_tile(int64_t M, int N, int K, int es)
         if ((nt & (nt - 1)) != 0) continue;                                       // super-tile map wants a power of two
         // 256 x 128 tiles must fill the chip; the 128 x 64 tile still beats the tile kernels on half of it
         // (fc.0 at 512 windows: 128 tiles, 139 vs 160 us; at 64 tiles it loses, 135 vs 95 us)
-        if (((M + bm - 1) / bm) * nt >= (t == 2 ? min_tiles : min_tiles1)) return t;
+        const int64_t tiles = ((M + bm - 1) / bm) * nt;
+        if (tiles < (t == 2 ? min_tiles : min_tiles1)) continue;
+        if (!cost_model) return t;
+        const double cost = (double)((tiles + 255) / 256) * (t == 2 ? 3.83 : 1.0);
+        if (best == 0 || cost < best_cost) { best = t; best_cost = cost; }
     }
-    return 0;
+    return best;
 }
 
 bool fc_gemm_phased_ok(int64_t M, int N, int K, int bf16) { return phased_tile(M, N, K, bf16 ? 2 : 4) != 0; }
