@@ -194,9 +194,19 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1)) {
             // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU
             // unless a tap asks for it); one small kernel adds them up.  Same summation tree as the tail kernel.
-            { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch,
-                                                          c->want_h2 ? c->h2 : nullptr, n, c->stream)); }
-            { Timer t(c, 3); HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, n, logits, pred, contacts, c->stream)); }
+            // The fused kernel runs whole rounds of 256 tiles = 4096 windows: a batch that ends up to 2048 windows
+            // past a round gives that remainder to the chain kernel + tail (same bits, rows are independent) instead
+            // of paying a full round for it.
+            static const bool peel = !(getenv("DCE_GEMM_PEEL") && atoi(getenv("DCE_GEMM_PEEL")) == 0);
+            const int64_t rest = n % 4096, nf = (peel && n > 4096 && rest && (rest <= 8 || fc_gemm_chain_ok(rest, FC2, FC1))) ? n - rest : n;
+            { Timer t(c, 2);
+              HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch,
+                                           c->want_h2 ? c->h2 : nullptr, nf, c->stream));
+              if (nf < n) HIP_TRY(c, (n - nf <= 8 ? launch_fc_gemv : launch_fc_gemm)(c->h1 + nf * FC1, c->fc2w, c->fc2b, c->h2 + nf * FC2, n - nf, FC2, FC1, 1, c->stream)); }
+            { Timer t(c, 3);
+              HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, c->stream));
+              if (nf < n) HIP_TRY(c, launch_fc3_tail(c->h2 + nf * FC2, c->fc3w, c->fc3b, n - nf, logits ? logits + nf * NCLS : nullptr,
+                                                     pred ? pred + nf : nullptr, contacts ? contacts + nf * 4 : nullptr, c->stream)); }
             if (c->spans.size() > 4096) return drain_spans(c);
             return DCE_OK;
         }

@@ -403,14 +403,42 @@ static hipError_t launch_gemm_cfg(const void* A, const void* W, const float* bia
     return hipGetLastError();
 }
 
+static hipError_t launch_fc_gemm_one(const float* A, const float* W, const float* bias, float* C,
+                                     int64_t M, int N, int K, int relu, hipStream_t st, bool remainder = false);
+
+// Rows are independent and every kernel of the library produces the same bits for a row, so a batch may be cut by rows and
+// each piece given to the kernel that suits its size.  The phased GEMMs run one workgroup per CU: a launch lasts whole
+// ROUNDS of 256 tiles (fc.0: 4096 rows of 256x128 tiles = 525 us, 1024 rows of 128x64 tiles = 137 us), and a batch that
+// ends just past a round pays a full one for the tail -- 4200 windows = 2 rounds of the big tile (1050 us) or 5 of the
+// small one (685 us).  So: whole big rounds, then whole small rounds, then the remainder on its own (chain kernel up to 640
+// rows, GEMV up to 8): 4200 windows = 525 + 31 us.  (DCE_GEMM_PEEL=0 switches the cut off.)
 hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, float* C,
                           int64_t M, int N, int K, int relu, hipStream_t st)
 {
     if (M <= 0) return hipSuccess;
     if (N % 128 || K % 32 || M > (1 << 30)) return hipErrorInvalidValue;
-    // chip-filling sizes: one phased workgroup per CU (fc_gemm_phased.hip); same K order, same bits
+    static const bool peel = !(getenv("DCE_GEMM_PEEL") && atoi(getenv("DCE_GEMM_PEEL")) == 0);
+    const int64_t rows1 = (int64_t)(256 / (N / 64)) * 128, rows2 = (int64_t)(256 / (N / 128)) * 256;   // rows of one round
+    if (peel && N <= 2048 && 256 % (N / 64) == 0 && M > rows1 && M % rows1 != 0 && fc_gemm_phased_ok(rows1, N, K, 0)) {
+        const int64_t big = fc_gemm_phased_ok(rows2, N, K, 0) ? M / rows2 * rows2 : 0;
+        const int64_t small = (M - big) / rows1 * rows1, rest = M - big - small;
+        hipError_t e = hipSuccess;
+        if (big) e = launch_fc_gemm_one(A, W, bias, C, big, N, K, relu, st);
+        if (e == hipSuccess && small) e = launch_fc_gemm_one(A + big * K, W, bias, C + big * N, small, N, K, relu, st);
+        if (e == hipSuccess && rest) e = launch_fc_gemm_one(A + (big + small) * K, W, bias, C + (big + small) * N, rest, N, K, relu, st, true);
+        return e;
+    }
+    return launch_fc_gemm_one(A, W, bias, C, M, N, K, relu, st);
+}
+
+static hipError_t launch_fc_gemm_one(const float* A, const float* W, const float* bias, float* C,
+                                     int64_t M, int N, int K, int relu, hipStream_t st, bool remainder)
+{
+    // a handful of rows as the remainder of a cut: the weight-streaming GEMV
+    if (remainder && M <= 8 && N % 8 == 0 && K % 128 == 0) return launch_fc_gemv(A, W, bias, C, M, N, K, relu, st);
     // a few dozen to a few hundred windows: chain-latency kernel, one 16x16 tile per wave (fc_gemm_chain.hip)
     if (fc_gemm_chain_ok(M, N, K)) return launch_fc_gemm_chain(A, W, bias, C, M, N, K, relu, st);
+    // chip-filling sizes: one phased workgroup per CU (fc_gemm_phased.hip); same K order, same bits
     if (fc_gemm_phased_ok(M, N, K, 0)) return launch_fc_gemm_phased(A, W, bias, C, 0, 0, M, N, K, relu, st);
     // (In between, a no-LDS kernel -- one 16x16 / 32x32 output tile per wave on v_mfma_f32_16x16x4_f32, operands streamed
     //  from L2 straight into MFMA registers, bit-identical -- was built and measured in round 2: 1.4x - 3.2x SLOWER than the

@@ -111,7 +111,7 @@ def big_batch_taps(models):
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 8, 9, 16, 17, 30, 31, 32, 33, 63, 64, 65, 100, 128, 129, 255, 256, 257, 300,
-                               512, 640, 641, 1000, 1024, 2048, 2049])
+                               512, 640, 641, 1000, 1024, 1025, 1030, 1100, 2048, 2049, 2100])
 def test_small_batch_kernels_are_bit_identical(n, models, big_batch_taps):
     """<= 8 windows (batch_size 1 of the reference's configs) take the weight-streaming GEMV kernel (csrc/fc_gemv.hip);
     from 9 windows (batch_size 30) the MFMA chain kernel (csrc/fc_gemm_chain.hip: one 16x16 tile per wave on
@@ -125,6 +125,24 @@ def test_small_batch_kernels_are_bit_identical(n, models, big_batch_taps):
     small = models(max_batch=4096).forward_taps(x[:n])
     for k in ("feat", "h1", "h2", "logits"):
         assert np.array_equal(small[k], big[k][:n]), k
+
+
+@pytest.mark.parametrize("n", [4097, 4200, 5000, 6200])
+def test_row_cuts_of_large_batches_are_bit_identical(n):
+    """Past a whole round of phased tiles (4096 windows of 256x128 fc.0 tiles / of fused fc.3 tiles, 1024 of 128x64 tiles)
+    the FC layers cut a batch by rows and give the remainder to the kernel that suits its size (chain kernel, GEMV):
+    rows are independent and every kernel produces the same bits for a row, so the logits must equal those of the same
+    windows inside a power-of-two batch."""
+    import torch
+    from deep_contact_estimator_amd import contact_cnn, synth
+    m = contact_cnn(device=0, max_batch=8192)
+    m.load_state_dict(synth.make_state_dict(1, "uniform"))
+    x = torch.randn((8192, 150, 54), generator=torch.Generator(device="cuda").manual_seed(7), device="cuda")
+    ref = m.predict(x)
+    got = m.predict(x[:n].contiguous())
+    for k in ("logits", "pred", "contacts"):
+        assert torch.equal(got[k], ref[k][:n]), k
+    m.close()
 
 
 def test_chunking_and_determinism(models, orc):
