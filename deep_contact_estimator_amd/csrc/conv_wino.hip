@@ -1035,12 +1035,23 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
                             void* feat, int feat_bf16, hipStream_t st, const long long* src_row)
 {
     if (n <= 0) return hipSuccess;
+    static const int64_t wino1_max = getenv("DCE_WINO1_MAX") ? atoll(getenv("DCE_WINO1_MAX")) : WINO1_MAX_N;
+    // The two-window kernel fills the chip with rounds of 512 workgroups = 1024 windows; up to 256 windows past a round
+    // would each sit alone on a CU for a lone workgroup's 65 us.  Windows are independent and every conv kernel produces
+    // the same bits, so that remainder goes to the one-window / segment kernels instead (20 .. 38 us).
+    static const bool peel = !(getenv("DCE_CONV_PEEL") && atoi(getenv("DCE_CONV_PEEL")) == 0);
+    if (peel && !feat_bf16 && !src_row && !DCE_TRACE && n > 1024 && n % 1024 != 0 && n % 1024 <= wino1_max) {
+        const int64_t rest = n % 1024, m = n - rest;
+        const hipError_t e = launch_conv_wino(src, zscore, m, pk, feat, feat_bf16, st, nullptr);
+        if (e != hipSuccess) return e;
+        return launch_conv_wino(src + m * (zscore ? (int64_t)CH : (int64_t)WIN * CH), zscore, rest, pk,
+                                static_cast<float*>(feat) + m * FEAT, feat_bf16, st, nullptr);
+    }
     size_t lds = WLDS_FLOATS * sizeof(float);
 #if DCE_TRACE
     if (getenv("DCE_ONE_PER_CU")) lds = 100 * 1024;      // debug: force one workgroup per CU
 #endif
     const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
-    static const int64_t wino1_max = getenv("DCE_WINO1_MAX") ? atoll(getenv("DCE_WINO1_MAX")) : WINO1_MAX_N;
     if (!feat_bf16 && n <= wino1_max && (!DCE_TRACE || getenv("DCE_TRACE_WINO1"))) {
         // at most one workgroup per CU: one window each finishes in 56 % of a two-window workgroup's time
         float* f = static_cast<float*>(feat);
