@@ -4,7 +4,8 @@ sizes around every kernel-selection threshold (GEMV <= 8, MFMA chain kernel up t
 conv <= 256, 64x64 vs 128x128 GEMM tiles, max_batch chunking), random checkpoints (He-normal x random gain, non-zero biases) and
 random input statistics, checked against the CPU oracle (tolerance + argmax contract) and for
 bit-identity between the streaming (fused z-score) path, the materialised-window path and the
-same windows embedded in a larger batch."""
+same windows embedded in a larger batch.  Sizes past whole rounds of the phased tiles / of the two-window conv kernel
+(1025 .. 4200) exercise the row cuts."""
 import json
 import os
 import sys
@@ -19,7 +20,7 @@ from oracle import oracle as orc
 TRIALS = int(os.environ.get("TRIALS", 120))
 rng = np.random.default_rng(int(os.environ.get("SEED", 2024)))
 edges = [1, 2, 3, 8, 9, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 513, 639, 640, 641, 700,
-         1023, 1025, 2047, 2048, 2049]
+         1023, 1025, 1030, 1100, 2047, 2048, 2049, 2100, 3000, 4097, 4200]
 worst, flips, total = 0.0, 0, 0
 t0 = time.time()
 for trial in range(TRIALS):
