@@ -50,7 +50,8 @@ hipError_t launch_zscore_windows(const float* seq_first_row, int64_t n, float* o
 hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, float* C,
                           int64_t M, int N, int K, int relu, hipStream_t st);
 
-// The same layer for M <= 32 windows (online mode / batch_size 1 and 30): weight-streaming GEMV on all CUs,
+// The same layer for M <= 32 windows (used up to 8: online mode / batch_size 1; from 9 windows the chain kernel below is
+// faster): weight-streaming GEMV on all CUs,
 // bit-identical to launch_fc_gemm (same K order).  N % 8 == 0, K % 128 == 0.
 constexpr int FC_GEMV_MAX_M = 32;
 hipError_t launch_fc_gemv(const float* A, const float* W, const float* bias, float* C,

@@ -1,6 +1,6 @@
 // fc_gemv.hip -- the FC layers for a handful of windows (online mode, batch_size 1 of
-// config/inference_one_seq_params.yaml): Linear + bias + ReLU of src/contact_cnn.py:49-55 when M <= 32
-// (batch_size 30 of config/test_params.yaml included).
+// config/inference_one_seq_params.yaml): Linear + bias + ReLU of src/contact_cnn.py:49-55 for M <= 32 -- since the MFMA
+// chain kernel (fc_gemm_chain.hip) took over from 9 windows, used for M <= 8 and for the <= 8-row remainders of row cuts.
 //
 // At M = 1 the 128x128 / 64x64 MFMA GEMM tiles of fc_gemm.hip leave 224+ of the 256 CUs idle and
 // each active block walks its K loop alone (fc.0: 110 us on 32 workgroups).  The work is a stream
