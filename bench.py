@@ -5,16 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: started plainly (no WORLD_SIZE in the environment) `--gpus N` re-executes itself under
+torch.distributed.run with N ranks on a free port and rank 0 prints the one JSON line.
+
 A step = one pass of the hot path over one batch: BASELINE.json configs[1], i.e. B=4096
 pre-normalised windows (B,150,54) fp32 already resident in HBM -> conv stack -> 3 FC ->
 logits (B,16) + argmax + 4 contact bits, all through the C ABI (dce_forward_windows, device
 pointers, torch's current stream).  With N>1 every rank (one process per GPU) runs its own B
-windows (weak scaling, no data-path collective inside the model) and the (B,16) logits are
-gathered to rank 0 over RCCL each step, asynchronously behind the next step's kernels.
+windows (weak scaling, no data-path collective inside the model) and its (B,68)-byte packed
+results (16 fp32 logits + 4 contact bits per window, written by the last kernel) are gathered to rank 0
+each step by ONE ncclGather that libdce.so issues itself (dce_gather_results) on its communication
+stream, behind the next step's kernels.  torch.distributed is the launcher plumbing only (rank
+environment, barriers, max-over-ranks of the elapsed time, the store that carries the ncclUniqueId).
 
 Order of one run (every rank):
-  1. settle   : the step loop runs untimed until >= --settle-s seconds of GPU time have passed,
-                whatever --warmup says, so the clocks are where a long job holds them;
+  1. settle   : the model's kernels (no exchange: every rank stops on its own clock, so nothing collective may
+                run here) loop untimed until >= --settle-s seconds of GPU time have passed, whatever --warmup
+                says, so the clocks are where a long job holds them; then a barrier;
   2. warm-up  : W untimed steps;
   3. timed    : barrier + synchronize, EXACTLY K steps with no events on the stream, synchronize +
                 barrier; max over ranks -> `value`, `ms_per_step`;
@@ -263,12 +270,13 @@ def extra_streaming(torch, contact_cnn, sd, dev, n_windows=1_000_000):
     ok_bits = bool(torch.equal(bits, out["contacts"]))
     host = seq.cpu().numpy()
     m.infer_sequence(host[:32768 + 149])
+    m.infer_sequence(host)                   # warm: the first full-length call grows the ctx's staging buffers
     htimes = []
-    for _ in range(3):                       # the first call also grows the ctx's staging buffers
+    for _ in range(3):
         t0 = time.perf_counter()
         out_h = m.infer_sequence(host)
         htimes.append(time.perf_counter() - t0)
-    dth = min(htimes[1:])
+    dth = statistics.median(htimes)          # the same statistic as the HBM-resident figure: median of 3 after a warm call
     same = bool(np.array_equal(out_h["contacts"], out["contacts"].cpu().numpy())
                 and np.array_equal(out_h["logits"], out["logits"].cpu().numpy()))
     m.close()
@@ -280,7 +288,7 @@ def extra_streaming(torch, contact_cnn, sd, dev, n_windows=1_000_000):
         "pcie_inclusive_windows_per_s": n_windows / dth, "pcie_inclusive_ms": dth * 1e3,
         "pcie_inclusive_ms_each": [round(t * 1e3, 2) for t in htimes],
         "pcie_note": "numpy (T,54) in, numpy logits/pred/contacts out (216 MB H2D + 72 MB D2H staged chunk by chunk "
-                     "on a second stream); never `value`",
+                     "on a second stream); median of 3 calls after one warm call, like the HBM-resident figure; never `value`",
         "host_path_equals_device_path_bitwise": same,
         "pred_is_argmax_of_logits": ok_pred, "contacts_are_bits_of_pred": ok_bits,
     }
@@ -346,8 +354,11 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
     [g*n, (g+1)*n + 149) (its 149-row halo regenerated, not communicated), one fused pass per rank,
     ONE gather of the packed (n,68)-byte results to rank 0."""
     from deep_contact_estimator_amd.distributed import infer_sequence_sharded, shard_rows
+    from deep_contact_estimator_amd.distributed import comm_bootstrap
     m = contact_cnn(device=dev.index, max_batch=32768)
     m.load_state_dict(sd).eval()
+    if backend == "nccl":
+        comm_bootstrap(m, rank, world, key="dce_comm_id_sharded")
     n_total = world * n_per_rank
     r0, r1, _, _ = shard_rows(n_total + 149, rank, world)
     g = torch.Generator(device=dev)
@@ -362,7 +373,7 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    res = infer_sequence_sharded(m.infer_sequence, rows, dst=0, n_windows=n_total, row_lo=r0)
+    res = infer_sequence_sharded(m.infer_sequence, rows, dst=0, n_windows=n_total, row_lo=r0, model=m)
     torch.cuda.synchronize()
     dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -374,7 +385,21 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
     return {"workload": f"BASELINE configs[3]: {world} x {n_per_rank} windows, halo-sharded, one gather of the packed "
                         "logits+contacts (68 B/window) to rank 0",
             "windows_per_s_incl_gather": n_total / float(t.item()), "ms": float(t.item()) * 1e3,
-            "gathered_MB": n_total * 68 / 1e6}
+            "gathered_MB": n_total * 68 / 1e6,
+            "transport": "dce_gather_results (ncclGather issued by libdce.so)" if backend == "nccl" else f"torch.distributed {backend} (functional test)"}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` started plainly: run the same command line as N ranks (one process per GPU) under
+    torch.distributed.run on a free port; the ranks inherit stdout, so rank 0's JSON line is this process's line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd).returncode
 
 
 def main():
@@ -391,6 +416,9 @@ def main():
                     help="fp32 = the headline (exact fp32 MFMA); bf16_fc = BASELINE configs[4] as the main workload")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     from deep_contact_estimator_amd import contact_cnn, synth
@@ -398,13 +426,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
-        args.gpus = world
+    args.gpus = world                                       # the launcher's world is what runs
     backend = os.environ.get("DCE_DIST_BACKEND", "nccl")   # "gloo": functional check of the N>1 flow on
     if backend != "nccl":                                   # fewer GPUs than ranks (ranks share devices)
         local_rank %= max(torch.cuda.device_count(), 1)
+    elif world > torch.cuda.device_count():
+        sys.exit(f"--gpus {world}: only {torch.cuda.device_count()} GPU(s) visible and RCCL takes one rank per device "
+                 "(DCE_DIST_BACKEND=gloo runs the N>1 flow with ranks sharing GPUs, as a functional test)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # DCE_FORCE_DIST=1: run the N>1 flow (process group, per-step gather, extra.sharded_1e6) in a world of ONE rank --
@@ -432,23 +460,39 @@ def main():
     windows = model.zscore_windows(seq, 0, B)
     torch.cuda.synchronize()
 
-    gatherer = None
-    if multi:
+    gatherer, rccl_info = None, None
+    if multi and backend == "nccl":
+        # the data path's one exchange: libdce.so's own RCCL communicator (dce_comm_init / dce_gather_results)
+        from deep_contact_estimator_amd.distributed import PackedStepGather, comm_bootstrap
+        comm_bootstrap(model, rank, world)
+        gatherer = PackedStepGather(model, B, dev, dst=0)
+        ci = model.comm_info()
+        rccl_info = {"backend": f"RCCL {ci['rccl_version']} through the C ABI (dce_gather_results: one ncclGather per step on the "
+                                "ctx's communication stream, two steps in flight)", "library": ci["library"],
+                     "world_size_ncclCommCount": ci["world"], "rank_ncclCommUserRank": ci["rank"],
+                     "gathered_bytes_per_step": gatherer.bytes_per_step, "row_bytes": 68,
+                     "host_plumbing": "torch.distributed (nccl): barriers, max-over-ranks of the elapsed time, store for the ncclUniqueId"}
+    elif multi:
         from deep_contact_estimator_amd.distributed import AsyncRowGather
-        gatherer = AsyncRowGather(B, 16, torch.float32, dev, dst=0, depth=2)
+        gatherer = AsyncRowGather(B, 68, torch.uint8, dev, dst=0, depth=2)     # functional test transport (ranks share a GPU)
 
     def step():
-        out = model.predict(windows)
+        if rccl_info is not None:
+            return gatherer.step(windows)
         if gatherer is not None:
-            gatherer.submit(out["logits"])
-        return out
+            packed = model.predict_packed(windows)
+            gatherer.submit(packed)
+            return packed
+        return model.predict(windows)
 
     def drain():
         if gatherer is not None:
             gatherer.drain()
 
-    # 1. settle, 2. warm-up
-    settle_steps, settle_s = settle(torch, step, args.settle_s)
+    # 1. settle (kernels only -- the ranks stop on their own clocks, so no collective may run here), 2. warm-up
+    settle_steps, settle_s = settle(torch, lambda: model.predict(windows), args.settle_s)
+    if multi:
+        dist.barrier()
     for _ in range(args.warmup):
         out = step()
     drain()
@@ -498,29 +542,40 @@ def main():
                             "HBM-resident -> fused conv stack + fc1/fc2/fc3 -> logits+argmax+contact bits "
                             "(dce_forward_windows, fp32 MFMA); synthetic He-init checkpoint seed 1",
                 "batch_per_gpu": B, "global_batch": B * world, "window": 150, "channels": 54,
-                "sharding": "independent windows per rank" + ("; async RCCL gather of (B,16) logits to rank 0 per step" if multi else ""),
+                "sharding": "independent windows per rank" + ("; async RCCL gather of the (B,68)-byte packed results to rank 0 per step" if multi else ""),
                 "settle": {"steps": settle_steps, "seconds": round(settle_s, 3)},
             },
         }
+        if rccl_info is not None:
+            res["rccl"] = rccl_info
+        elif multi:
+            res["rccl"] = {"backend": f"none: torch.distributed {backend} with ranks sharing GPUs (functional test of the N>1 flow)"}
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
             kd = kernels[dom]
-            traffic, traffic_src = None, None
+            traffic, traffic_src, traffic_stale = None, None, None
             pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc_path):
                 try:
-                    ent = json.load(open(pmc_path)).get(dom, {})
+                    from deep_contact_estimator_amd import build as dce_build
+                    pmc = json.load(open(pmc_path))
+                    ent = pmc.get(dom, {})
                     traffic = ent.get("hbm_bytes_per_launch")
+                    # stale = the counters were collected on a library built from other sources than the one timed here
+                    prof_hash, here_hash = pmc.get("_meta", {}).get("source_hash"), dce_build.built_hash()
+                    traffic_stale = not (prof_hash and here_hash and prof_hash == here_hash)
                     traffic_src = (f"profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                                    f"profile {ent.get('profile')}; replayed, not measured in this run)")
                 except Exception:
                     traffic = None
             res["roofline"] = {
                 "kernel": dom, "bound": "mfma", "achieved": kd["executed_tflops"], "peak": kd["peak_tflops"],
-                "unit": "TFLOP/s", "frac": kd["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "unit": "TFLOP/s", "frac": kd["frac"], "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "flops_per_launch": EXEC_FLOP[dom] * B, "avg_launch_ms": kd["avg_ms"], "launches_timed": kd["launches"],
                 "algorithmic_flops_per_launch": ALGO_FLOP[dom] * B,
-                "hbm_informational": {"algorithmic_bytes_per_launch": ALGO_BYTES[dom] * B,
+                "hbm_informational": {"note": "the step's inputs (133 MB) fit the 256 MB Infinity Cache and are re-read every step: these are "
+                                              "cache-resident bytes moved per second, not HBM traffic",
+                                      "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * B,
                                       "algorithmic_GBs": kd["algorithmic_GBs"],
                                       "frac_of_8TBs": kd["algorithmic_GBs"] / PEAK_HBM_GBS},
                 "note": "achieved = matrix-pipe FLOPs issued per launch / average launch duration (HIP events on the launch "
@@ -550,7 +605,7 @@ def main():
                 "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s),
             }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not multi and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, windows.cpu().numpy(), seq_np, out["logits"].cpu().numpy(),
                                                out["pred"].cpu().numpy())
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]

@@ -23,13 +23,25 @@ SYMBOLS = {
     "dce_finalize_weights": (C.c_int, [C.c_void_p, C.c_int]),
     "dce_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dce_infer_sequence": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dce_forward_windows_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "dce_infer_sequence_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "dce_unpack_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dce_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "dce_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dce_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "dce_gather_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, _i64p, C.c_int, C.c_int]),
+    "dce_allreduce_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "dce_comm_sync": (C.c_int, [C.c_void_p]),
+    "dce_comm_destroy": (C.c_int, [C.c_void_p]),
     "dce_zscore_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "dce_forward_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dce_conv_layer_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int] + [C.c_void_p] * 6),
     "dce_confusion_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "dce_online_reset": (C.c_int, [C.c_void_p]),
     "dce_online_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dce_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dce_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), _i64p, C.c_int]),
+    "dce_last_plan": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "dce_sync": (C.c_int, [C.c_void_p]),
     "dce_last_error": (C.c_char_p, [C.c_void_p]),
 }
@@ -80,6 +92,21 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def use_process_rccl():
+    """Point libdce.so's run-time RCCL binding (csrc/dce_comm.hip) at the librccl that belongs to the HIP runtime of
+    this process: torch's bundled copy when torch is installed (its librccl is linked to its own libamdhip64), the
+    system ROCm one otherwise.  DCE_RCCL_LIB set by the user wins."""
+    if os.environ.get("DCE_RCCL_LIB"):
+        return
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(cand):
+            os.environ["DCE_RCCL_LIB"] = cand
+    except Exception:
+        pass
 
 
 class DceError(RuntimeError):

@@ -15,8 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdce.so")
-SOURCES = ["conv_stack.hip", "conv_wino.hip", "fc_gemm.hip", "fc_gemm_phased.hip", "fc_gemm_chain.hip", "fc_gemv.hip", "dce_api.hip"]
-HEADERS = ["dce_kernels.h", "conv_common.h", "fc6_chain.h", os.path.join("..", "..", "include", "dce.h")]
+SOURCES = ["conv_stack.hip", "conv_wino.hip", "fc_gemm.hip", "fc_gemm_phased.hip", "fc_gemm_chain.hip", "fc_gemv.hip", "dce_api.hip", "dce_comm.hip"]
+HEADERS = ["dce_kernels.h", "dce_ctx.h", "conv_common.h", "fc6_chain.h", os.path.join("..", "..", "include", "dce.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 OBJDIR = os.path.join(HERE, "build")
 
@@ -28,8 +28,28 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm to build libdce.so)")
 
 
+def source_hash() -> str:
+    """sha256 over the sources libdce.so is built from (names + contents, fixed order)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in sorted(SOURCES + HEADERS):
+        path = os.path.normpath(os.path.join(CSRC, rel))
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def built_hash(lib: str = LIB) -> str | None:
+    """The source hash recorded next to libdce.so when it was built (it travels with the .so to the GPU box):
+    ties measurements (profiles/pmc_latest.json) to the build they were taken on."""
+    try:
+        return open(lib + ".srchash").read().strip()
+    except OSError:
+        return None
+
+
 def stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or built_hash() is None:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -79,6 +99,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + " ".join(link) + "\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
+    with open(LIB + ".srchash", "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

@@ -24,6 +24,7 @@ from . import _lib
 from .synth import STATE_DICT_SHAPES
 
 WINDOW, CHANNELS, CLASSES = 150, 54, 16
+PACKED_ROW = 68                        # include/dce.h DCE_PACKED_ROW: 16 fp32 logits + 4 contact bits
 PRECISIONS = {"fp32": 0, "bf16_fc": 1}
 
 
@@ -79,6 +80,7 @@ class contact_cnn:
         if getattr(self, "_ctx", None):
             self._lib.dce_destroy(self._ctx)
             self._ctx = C.c_void_p()
+            self.comm_world = 0
         self._finalized = False             # a later call re-creates the ctx and uploads the weights again
 
     def __del__(self):
@@ -223,20 +225,182 @@ class contact_cnn:
             raise RuntimeError(f"expected a (T,{CHANNELS}) sequence, got {tuple(seq.shape)}")
         return self._run(seq, True)
 
+    # ---- packed results + the multi-GPU exchange (include/dce.h: dce_*_packed, dce_comm_*, dce_gather_results) ----
+    def _torch_stream(self, t):
+        import torch
+        _lib.check(self._lib.dce_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream), 0), self._ctx)
+
+    def _run_packed(self, x, raw_sequence: bool, out=None):
+        """-> (n,68) uint8 rows: 16 fp32 logits + 4 contact bits per window, written by the last kernel of the path.
+        CUDA tensor in -> CUDA tensor out (`out` may name a pre-allocated one); numpy in -> numpy out."""
+        self._finalize()
+        ctx, lib = self._ctx, self._lib
+        if _is_torch(x) and x.is_cuda:
+            import torch
+            x = x.contiguous()
+            if x.dtype != torch.float32:
+                x = x.float()
+            n = max(x.shape[0] - (WINDOW - 1) if raw_sequence else x.shape[0], 0)
+            if out is None:
+                out = torch.empty((n, PACKED_ROW), dtype=torch.uint8, device=x.device)
+            elif tuple(out.shape) != (n, PACKED_ROW) or out.dtype != torch.uint8 or not out.is_contiguous():
+                raise RuntimeError(f"out must be a contiguous ({n},{PACKED_ROW}) uint8 tensor")
+            self._torch_stream(x)
+            dst = C.c_void_p(out.data_ptr()) if n > 0 else None
+            if raw_sequence:
+                rc = lib.dce_infer_sequence_packed(ctx, C.c_void_p(x.data_ptr()), x.shape[0], WINDOW, 1, dst)
+            else:
+                rc = lib.dce_forward_windows_packed(ctx, C.c_void_p(x.data_ptr()), n, 1, dst)
+            _lib.check(rc, ctx)
+            return out
+        a = np.ascontiguousarray(x.detach().numpy() if _is_torch(x) else np.asarray(x), dtype=np.float32)
+        n = max(a.shape[0] - (WINDOW - 1) if raw_sequence else a.shape[0], 0)
+        out = np.empty((n, PACKED_ROW), np.uint8)
+        _lib.check(lib.dce_set_stream(ctx, None, 1), ctx)
+        dst = out.ctypes.data_as(C.c_void_p) if n > 0 else None
+        if raw_sequence:
+            rc = lib.dce_infer_sequence_packed(ctx, a.ctypes.data_as(C.c_void_p), a.shape[0], WINDOW, 0, dst)
+        else:
+            rc = lib.dce_forward_windows_packed(ctx, a.ctypes.data_as(C.c_void_p), n, 0, dst)
+        _lib.check(rc, ctx)
+        return out
+
+    def predict_packed(self, x, out=None):
+        """predict() with the results as (B,68)-byte rows (the gather's wire format)."""
+        self._check_windows(x)
+        return self._run_packed(x, False, out)
+
+    def infer_sequence_packed(self, seq, out=None):
+        """infer_sequence() with the results as (T-149,68)-byte rows."""
+        if seq.ndim != 2 or seq.shape[1] != CHANNELS:
+            raise RuntimeError(f"expected a (T,{CHANNELS}) sequence, got {tuple(seq.shape)}")
+        return self._run_packed(seq, True, out)
+
+    def unpack_results(self, packed):
+        """(n,68) packed rows -> dict(logits (n,16) f32, pred (n,) i32, contacts (n,4) u8), same kind as `packed`."""
+        ctx = self._ensure_ctx()
+        n = packed.shape[0]
+        if _is_torch(packed) and packed.is_cuda:
+            import torch
+            packed = packed.contiguous()
+            out = {"logits": torch.empty((n, CLASSES), dtype=torch.float32, device=packed.device),
+                   "pred": torch.empty((n,), dtype=torch.int32, device=packed.device),
+                   "contacts": torch.empty((n, 4), dtype=torch.uint8, device=packed.device)}
+            self._torch_stream(packed)
+            if n:
+                _lib.check(self._lib.dce_unpack_results(ctx, C.c_void_p(packed.data_ptr()), n, 1, C.c_void_p(out["logits"].data_ptr()),
+                                                        C.c_void_p(out["pred"].data_ptr()), C.c_void_p(out["contacts"].data_ptr())), ctx)
+            return out
+        a = np.ascontiguousarray(packed.numpy() if _is_torch(packed) else packed, dtype=np.uint8)
+        out = {"logits": np.empty((n, CLASSES), np.float32), "pred": np.empty((n,), np.int32), "contacts": np.empty((n, 4), np.uint8)}
+        if n:
+            _lib.check(self._lib.dce_unpack_results(ctx, a.ctypes.data_as(C.c_void_p), n, 0, out["logits"].ctypes.data_as(C.c_void_p),
+                                                    out["pred"].ctypes.data_as(C.c_void_p), out["contacts"].ctypes.data_as(C.c_void_p)), ctx)
+        return out
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: a fresh ncclUniqueId (128 bytes) for comm_init; carry it to the other ranks by any means."""
+        _lib.use_process_rccl()
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.load().dce_comm_get_unique_id(buf), None)
+        return bytes(buf)
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        """Join the RCCL communicator of the node's ranks (collective: blocks until all `world` ranks call)."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        _lib.use_process_rccl()
+        ctx = self._ensure_ctx()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(self._lib.dce_comm_init(ctx, int(rank), int(world), buf), ctx)
+        self.comm_rank, self.comm_world = int(rank), int(world)
+        return self
+
+    comm_rank, comm_world = 0, 0          # comm_world > 0: this model holds an RCCL communicator
+
+    def comm_info(self) -> dict:
+        """What RCCL itself reports for the communicator, and the library that was bound."""
+        r, w, v = C.c_int(), C.c_int(), C.c_int()
+        name = C.create_string_buffer(512)
+        _lib.check(self._lib.dce_comm_info(self._ctx, C.byref(r), C.byref(w), C.byref(v), name, 512), self._ctx)
+        return {"rank": r.value, "world": w.value, "rccl_version": v.value, "library": name.value.decode()}
+
+    def gather_results(self, packed, sizes=None, root: int = 0, out=None, async_: bool = False):
+        """ONE RCCL gather of every rank's (n_r,68) packed CUDA rows to `root` (dce_gather_results), on the library's
+        communication stream behind the kernels that produced them.  sizes[r] = rows of rank r (None: all equal).
+        Returns the (sum,68) tensor on the root (stream-ordered; `out` may name it), None elsewhere.  async_: the
+        gather overlaps later kernels; alternate two `packed`/`out` buffers and call comm_sync() before reading."""
+        import torch
+        if not self.comm_world:
+            raise RuntimeError("gather_results: call comm_init first")
+        packed = packed.contiguous()
+        n = packed.shape[0]
+        total = sum(sizes) if sizes is not None else n * self.comm_world
+        if self.comm_rank == root:
+            if out is None:
+                out = torch.empty((total, PACKED_ROW), dtype=torch.uint8, device=packed.device)
+            elif tuple(out.shape) != (total, PACKED_ROW) or not out.is_contiguous():
+                raise RuntimeError(f"out must be a contiguous ({total},{PACKED_ROW}) uint8 tensor")
+        rows = (C.c_int64 * self.comm_world)(*[int(v) for v in sizes]) if sizes is not None else None
+        self._torch_stream(packed)
+        _lib.check(self._lib.dce_gather_results(self._ctx, C.c_void_p(packed.data_ptr()) if n else None, n,
+                                                C.c_void_p(out.data_ptr()) if (self.comm_rank == root and total) else None,
+                                                rows, int(root), int(bool(async_))), self._ctx)
+        return out if self.comm_rank == root else None
+
+    def allreduce_counts(self, counts):
+        """Sum the (16,16) int64 confusion counts over the ranks (ncclAllReduce), in place."""
+        if _is_torch(counts) and counts.is_cuda:
+            self._torch_stream(counts)
+            _lib.check(self._lib.dce_allreduce_counts(self._ctx, C.c_void_p(counts.data_ptr()), 1), self._ctx)
+            return counts
+        a = counts.numpy() if _is_torch(counts) else counts
+        _lib.check(self._lib.dce_allreduce_counts(self._ctx, a.ctypes.data_as(C.c_void_p), 0), self._ctx)
+        return counts
+
+    def comm_sync(self):
+        _lib.check(self._lib.dce_comm_sync(self._ctx), self._ctx)
+
+    def comm_destroy(self):
+        if self.comm_world and self._ctx:
+            _lib.check(self._lib.dce_comm_destroy(self._ctx), self._ctx)
+        self.comm_world = 0
+
     def forward_taps(self, x):
-        """Parity-test hook: numpy (n,150,54) -> dict(feat, h1, h2, logits) as numpy."""
+        """Parity-test hook: numpy (n,150,54) -> dict(feat, h1, h2, logits) as numpy (feat / h1 are uint16 bf16 bit
+        patterns in the bf16_fc precision)."""
         self._finalize()
         a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
         self._check_windows(a)
         n = a.shape[0]
         out = {"h2": np.empty((n, 512), np.float32), "logits": np.empty((n, CLASSES), np.float32)}
-        if self._precision == "fp32":          # feat / h1 are bf16 scratch in the bf16-FC mode
-            out["feat"] = np.empty((n, 4736), np.float32)
-            out["h1"] = np.empty((n, 2048), np.float32)
+        act = np.float32 if self._precision == "fp32" else np.uint16     # bf16-FC mode: the bf16 bit patterns
+        out["feat"] = np.empty((n, 4736), act)
+        out["h1"] = np.empty((n, 2048), act)
         p = lambda k: out[k].ctypes.data_as(C.c_void_p) if k in out else None
         _lib.check(self._lib.dce_set_stream(self._ctx, None, 1), self._ctx)
         _lib.check(self._lib.dce_forward_taps(self._ctx, a.ctypes.data_as(C.c_void_p), n, 0,
                                               p("feat"), p("h1"), p("h2"), p("logits")), self._ctx)
+        return out
+
+    CONV_KERNELS = {"wino2": 0, "wino1x8": 1, "half": 2, "quarter": 3, "direct": 4, "wino1x4": 5, "wino4": 6}
+
+    def conv_layer_taps(self, x, kernel="wino2"):
+        """Parity-test hook (dce_conv_layer_taps): numpy (n<=64,150,54) pre-normalised windows through ONE named conv
+        kernel family -> dict(conv1 (n,64,150), conv2 (n,64,150), pool1 (n,64,75), conv3 (n,128,75), conv4 (n,128,75),
+        feat (n,4736)), post-ReLU, PyTorch layout -- the reference's forward-hook taps (tests/golden/make_golden.py)."""
+        self._finalize()
+        a = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+        self._check_windows(a)
+        n = a.shape[0]
+        out = {"conv1": np.empty((n, 64, 150), np.float32), "conv2": np.empty((n, 64, 150), np.float32),
+               "pool1": np.empty((n, 64, 75), np.float32), "conv3": np.empty((n, 128, 75), np.float32),
+               "conv4": np.empty((n, 128, 75), np.float32), "feat": np.empty((n, 4736), np.float32)}
+        _lib.check(self._lib.dce_set_stream(self._ctx, None, 1), self._ctx)
+        _lib.check(self._lib.dce_conv_layer_taps(self._ctx, a.ctypes.data_as(C.c_void_p), n, self.CONV_KERNELS.get(kernel, kernel),
+                                                 *[out[k].ctypes.data_as(C.c_void_p) for k in ("conv1", "conv2", "pool1", "conv3", "conv4", "feat")]),
+                   self._ctx)
         return out
 
     def zscore_windows(self, seq, first: int = 0, n: int | None = None):
@@ -314,6 +478,12 @@ class contact_cnn:
         _lib.check(self._lib.dce_profile_read(self._ctx, ms, cnt, int(reset)), self._ctx)
         names = ("conv_stack", "fc1_gemm", "fc2_gemm", "fc3_tail")
         return {k: {"ms": ms[i], "launches": cnt[i]} for i, k in enumerate(names)}
+
+    def last_plan(self) -> list[str]:
+        """Kernel families launched by this model's most recent kernel sequence, in launch order (dce_last_plan)."""
+        buf = C.create_string_buffer(1024)
+        _lib.check(self._lib.dce_last_plan(self._ensure_ctx(), buf, 1024), self._ctx)
+        return buf.value.decode().split()
 
     def sync(self):
         if self._ctx:

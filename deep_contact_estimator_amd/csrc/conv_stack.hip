@@ -180,9 +180,9 @@ __device__ __forceinline__ bool col_valid(int p)
 }
 
 // ReLU + write back a layer's accumulators in place (no pooling).
-template <int S, int WS, int TLEN>
+template <int S, int WS, int TLEN, bool TAPS = false>
 __device__ __forceinline__ void store_plain(float* __restrict__ act, const f32x16 (&acc)[NT],
-                                            int m0, int nt0, int lane)
+                                            int m0, int nt0, int lane, float* __restrict__ tap = nullptr, int cout = 0)
 {
     const int j = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -194,6 +194,9 @@ __device__ __forceinline__ void store_plain(float* __restrict__ act, const f32x1
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 act[co * S + p + 1] = valid ? relu_nan(acc[t][r]) : 0.f;
+                if constexpr (TAPS) {
+                    if (valid) { const int w = (p - 2) >= WS ? 1 : 0; tap[((size_t)w * cout + co) * TLEN + (p - 2 - WS * w)] = relu_nan(acc[t][r]); }
+                }
             }
         }
     }
@@ -202,8 +205,10 @@ __device__ __forceinline__ void store_plain(float* __restrict__ act, const f32x1
 // ReLU + MaxPool1d(2,2) + write back into the stage-2 layout (q = p/2 + 1).  After the
 // adjacent-lane max both lanes of a pair hold the pooled value, so the even lane stores
 // accumulator row r and the odd lane row r+1: every lane stores, no per-store predication.
+template <bool TAPS = false>
 __device__ __forceinline__ void store_pool_stage2(float* __restrict__ act, const f32x16 (&acc)[NT],
-                                                  int m0, int nt0, int lane)
+                                                  int m0, int nt0, int lane,
+                                                  float* __restrict__ tap_conv2 = nullptr, float* __restrict__ tap_pool1 = nullptr)
 {
     const int j = lane & 31, h = lane >> 5, odd = j & 1;
 #pragma unroll
@@ -218,19 +223,42 @@ __device__ __forceinline__ void store_pool_stage2(float* __restrict__ act, const
                 const float o0 = fmaxf(v0, swap_adjacent(v0));   // a NaN window is NaN everywhere
                 const float o1 = fmaxf(v1, swap_adjacent(v1));
                 dst[((r & 3) + 8 * (r >> 2)) * S2] = valid ? (odd ? o1 : o0) : 0.f;
+                if constexpr (TAPS) {
+                    const int pj = 32 * (nt0 + t) + j;                       // this lane's own column
+                    if (col_valid<152, 150>(pj)) {
+                        const int w = (pj - 2) >= 152 ? 1 : 0, tt = pj - 2 - 152 * w;
+                        tap_conv2[((size_t)w * 64 + m0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 150 + tt] = v0;
+                        tap_conv2[((size_t)w * 64 + m0 + ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 150 + tt] = v1;
+                    }
+                    if (valid) {
+                        const int w = (p - 2) >= 152 ? 1 : 0, tt = (p - 2 - 152 * w) >> 1;
+                        tap_pool1[((size_t)w * 64 + m0 + 4 * h + odd + (r & 3) + 8 * (r >> 2)) * 75 + tt] = odd ? o1 : o0;
+                    }
+                }
             }
         }
     }
 }
 
 // ReLU + MaxPool1d(2,2) (floor: t = 74 dropped) + flatten (c*37 + j) to HBM; same lane pairing.
-template <typename FT>   // FT = float (headline) or unsigned short (bf16 features for DCE_BF16_FC)
+template <typename FT, bool TAPS = false>   // FT = float (headline) or unsigned short (bf16 features for DCE_BF16_FC)
 __device__ __forceinline__ void store_pool_feat(FT* __restrict__ feat, int64_t win0, int nvalid,
-                                                const f32x16 (&acc)[NT], int m0, int lane)
+                                                const f32x16 (&acc)[NT], int m0, int lane, float* __restrict__ tap_conv4 = nullptr)
 {
     const int j = lane & 31, h = lane >> 5, odd = j & 1;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        if constexpr (TAPS) {
+            const int pj = 32 * t + j;                                       // this lane's own column of the stage-2 layout
+            if (col_valid<76, 75>(pj)) {
+                const int w = (pj - 2) >= 76 ? 1 : 0, tt = pj - 2 - 76 * w;
+                if (w < nvalid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tap_conv4[((size_t)w * 128 + m0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 75 + tt] = relu_nan(acc[t][r]);
+                }
+            }
+        }
         const int q = 32 * t + (j & ~1);
         const int r_ = q - 2;
         const int w = r_ >= 76 ? 1 : 0;
@@ -251,9 +279,9 @@ __device__ __forceinline__ void store_pool_feat(FT* __restrict__ feat, int64_t w
 // ------------------------------------------------------------------------------------------
 // The fused kernel
 // ------------------------------------------------------------------------------------------
-template <bool ZS, typename FT>
+template <bool ZS, typename FT, bool TAPS = false>
 __global__ __launch_bounds__(256, 2)
-void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT* __restrict__ feat)
+void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT* __restrict__ feat, LayerTaps taps)
 {
     extern __shared__ __attribute__((aligned(16))) float act[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -315,7 +343,7 @@ void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT
         TRACE_MARK(2);
         a0 = load_a(ap2, 0);                             // next layer's first weights: in flight
         __syncthreads();                                 // across the write-back
-        store_plain<S1, 152, 150>(act, acc, 32 * mt, nt0, lane);
+        store_plain<S1, 152, 150, TAPS>(act, acc, 32 * mt, nt0, lane, TAPS ? taps.conv1 + win0 * 64 * 150 : nullptr, 64);
         acc_init_bias(bias_lds + 64, 32 * mt, h, acc);
         __syncthreads();
         TRACE_MARK(3);
@@ -329,7 +357,8 @@ void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT
         const float4* ap4 = reinterpret_cast<const float4*>(pk.w[3]) + mt * (3 * 16 * 64) + lane;
         a0 = load_a(ap3, 0);
         __syncthreads();
-        store_pool_stage2(act, acc, 32 * mt12, nt0, lane);
+        store_pool_stage2<TAPS>(act, acc, 32 * mt12, nt0, lane, TAPS ? taps.conv2 + win0 * 64 * 150 : nullptr,
+                                TAPS ? taps.pool1 + win0 * 64 * 75 : nullptr);
         acc_init_bias(bias_lds + 128, 32 * mt, h, acc);
         __syncthreads();
         TRACE_MARK(5);
@@ -338,14 +367,14 @@ void conv_stack_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT
         TRACE_MARK(6);
         a0 = load_a(ap4, 0);
         __syncthreads();
-        store_plain<S2, 76, 75>(act, acc, 32 * mt, 0, lane);
+        store_plain<S2, 76, 75, TAPS>(act, acc, 32 * mt, 0, lane, TAPS ? taps.conv3 + win0 * 128 * 75 : nullptr, 128);
         acc_init_bias(bias_lds + 256, 32 * mt, h, acc);
         __syncthreads();
         TRACE_MARK(7);
         // ---- conv4: 128 -> 128, ReLU, pool, flatten -> HBM
         conv_mfma<128, S2>(act + h * S2 + j, ap4, a0, acc);
         TRACE_MARK(8);
-        store_pool_feat(feat, win0, nvalid, acc, 32 * mt, lane);
+        store_pool_feat<FT, TAPS>(feat, win0, nvalid, acc, 32 * mt, lane, TAPS ? taps.conv4 + win0 * 128 * 75 : nullptr);
         TRACE_MARK(9);
     }
 }
@@ -372,7 +401,23 @@ hipError_t init_conv_stack()
     if ((e = grant_conv_lds<true, float>()) != hipSuccess) return e;
     if ((e = grant_conv_lds<false, float>()) != hipSuccess) return e;
     if ((e = grant_conv_lds<true, unsigned short>()) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_kernel<false, float, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     return grant_conv_lds<false, unsigned short>();
+}
+
+hipError_t launch_conv_wino_taps(int kernel, const float* src, int64_t n, const ConvPack& pk, float* f,
+                                 const LayerTaps& taps, hipStream_t st);
+
+// dce_conv_layer_taps: one named conv kernel family with the per-layer taps on (kernel 4 = this file's direct form)
+hipError_t launch_conv_taps(int kernel, const float* windows, int64_t n, const ConvPack& pk, float* feat,
+                            const LayerTaps& taps, hipStream_t st)
+{
+    if (kernel != 4) return launch_conv_wino_taps(kernel, windows, n, pk, feat, taps, st);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL((conv_stack_kernel<false, float, true>), dim3((unsigned)((n + NW - 1) / NW)), dim3(256),
+                       LDS_FLOATS * sizeof(float), st, windows, n, pk, feat, taps);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const ConvPack& pk,
@@ -382,17 +427,18 @@ hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const Conv
     if (n <= 0) return hipSuccess;
     size_t lds = LDS_FLOATS * sizeof(float);
 #if DCE_TRACE
-    if (getenv("DCE_ONE_PER_CU")) lds = 100 * 1024;      // debug: force one workgroup per CU
+    if (tune().one_per_cu) lds = 100 * 1024;      // debug: force one workgroup per CU
 #endif
     const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
+    plan_note("conv_direct");
     if (feat_bf16) {
         unsigned short* f = static_cast<unsigned short*>(feat);
-        if (zscore) hipLaunchKernelGGL((conv_stack_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f);
-        else        hipLaunchKernelGGL((conv_stack_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f);
+        if (zscore) hipLaunchKernelGGL((conv_stack_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f, LayerTaps{});
+        else        hipLaunchKernelGGL((conv_stack_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f, LayerTaps{});
     } else {
         float* f = static_cast<float*>(feat);
-        if (zscore) hipLaunchKernelGGL((conv_stack_kernel<true, float>), grid, block, lds, st, src, n, pk, f);
-        else        hipLaunchKernelGGL((conv_stack_kernel<false, float>), grid, block, lds, st, src, n, pk, f);
+        if (zscore) hipLaunchKernelGGL((conv_stack_kernel<true, float>), grid, block, lds, st, src, n, pk, f, LayerTaps{});
+        else        hipLaunchKernelGGL((conv_stack_kernel<false, float>), grid, block, lds, st, src, n, pk, f, LayerTaps{});
     }
     return hipGetLastError();
 }

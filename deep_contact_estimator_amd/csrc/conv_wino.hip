@@ -362,10 +362,10 @@ __device__ __forceinline__ void col_offsets(int nt0, int j, int (&boff)[NTW])
 }
 
 // output transform + ReLU + in-place write-back, no pooling (conv1: T=150, conv3: T=75)
-template <int RS, int WSEG, int TP, int T, int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW>
+template <int RS, int WSEG, int TP, int T, int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW, bool TAPS = false>
 __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const f32x4 (&acc)[MT][NTW][4],
-                                                 int co0, int nt0, int lane)
-{
+                                                 int co0, int nt0, int lane, float* __restrict__ tap = nullptr, int cout = 0)
+{   // tap (TAPS only): this layer's (windows, cout, T) block of the first window of the workgroup
     const int j = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
@@ -386,15 +386,21 @@ __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const 
                     d[0] = fmaxf((m0 + m1) + m2, 0.f);
                     d[1] = (T % 2 == 0 || 2 * m + 1 < T) ? fmaxf((m1 - m2) - m3, 0.f) : 0.f;   // index T+1 is a zero pad
 #endif
+                    if constexpr (TAPS) {
+                        float* tp = tap + ((size_t)w * cout + co0 + 16 * mt + 4 * q + r) * T + 2 * m;
+                        tp[0] = d[0];
+                        if (2 * m + 1 < T) tp[1] = d[1];
+                    }
                 }
         }
     }
 }
 
 // output transform + ReLU + MaxPool1d(2,2) -> stage-2 layout (conv2)
-template <int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW>
+template <int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW, bool TAPS = false, int R2 = RS2, int W2 = WS2>
 __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, const f32x4 (&acc)[MT][NTW][4],
-                                                       int co0, int nt0, int lane)
+                                                       int co0, int nt0, int lane,
+                                                       float* __restrict__ tap_conv2 = nullptr, float* __restrict__ tap_pool1 = nullptr)
 {
     const int j = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -411,21 +417,27 @@ __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, 
                     const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
                     // max(relu(y0), relu(y1)) = max(y0, y1, 0)
 #if WINO_EXP & 16
-                    act[(co0 + 16 * mt + 4 * q + r) * RS2 + w * WS2 + 1 + m] = m0; asm volatile("" :: "v"(m1), "v"(m2), "v"(m3));
+                    act[(co0 + 16 * mt + 4 * q + r) * R2 + w * W2 + 1 + m] = m0; asm volatile("" :: "v"(m1), "v"(m2), "v"(m3));
 #else
-                    act[(co0 + 16 * mt + 4 * q + r) * RS2 + w * WS2 + 1 + m] =
+                    act[(co0 + 16 * mt + 4 * q + r) * R2 + w * W2 + 1 + m] =
                         fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
 #endif
+                    if constexpr (TAPS) {
+                        const size_t row = (size_t)w * 64 + co0 + 16 * mt + 4 * q + r;
+                        tap_conv2[row * 150 + 2 * m] = fmaxf((m0 + m1) + m2, 0.f);
+                        tap_conv2[row * 150 + 2 * m + 1] = fmaxf((m1 - m2) - m3, 0.f);
+                        tap_pool1[row * 75 + m] = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+                    }
                 }
         }
     }
 }
 
 // output transform + ReLU + MaxPool1d(2,2) (pairs 0..36; t = 74 dropped) + flatten c*37+j -> HBM
-template <typename FT, int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW>
+template <typename FT, int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW, bool TAPS = false>
 __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t win0, int nvalid,
                                                 const f32x4 (&acc)[MT][NTW][4], int co0, int lane,
-                                                bool nan0, bool nan1)
+                                                bool nan0, bool nan1, float* __restrict__ tap_conv4 = nullptr)
 {
     const int j = lane & 15, q = lane >> 4;
     // one 64-bit address per column tile; the 8 (row tile, r) outputs of a lane sit at compile-time offsets from it
@@ -437,6 +449,20 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
         const int n = 16 * nt + j;
         const int w = (NWIN > 1 && n >= TP2) ? 1 : 0;
         const int m = n - w * TP2;
+        if constexpr (TAPS) {
+            if (n < NWIN * TP2 && w < nvalid) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
+                        const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
+                        float* tp = tap_conv4 + ((size_t)w * 128 + co0 + 16 * mt + 4 * q + r) * 75 + 2 * m;
+                        tp[0] = fmaxf((m0 + m1) + m2, 0.f);
+                        if (2 * m + 1 < 75) tp[1] = fmaxf((m1 - m2) - m3, 0.f);
+                    }
+            }
+        }
         if (n < NWIN * TP2 && m < 37 && w < nvalid) {
             FT* base = feat + (win0 + w) * FEAT + (co0 + 4 * q) * 37 + m;
             const bool bad = w ? nan1 : nan0;
@@ -460,10 +486,10 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
 // ------------------------------------------------------------------------------------------
 // The fused kernel
 // ------------------------------------------------------------------------------------------
-template <bool ZS, typename FT>
+template <bool ZS, typename FT, bool TAPS = false>
 __global__ __launch_bounds__(256, 2)
 void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT* __restrict__ feat,
-                      const long long* __restrict__ src_row)
+                      const long long* __restrict__ src_row, LayerTaps taps)
 {
     extern __shared__ __attribute__((aligned(16))) float act[];
     if (src_row) src += *src_row * CH;                    // online graph: the window start lives in device memory
@@ -555,7 +581,7 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
         TRACE_MARK(2);
         a = load_a8(ap2, 0);                              // next layer's first weights in flight
         __syncthreads();                                  // across the write-back
-        wino_store_plain<RS1, WS1, TP1, 150>(act, acc, co0, nt0, lane);
+        wino_store_plain<RS1, WS1, TP1, 150, MT, NTW, NW, TAPS>(act, acc, co0, nt0, lane, TAPS ? taps.conv1 + win0 * 64 * 150 : nullptr, 64);
         __syncthreads();
         TRACE_MARK(3);
         wino_mfma<RS1, 16>(xrow1, boff, ap2, a, bias_lds + 64, co0, lane, acc);
@@ -563,7 +589,8 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
         const float4* ap3 = reinterpret_cast<const float4*>(pk.ww[2]) + wv * (16 * 128) + 2 * lane;
         a = load_a8(ap3, 0);
         __syncthreads();
-        wino_store_pool_stage2(act, acc, co0, nt0, lane);
+        wino_store_pool_stage2<MT, NTW, NW, TAPS>(act, acc, co0, nt0, lane, TAPS ? taps.conv2 + win0 * 64 * 150 : nullptr,
+                                                  TAPS ? taps.pool1 + win0 * 64 * 75 : nullptr);
         // stage-2 pads: index 0, 76, 77 of each window segment, all 128 rows
         for (int i = tid; i < 128 * 6; i += 256) {
             const int c = i / 6, k = i % 6;
@@ -579,12 +606,12 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
         TRACE_MARK(6);
         a = load_a8(ap4, 0);
         __syncthreads();
-        wino_store_plain<RS2, WS2, TP2, 75>(act, acc, co2, 0, lane);
+        wino_store_plain<RS2, WS2, TP2, 75, MT, NTW, NW, TAPS>(act, acc, co2, 0, lane, TAPS ? taps.conv3 + win0 * 128 * 75 : nullptr, 128);
         __syncthreads();
         TRACE_MARK(7);
         wino_mfma<RS2, 32>(xrow2, boff, ap4, a, bias_lds + 256, co2, lane, acc);
         TRACE_MARK(8);
-        wino_store_feat(feat, win0, nvalid, acc, co2, lane, nan0, nan1);
+        wino_store_feat<FT, MT, NTW, NW, TAPS>(feat, win0, nvalid, acc, co2, lane, nan0, nan1, TAPS ? taps.conv4 + win0 * 128 * 75 : nullptr);
         TRACE_MARK(9);
     }
 }
@@ -597,10 +624,10 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
 // 3 column tiles (38 pairs): 1752 MFMAs per wave instead of 3120 for a half-empty two-window
 // workgroup, and twice as many workgroups to spread over the CUs.
 // ------------------------------------------------------------------------------------------
-template <bool ZS>
+template <bool ZS, bool TAPS = false>
 __global__ __launch_bounds__(256)
 void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat,
-                       const long long* __restrict__ src_row)
+                       const long long* __restrict__ src_row, LayerTaps taps)
 {
     extern __shared__ __attribute__((aligned(16))) float act[];
     if (src_row) src += *src_row * CH;                    // online graph: the window start lives in device memory
@@ -661,13 +688,14 @@ void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
         wino_mfma_deep<RS1, 14, 1, 5, PF, 1, 0>(xrow1, boff, ap1, ap2, ring, bias_lds, co0, lane, acc);
         TRACE_MARK(2);
         __syncthreads();
-        wino_store_plain<RS1, WS1, TP1, 150, 1, 5, 1>(act, acc, co0, 0, lane);
+        wino_store_plain<RS1, WS1, TP1, 150, 1, 5, 1, TAPS>(act, acc, co0, 0, lane, TAPS ? taps.conv1 + win0 * 64 * 150 : nullptr, 64);
         __syncthreads();
         TRACE_MARK(3);
         wino_mfma_deep<RS1, 16, 1, 5, PF, 2, 14 % PF>(xrow1, boff, ap2, ap3, ring, bias_lds + 64, co0, lane, acc);
         TRACE_MARK(4);
         __syncthreads();
-        wino_store_pool_stage2<1, 5, 1>(act, acc, co0, 0, lane);
+        wino_store_pool_stage2<1, 5, 1, TAPS>(act, acc, co0, 0, lane, TAPS ? taps.conv2 + win0 * 64 * 150 : nullptr,
+                                              TAPS ? taps.pool1 + win0 * 64 * 75 : nullptr);
         for (int i = tid; i < 128 * 3; i += 256) {       // stage-2 pads: index 0, 76, 77
             const int c = i / 3, k = i % 3;
             act[c * RS2 + (k == 0 ? 0 : 75 + k)] = 0.f;
@@ -683,12 +711,12 @@ void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
         wino_mfma_deep<RS2, 16, 2, 3, PF, 2, 30 % PF>(xrow2, boff, ap3, ap4, ring, bias_lds + 128, co2, lane, acc);
         TRACE_MARK(6);
         __syncthreads();
-        wino_store_plain<RS2, WS2, TP2, 75, 2, 3, 1>(act, acc, co2, 0, lane);
+        wino_store_plain<RS2, WS2, TP2, 75, 2, 3, 1, TAPS>(act, acc, co2, 0, lane, TAPS ? taps.conv3 + win0 * 128 * 75 : nullptr, 128);
         __syncthreads();
         TRACE_MARK(7);
         wino_mfma_deep<RS2, 32, 2, 3, PF, 2, 46 % PF>(xrow2, boff, ap4, nullptr, ring, bias_lds + 256, co2, lane, acc);
         TRACE_MARK(8);
-        wino_store_feat<float, 2, 3, 1>(feat, win0, 1, acc, co2, lane, nan0, false);
+        wino_store_feat<float, 2, 3, 1, TAPS>(feat, win0, 1, acc, co2, lane, nan0, false, TAPS ? taps.conv4 + win0 * 128 * 75 : nullptr);
         TRACE_MARK(9);
     }
 }
@@ -705,10 +733,10 @@ void conv_wino1_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, fl
 //  of wino_step needs at least two column tiles per wave)
 // Same LDS layout, same per-accumulator K order: bit-identical features.
 // ------------------------------------------------------------------------------------------
-template <int NTW1>
+template <int NTW1, bool TAPS = false>
 __device__ __forceinline__ void wino1x8_stage1(float* __restrict__ act, const float* __restrict__ bias_lds,
                                                const float4* ap1, const float4* ap2, const float4* ap3, A8 (&ring)[WINO1_PF],
-                                               int rt, int nt0, int lane, int tid)
+                                               int rt, int nt0, int lane, int tid, const LayerTaps& taps, int64_t win0)
 {
     constexpr int PF = WINO1_PF;
     const int j = lane & 15, q = lane >> 4;
@@ -720,23 +748,24 @@ __device__ __forceinline__ void wino1x8_stage1(float* __restrict__ act, const fl
     wino_mfma_deep<RS1, 14, 1, NTW1, PF, 1, 0>(xrow1, boff, ap1, ap2, ring, bias_lds, co0, lane, acc);
     TRACE_MARK(2);
     __syncthreads();
-    wino_store_plain<RS1, WS1, TP1, 150, 1, NTW1, 1>(act, acc, co0, nt0, lane);
+    wino_store_plain<RS1, WS1, TP1, 150, 1, NTW1, 1, TAPS>(act, acc, co0, nt0, lane, TAPS ? taps.conv1 + win0 * 64 * 150 : nullptr, 64);
     __syncthreads();
     TRACE_MARK(3);
     wino_mfma_deep<RS1, 16, 1, NTW1, PF, 1, 14 % PF>(xrow1, boff, ap2, ap3, ring, bias_lds + 64, co0, lane, acc);
     TRACE_MARK(4);
     __syncthreads();
-    wino_store_pool_stage2<1, NTW1, 1>(act, acc, co0, nt0, lane);
+    wino_store_pool_stage2<1, NTW1, 1, TAPS>(act, acc, co0, nt0, lane, TAPS ? taps.conv2 + win0 * 64 * 150 : nullptr,
+                                             TAPS ? taps.pool1 + win0 * 64 * 75 : nullptr);
     for (int i = tid; i < 128 * 3; i += 512) {           // stage-2 pads: index 0, 76, 77
         const int c = i / 3, k = i % 3;
         act[c * RS2 + (k == 0 ? 0 : 75 + k)] = 0.f;
     }
 }
 
-template <bool ZS>
+template <bool ZS, bool TAPS = false>
 __global__ __launch_bounds__(512)
 void conv_wino1x8_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat,
-                         const long long* __restrict__ src_row)
+                         const long long* __restrict__ src_row, LayerTaps taps)
 {
     extern __shared__ __attribute__((aligned(16))) float act[];
     if (src_row) src += *src_row * CH;                    // online graph: the window start lives in device memory
@@ -787,8 +816,8 @@ void conv_wino1x8_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, 
     const float4* ap2 = reinterpret_cast<const float4*>(pk.ww[1]) + (rt >> 1) * (16 * 128) + 2 * lane + (rt & 1);
     const float4* ap3 = reinterpret_cast<const float4*>(pk.ww[2]) + (wv >> 1) * (16 * 128) + 2 * lane + (wv & 1);
     const float4* ap4 = reinterpret_cast<const float4*>(pk.ww[3]) + (wv >> 1) * (32 * 128) + 2 * lane + (wv & 1);
-    if (wv < 4) wino1x8_stage1<3>(act, bias_lds, ap1, ap2, ap3, ring, rt, 0, lane, tid);
-    else        wino1x8_stage1<2>(act, bias_lds, ap1, ap2, ap3, ring, rt, 3, lane, tid);
+    if (wv < 4) wino1x8_stage1<3, TAPS>(act, bias_lds, ap1, ap2, ap3, ring, rt, 0, lane, tid, taps, win0);
+    else        wino1x8_stage1<2, TAPS>(act, bias_lds, ap1, ap2, ap3, ring, rt, 3, lane, tid, taps, win0);
     {   // ---- stage 2: wave = row tile wv (16 output channels) x 3 column tiles
         const int j = lane & 15, q = lane >> 4;
         const float* xrow2 = act + q * RS2;
@@ -801,12 +830,12 @@ void conv_wino1x8_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, 
         wino_mfma_deep<RS2, 16, 1, 3, PF, 1, 30 % PF>(xrow2, boff, ap3, ap4, ring, bias_lds + 128, co2, lane, acc);
         TRACE_MARK(6);
         __syncthreads();
-        wino_store_plain<RS2, WS2, TP2, 75, 1, 3, 1>(act, acc, co2, 0, lane);
+        wino_store_plain<RS2, WS2, TP2, 75, 1, 3, 1, TAPS>(act, acc, co2, 0, lane, TAPS ? taps.conv3 + win0 * 128 * 75 : nullptr, 128);
         __syncthreads();
         TRACE_MARK(7);
         wino_mfma_deep<RS2, 32, 1, 3, PF, 1, 46 % PF>(xrow2, boff, ap4, nullptr, ring, bias_lds + 256, co2, lane, acc);
         TRACE_MARK(8);
-        wino_store_feat<float, 1, 3, 1>(feat, win0, 1, acc, co2, lane, nan0, false);
+        wino_store_feat<float, 1, 3, 1, TAPS>(feat, win0, 1, acc, co2, lane, nan0, false, TAPS ? taps.conv4 + win0 * 128 * 75 : nullptr);
         TRACE_MARK(9);
     }
 }
@@ -834,10 +863,11 @@ constexpr int HLDS_FLOATS = HACT_FLOATS + 384 + 2 + 864 + 2; // + biases + NaN f
 constexpr int WINOH_MAX_N = 128, WINOQ_MAX_N = 64;
 
 // stage 1 of a segment for one wave: row tile rt x NTW column tiles starting at column tile nt0 (column n <-> pair a + n)
-template <int NTW>
+template <int NTW, bool TAPS = false>
 __device__ __forceinline__ void seg_stage1(float* __restrict__ act, const float* __restrict__ bias_lds,
                                            const float4* ap1, const float4* ap2, const float4* ap3, A8 (&ring)[WINO1_PF],
-                                           int rt, int nt0, int lane, int tid, int a1, int b1, int a2, int b2, int tb1, int tb2)
+                                           int rt, int nt0, int lane, int tid, int a1, int b1, int a2, int b2, int tb1, int tb2,
+                                           const LayerTaps& taps, int64_t win0)
 {
     constexpr int PF = WINO1_PF;
     const int j = lane & 15, q = lane >> 4;
@@ -859,6 +889,10 @@ __device__ __forceinline__ void seg_stage1(float* __restrict__ act, const float*
                 float* d = act + (co0 + 4 * q + r) * RS1H + 2 * m - tb1;
                 d[0] = fmaxf((m0 + m1) + m2, 0.f);
                 d[1] = fmaxf((m1 - m2) - m3, 0.f);
+                if constexpr (TAPS) {      // (halo pairs are written by both neighbouring segments: the same bits)
+                    float* tp = taps.conv1 + (win0 * 64 + co0 + 4 * q + r) * 150 + 2 * m;
+                    tp[0] = d[0]; tp[1] = d[1];
+                }
             }
         }
     }
@@ -875,6 +909,12 @@ __device__ __forceinline__ void seg_stage1(float* __restrict__ act, const float*
             for (int r = 0; r < 4; ++r) {
                 const float m0 = acc[0][nt][0][r], m1 = acc[0][nt][1][r], m2 = acc[0][nt][2][r], m3 = acc[0][nt][3][r];
                 act[(co0 + 4 * q + r) * RS2H + m - tb2] = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+                if constexpr (TAPS) {
+                    const int64_t row = win0 * 64 + co0 + 4 * q + r;
+                    taps.conv2[row * 150 + 2 * m] = fmaxf((m0 + m1) + m2, 0.f);
+                    taps.conv2[row * 150 + 2 * m + 1] = fmaxf((m1 - m2) - m3, 0.f);
+                    taps.pool1[row * 75 + m] = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+                }
             }
         }
     }
@@ -885,10 +925,10 @@ __device__ __forceinline__ void seg_stage1(float* __restrict__ act, const float*
     }
 }
 
-template <bool ZS, int NSEG, int NT1, int NT2>
+template <bool ZS, int NSEG, int NT1, int NT2, bool TAPS = false>
 __global__ __launch_bounds__(512)
 void conv_wino_seg_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat,
-                          const long long* __restrict__ src_row)
+                          const long long* __restrict__ src_row, LayerTaps taps)
 {
     static_assert((NSEG == 2 && NT1 == 3 && NT2 == 2) || (NSEG == 4 && NT1 == 2 && NT2 == 1), "column tiles per segment count");
     extern __shared__ __attribute__((aligned(16))) float act[];
@@ -952,9 +992,9 @@ void conv_wino_seg_kernel(const float* __restrict__ src, int64_t n, ConvPack pk,
 
     // ---- stage 1: conv1, conv2; wave (row tile w&3, column group w>>2): halves = column tiles {0,1} / {2}, quarters = {0} / {1}
     //      (waves w and w+4 share a SIMD: every SIMD carries NT1 column tiles of one row tile)
-    if constexpr (NSEG == 4) seg_stage1<1>(act, bias_lds, ap1, ap2, ap3, ring, rt, wv >> 2, lane, tid, a1, b1, a2, b2, tb1, tb2);
-    else if (wv < 4)         seg_stage1<2>(act, bias_lds, ap1, ap2, ap3, ring, rt, 0, lane, tid, a1, b1, a2, b2, tb1, tb2);
-    else                     seg_stage1<1>(act, bias_lds, ap1, ap2, ap3, ring, rt, 2, lane, tid, a1, b1, a2, b2, tb1, tb2);
+    if constexpr (NSEG == 4) seg_stage1<1, TAPS>(act, bias_lds, ap1, ap2, ap3, ring, rt, wv >> 2, lane, tid, a1, b1, a2, b2, tb1, tb2, taps, win0);
+    else if (wv < 4)         seg_stage1<2, TAPS>(act, bias_lds, ap1, ap2, ap3, ring, rt, 0, lane, tid, a1, b1, a2, b2, tb1, tb2, taps, win0);
+    else                     seg_stage1<1, TAPS>(act, bias_lds, ap1, ap2, ap3, ring, rt, 2, lane, tid, a1, b1, a2, b2, tb1, tb2, taps, win0);
     // ---- stage 2 (all eight waves): conv3, conv4 for row tile wv x NT2 column tiles
     {
         f32x4 acc[1][NT2][4];
@@ -976,6 +1016,11 @@ void conv_wino_seg_kernel(const float* __restrict__ src, int64_t n, ConvPack pk,
                     float* d = act + (co2 + 4 * q + r) * RS2H + 2 * m - tb2;
                     d[0] = fmaxf((m0 + m1) + m2, 0.f);
                     d[1] = 2 * m + 1 < 75 ? fmaxf((m1 - m2) - m3, 0.f) : 0.f;        // x[75] is a zero pad
+                    if constexpr (TAPS) {
+                        float* tp = taps.conv3 + (win0 * 128 + co2 + 4 * q + r) * 75 + 2 * m;
+                        tp[0] = d[0];
+                        if (2 * m + 1 < 75) tp[1] = d[1];
+                    }
                 }
             }
         }
@@ -994,6 +1039,11 @@ void conv_wino_seg_kernel(const float* __restrict__ src, int64_t n, ConvPack pk,
                     const float m0 = acc[0][nt][0][r], m1 = acc[0][nt][1][r], m2 = acc[0][nt][2][r], m3 = acc[0][nt][3][r];
                     const float v = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
                     base[r * 37] = nan0 ? nanv : v;
+                    if constexpr (TAPS) {      // conv4 before the pool: pairs a4..b4 (t = 74, which the pool drops, is never computed here)
+                        float* tp = taps.conv4 + (win0 * 128 + co2 + 4 * q + r) * 75 + 2 * m;
+                        tp[0] = fmaxf((m0 + m1) + m2, 0.f);
+                        tp[1] = fmaxf((m1 - m2) - m3, 0.f);
+                    }
                 }
             }
         }
@@ -1026,20 +1076,46 @@ hipError_t init_conv_wino()
                           reinterpret_cast<const void*>(&conv_wino1x8_kernel<true>), reinterpret_cast<const void*>(&conv_wino1x8_kernel<false>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     for (const void* k : {reinterpret_cast<const void*>(&conv_wino_seg_kernel<true, 2, 3, 2>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 2, 3, 2>),
-                          reinterpret_cast<const void*>(&conv_wino_seg_kernel<true, 4, 2, 1>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 4, 2, 1>)})
+                          reinterpret_cast<const void*>(&conv_wino_seg_kernel<true, 4, 2, 1>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 4, 2, 1>),
+                          reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 2, 3, 2, true>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 4, 2, 1, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
+    // the TAPS instantiations (dce_conv_layer_taps: parity tests of the layers inside the fused stack)
+    for (const void* k : {reinterpret_cast<const void*>(&conv_wino_kernel<false, float, true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false, true>),
+                          reinterpret_cast<const void*>(&conv_wino1x8_kernel<false, true>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     return hipSuccess;
+}
+
+// One launch of a NAMED conv kernel family on pre-normalised windows with the per-layer taps switched on
+// (kernel numbering: dce_kernels.h).  The TAPS instantiations differ from the product kernels only by the extra
+// global stores next to each layer's write-back.
+hipError_t launch_conv_wino_taps(int kernel, const float* src, int64_t n, const ConvPack& pk, float* f,
+                                 const LayerTaps& taps, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t lds = WLDS_FLOATS * sizeof(float), hl = HLDS_FLOATS * sizeof(float);
+    const long long* none = nullptr;
+    switch (kernel) {
+    case 0: hipLaunchKernelGGL((conv_wino_kernel<false, float, true>), dim3((unsigned)((n + NW - 1) / NW)), dim3(256), lds, st, src, n, pk, f, none, taps); break;
+    case 1: hipLaunchKernelGGL((conv_wino1x8_kernel<false, true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, none, taps); break;
+    case 2: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2, true>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, none, taps); break;
+    case 3: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1, true>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, none, taps); break;
+    case 5: hipLaunchKernelGGL((conv_wino1_kernel<false, true>), dim3((unsigned)n), dim3(256), lds, st, src, n, pk, f, none, taps); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvPack& pk,
                             void* feat, int feat_bf16, hipStream_t st, const long long* src_row)
 {
     if (n <= 0) return hipSuccess;
-    static const int64_t wino1_max = getenv("DCE_WINO1_MAX") ? atoll(getenv("DCE_WINO1_MAX")) : WINO1_MAX_N;
+    const Tuning& tu = tune();
+    const int64_t wino1_max = tu.wino1_max >= 0 ? tu.wino1_max : WINO1_MAX_N;
     // The two-window kernel fills the chip with rounds of 512 workgroups = 1024 windows; up to 256 windows past a round
     // would each sit alone on a CU for a lone workgroup's 65 us.  Windows are independent and every conv kernel produces
     // the same bits, so that remainder goes to the one-window / segment kernels instead (20 .. 38 us).
-    static const bool peel = !(getenv("DCE_CONV_PEEL") && atoi(getenv("DCE_CONV_PEEL")) == 0);
+    const bool peel = tu.conv_peel;
     if (peel && !feat_bf16 && !src_row && !DCE_TRACE && n > 1024 && n % 1024 != 0 && n % 1024 <= wino1_max) {
         const int64_t rest = n % 1024, m = n - rest;
         const hipError_t e = launch_conv_wino(src, zscore, m, pk, feat, feat_bf16, st, nullptr);
@@ -1049,44 +1125,49 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
     }
     size_t lds = WLDS_FLOATS * sizeof(float);
 #if DCE_TRACE
-    if (getenv("DCE_ONE_PER_CU")) lds = 100 * 1024;      // debug: force one workgroup per CU
+    if (tu.one_per_cu) lds = 100 * 1024;      // debug: force one workgroup per CU
 #endif
     const dim3 grid((unsigned)((n + NW - 1) / NW)), block(256);
-    if (!feat_bf16 && n <= wino1_max && (!DCE_TRACE || getenv("DCE_TRACE_WINO1"))) {
+    if (!feat_bf16 && n <= wino1_max && (!DCE_TRACE || tu.trace_wino1)) {
         // at most one workgroup per CU: one window each finishes in 56 % of a two-window workgroup's time
         float* f = static_cast<float*>(feat);
         // two / four CUs per window while that leaves no CU without one
-        static const int64_t half_max = getenv("DCE_WINOH_MAX") ? atoll(getenv("DCE_WINOH_MAX")) : WINOH_MAX_N;
-        static const int64_t quarter_max = getenv("DCE_WINOQ_MAX") ? atoll(getenv("DCE_WINOQ_MAX")) : WINOQ_MAX_N;
+        const int64_t half_max = tu.winoh_max >= 0 ? tu.winoh_max : WINOH_MAX_N;
+        const int64_t quarter_max = tu.winoq_max >= 0 ? tu.winoq_max : WINOQ_MAX_N;
         const size_t hl = HLDS_FLOATS * sizeof(float);
         if (n <= quarter_max) {
-            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 4, 2, 1>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, src_row);
-            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, src_row);
+            plan_note("conv_wino_quarter");
+            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 4, 2, 1>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{});
+            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{});
             return hipGetLastError();
         }
         if (n <= half_max) {
-            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row);
-            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row);
+            plan_note("conv_wino_half");
+            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{});
+            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{});
             return hipGetLastError();
         }
-        static const bool w8 = !(getenv("DCE_WINO1_WAVES") && atoi(getenv("DCE_WINO1_WAVES")) == 4);
+        const bool w8 = tu.wino1_w8;
         if (w8) {
-            if (zscore) hipLaunchKernelGGL((conv_wino1x8_kernel<true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row);
-            else        hipLaunchKernelGGL((conv_wino1x8_kernel<false>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row);
+            plan_note("conv_wino1x8");
+            if (zscore) hipLaunchKernelGGL((conv_wino1x8_kernel<true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row, LayerTaps{});
+            else        hipLaunchKernelGGL((conv_wino1x8_kernel<false>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row, LayerTaps{});
             return hipGetLastError();
         }
-        if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row);
-        else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row);
+        plan_note("conv_wino1x4");
+        if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+        else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
         return hipGetLastError();
     }
+    plan_note("conv_wino2");
     if (feat_bf16) {
         unsigned short* f = static_cast<unsigned short*>(feat);
-        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f, src_row);
-        else        hipLaunchKernelGGL((conv_wino_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f, src_row);
+        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+        else        hipLaunchKernelGGL((conv_wino_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
     } else {
         float* f = static_cast<float*>(feat);
-        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, float>), grid, block, lds, st, src, n, pk, f, src_row);
-        else        hipLaunchKernelGGL((conv_wino_kernel<false, float>), grid, block, lds, st, src, n, pk, f, src_row);
+        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+        else        hipLaunchKernelGGL((conv_wino_kernel<false, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
     }
     return hipGetLastError();
 }

@@ -3,8 +3,7 @@
 // arbitrarily long inputs over the scratch, and sequences the four kernels of the path:
 //   conv_stack (z-score+conv1..4)  ->  fc_gemm (fc.0)  ->  fc_gemm (fc.3)  ->  fc3_tail (fc.6+argmax+bits)
 // No exception or abort crosses the boundary; every failure is a negative dce_status plus a message.
-#include "../../include/dce.h"
-#include "dce_kernels.h"
+#include "dce_ctx.h"
 #include <chrono>
 
 #include <cstdarg>
@@ -29,108 +28,54 @@ const KeyInfo kKeys[14] = {
     {"fc.6.weight", 2, {16, 512, 0}},      {"fc.6.bias", 1, {16, 0, 0}},
 };
 
-thread_local std::string g_create_error;
-
 }  // namespace
 
-struct dce_ctx {
-    int device = 0;
-    int64_t max_batch = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t xstream_ev = nullptr;
-    hipStream_t xfer_stream = nullptr;     // host-buffer callers: chunk copies overlap the kernels of the
-    hipEvent_t ring_ev[3][3] = {};         // neighbouring chunks; per ring slot: staged-in, computed, staged-out
-    std::string err;
+namespace dce {
 
-    std::vector<float> host_w[14];         // staged state_dict (host, PyTorch layout)
-    bool have[14] = {};
-    bool finalized = false;
-    int precision = DCE_FP32;
-    bool winograd = true;                  // conv stack algorithm; DCE_CONV=direct selects the direct form
-    bool gemv = true;                      // FC layers of <= 32 windows as weight-streaming GEMV; DCE_SMALL_BATCH=gemm disables
+thread_local std::string g_create_error;
+thread_local const Tuning* t_tuning = nullptr;
+thread_local std::vector<const char*>* t_plan = nullptr;
 
-    float* d_weights = nullptr;            // one allocation: conv packs, biases, fc weights
-    ConvPack pk{};
-    const float *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr,
-                *fc3w = nullptr, *fc3b = nullptr;
-    const void *fc1w_bf16 = nullptr, *fc2w_bf16 = nullptr;   // DCE_BF16_FC only
+Tuning tuning_from_env()
+{
+    Tuning t;
+    auto num = [](const char* k, long long dflt) { const char* e = getenv(k); return e ? atoll(e) : dflt; };
+    auto off = [](const char* k) { const char* e = getenv(k); return e && atoi(e) == 0; };
+    if (const char* e = getenv("DCE_GEMM")) { t.gemm_tile = strcmp(e, "tile") == 0; t.gemm_lockstep = strcmp(e, "lockstep") == 0; }
+    t.phased_min_tiles = (int)num("DCE_PHASED_MIN_TILES", t.phased_min_tiles);
+    t.phased_min_tiles1 = (int)num("DCE_PHASED_MIN_TILES1", t.phased_min_tiles1);
+    t.phased_min = (int)num("DCE_GEMM_PHASED_MIN", t.phased_min);
+    t.phased_cost = !off("DCE_PHASED_COST");
+    t.phased_sn = (int)num("DCE_PHASED_SN", t.phased_sn);
+    if (const char* e = getenv("DCE_FC23")) t.fc23_mode = strcmp(e, "split") == 0 ? 1 : strcmp(e, "always") == 0 ? 2 : 0;
+    t.gemm_peel = !off("DCE_GEMM_PEEL");
+    t.conv_peel = !off("DCE_CONV_PEEL");
+    t.gemm_small_deep = !off("DCE_GEMM_SMALL");
+    t.chain_min = num("DCE_CHAIN_MIN", t.chain_min);
+    t.chain_max = num("DCE_CHAIN_MAX", t.chain_max);
+    t.chain_max3 = num("DCE_CHAIN_MAX3", t.chain_max3);
+    t.chain_bn16_max = num("DCE_CHAIN_BN16_MAX", t.chain_bn16_max);
+    t.wino1_max = num("DCE_WINO1_MAX", -1);
+    t.winoh_max = num("DCE_WINOH_MAX", -1);
+    t.winoq_max = num("DCE_WINOQ_MAX", -1);
+    t.wino1_w8 = num("DCE_WINO1_WAVES", 8) != 4;
+    t.one_per_cu = getenv("DCE_ONE_PER_CU") != nullptr;
+    t.trace_wino1 = getenv("DCE_TRACE_WINO1") != nullptr;
+    t.conv4 = (int)num("DCE_CONV4", -1);
+    return t;
+}
 
-    float *feat = nullptr, *h1 = nullptr, *h2 = nullptr;   // scratch, max_batch rows each
-    float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
-    bool want_h2 = false;                                  // dce_forward_taps: the fused epilogue also writes h2
+const Tuning& tune()
+{
+    if (t_tuning) return *t_tuning;
+    static const Tuning process_default = tuning_from_env();     // a launcher reached outside a C-ABI call
+    return process_default;
+}
 
-    // staging for host-pointer callers: a ring of RING_SLOTS chunk-sized slots (run_all), so that
-    // the device footprint is bounded by max_batch, not by the length of the caller's input
-    float* d_in = nullptr;   size_t d_in_bytes = 0;
-    float* d_logits = nullptr; int32_t* d_pred = nullptr; uint8_t* d_contacts = nullptr;
-    size_t d_out_rows = 0;
-
-    // online mode: linear buffer of ONLINE_ROWS sample rows; the live window is its last 150 rows
-    float* d_ring = nullptr;
-    int64_t ring_rows = 0;
-    float* h_online_pin = nullptr;         // pinned, device-visible: logits(16) | pred | contacts | ... | flag
-    unsigned online_seq = 0;
-    unsigned* done_flag = nullptr;         // set around an online push: the tail kernel publishes done_seq there
-    unsigned done_seq = 0;
-    // online mode as one hipGraph launch per sample (constant launch parameters; see dce_kernels.h)
-    OnlineState* d_online_state = nullptr;
-    const long long* src_row_dev = nullptr;   // set around the graph's kernel sequence
-    unsigned* seq_counter_dev = nullptr;
-    hipGraph_t online_graph = nullptr;
-    hipGraphExec_t online_exec = nullptr;
-    int online_mode = -1;                  // -1 undecided, 0 direct launches, 1 graph
-    bool online_state_dirty = true;        // device state must be zeroed before the next push
-
-    // profiling
-    int prof_period = 0;                   // 0 = off, k = time every k-th kernel sequence
-    int64_t prof_tick = 0;
-    bool prof = false;                     // events are recorded for the CURRENT sequence
-    std::vector<hipEvent_t> ev_pool;
-    struct Span { int slot; hipEvent_t a, b; };
-    std::vector<Span> spans;
-    double prof_ms[DCE_PROFILE_SLOTS] = {};
-    int64_t prof_n[DCE_PROFILE_SLOTS] = {};
-};
+}  // namespace dce
 
 namespace {
 
-int fail(dce_ctx* c, int code, const char* fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (c) c->err = buf; else g_create_error = buf;
-    return code;
-}
-
-#define HIP_TRY(c, expr)                                                                       \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail((c), DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
-    } while (0)
-
-// Every entry point binds the calling thread to the ctx's device for the duration of the call and
-// puts the caller's device back on return (a single-process multi-GPU host must not find its
-// current device changed by a call into this library).
-struct DeviceGuard {
-    int prev = -1; bool switched = false; hipError_t err = hipSuccess;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
-    }
-    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
-    DeviceGuard(const DeviceGuard&) = delete;
-    DeviceGuard& operator=(const DeviceGuard&) = delete;
-};
-#define DEVICE_GUARD(c)                                                                         \
-    DeviceGuard dev_guard_((c)->device);                                                        \
-    if (dev_guard_.err != hipSuccess)                                                           \
-        return fail((c), DCE_ERR_HIP, "hipSetDevice(%d) failed: %s", (c)->device, hipGetErrorString(dev_guard_.err))
 
 struct Timer {   // records a [begin,end] event pair around one launch when profiling is on
     dce_ctx* c; int slot; hipEvent_t a = nullptr, b = nullptr;
@@ -169,8 +114,10 @@ int drain_spans(dce_ctx* c)
 // One chunk (n <= max_batch) of the path, everything on device.
 //   src: raw sequence rows (zscore=1) or pre-normalised windows (zscore=0)
 int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
-              float* logits, int32_t* pred, uint8_t* contacts)
+              float* logits, int32_t* pred, uint8_t* contacts, uint8_t* packed = nullptr)
 {
+    TuningScope tuning_scope(&c->tuning);
+    struct PlanScope { explicit PlanScope(std::vector<const char*>* p) { p->clear(); t_plan = p; } ~PlanScope() { t_plan = nullptr; } } plan_scope(&c->plan);
     c->prof = c->prof_period > 0 && (c->prof_tick++ % c->prof_period) == 0;
     if (c->precision == DCE_BF16_FC) {
         // conv stack in fp32 -> bf16 features; fc.0 / fc.3 on bf16 MFMA with fp32 accumulate
@@ -180,7 +127,7 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         if (fc23_fused_ok(n, 1)) {
             { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch,
                                                           c->want_h2 ? c->h2 : nullptr, n, c->stream)); }
-            { Timer t(c, 3); HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, n, logits, pred, contacts, c->stream)); }
+            { Timer t(c, 3); HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, n, logits, pred, contacts, c->stream, packed)); }
             if (c->spans.size() > 4096) return drain_spans(c);
             return DCE_OK;
         }
@@ -197,22 +144,23 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
             // The fused kernel runs whole rounds of 256 tiles = 4096 windows: a batch that ends up to 2048 windows
             // past a round gives that remainder to the chain kernel + tail (same bits, rows are independent) instead
             // of paying a full round for it.
-            static const bool peel = !(getenv("DCE_GEMM_PEEL") && atoi(getenv("DCE_GEMM_PEEL")) == 0);
+            const bool peel = c->tuning.gemm_peel;
             const int64_t rest = n % 4096, nf = (peel && n > 4096 && rest && (rest <= 8 || fc_gemm_chain_ok(rest, FC2, FC1))) ? n - rest : n;
             { Timer t(c, 2);
               HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch,
                                            c->want_h2 ? c->h2 : nullptr, nf, c->stream));
               if (nf < n) HIP_TRY(c, (n - nf <= 8 ? launch_fc_gemv : launch_fc_gemm)(c->h1 + nf * FC1, c->fc2w, c->fc2b, c->h2 + nf * FC2, n - nf, FC2, FC1, 1, c->stream)); }
             { Timer t(c, 3);
-              HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, c->stream));
+              HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, c->stream, packed));
               if (nf < n) HIP_TRY(c, launch_fc3_tail(c->h2 + nf * FC2, c->fc3w, c->fc3b, n - nf, logits ? logits + nf * NCLS : nullptr,
-                                                     pred ? pred + nf : nullptr, contacts ? contacts + nf * 4 : nullptr, c->stream)); }
+                                                     pred ? pred + nf : nullptr, contacts ? contacts + nf * 4 : nullptr, c->stream,
+                                                     nullptr, 0, nullptr, packed ? packed + nf * PACKED_ROW : nullptr)); }
             if (c->spans.size() > 4096) return drain_spans(c);
             return DCE_OK;
         }
         { Timer t(c, 2); HIP_TRY(c, fc(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
     }
-    { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream, c->done_flag, c->done_seq, c->seq_counter_dev)); }
+    { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream, c->done_flag, c->done_seq, c->seq_counter_dev, packed)); }
     if (c->spans.size() > 4096) return drain_spans(c);
     return DCE_OK;
 }
@@ -233,6 +181,8 @@ int ensure_out(dce_ctx* c, size_t rows)
     if (c->d_logits)   { HIP_TRY(c, hipFree(c->d_logits));   c->d_logits = nullptr; }
     if (c->d_pred)     { HIP_TRY(c, hipFree(c->d_pred));     c->d_pred = nullptr; }
     if (c->d_contacts) { HIP_TRY(c, hipFree(c->d_contacts)); c->d_contacts = nullptr; }
+    if (c->d_packed)   { HIP_TRY(c, hipFree(c->d_packed));   c->d_packed = nullptr; }
+    HIP_TRY(c, hipMalloc(&c->d_packed, rows * PACKED_ROW));
     HIP_TRY(c, hipMalloc(&c->d_logits, rows * NCLS * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->d_pred, rows * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc(&c->d_contacts, rows * 4));
@@ -254,7 +204,7 @@ int check_ready(dce_ctx* c)
 //                    kernels of chunk i (the copies are ~10 % of a 1e6-window call when serialised);
 //                    returns once every result has landed.
 int run_all(dce_ctx* c, const float* src, int zscore, int64_t n, int64_t src_floats, int on_device,
-            float* logits, int32_t* pred, uint8_t* contacts)
+            float* logits, int32_t* pred, uint8_t* contacts, uint8_t* packed = nullptr)
 {
     const int64_t row_floats = zscore ? CH : (int64_t)WIN * CH;
     const int64_t nchunks = (n + c->max_batch - 1) / c->max_batch;
@@ -264,7 +214,7 @@ int run_all(dce_ctx* c, const float* src, int zscore, int64_t n, int64_t src_flo
             const int64_t i0 = i * c->max_batch;
             int rc = run_chunk(c, src + i0 * row_floats, zscore, chunk_rows(i),
                                logits ? logits + i0 * NCLS : nullptr, pred ? pred + i0 : nullptr,
-                               contacts ? contacts + i0 * 4 : nullptr);
+                               contacts ? contacts + i0 * 4 : nullptr, packed ? packed + i0 * PACKED_ROW : nullptr);
             if (rc) return rc;
         }
         return DCE_OK;
@@ -312,6 +262,7 @@ int run_all(dce_ctx* c, const float* src, int zscore, int64_t n, int64_t src_flo
         if (logits)   RING_TRY(hipMemcpyAsync(logits + i0 * NCLS, c->d_logits + s * mb * NCLS, (size_t)nb * NCLS * sizeof(float), hipMemcpyDeviceToHost, xs));
         if (pred)     RING_TRY(hipMemcpyAsync(pred + i0, c->d_pred + s * mb, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, xs));
         if (contacts) RING_TRY(hipMemcpyAsync(contacts + i0 * 4, c->d_contacts + s * mb * 4, (size_t)nb * 4, hipMemcpyDeviceToHost, xs));
+        if (packed)   RING_TRY(hipMemcpyAsync(packed + i0 * PACKED_ROW, c->d_packed + s * mb * PACKED_ROW, (size_t)nb * PACKED_ROW, hipMemcpyDeviceToHost, xs));
         RING_TRY(hipEventRecord(c->ring_ev[s][EV_OUT], xs));
         return DCE_OK;
     };
@@ -321,7 +272,8 @@ int run_all(dce_ctx* c, const float* src, int zscore, int64_t n, int64_t src_flo
         RING_TRY(hipStreamWaitEvent(c->stream, c->ring_ev[s][EV_IN], 0));
         if (i >= RING) RING_TRY(hipStreamWaitEvent(c->stream, c->ring_ev[s][EV_OUT], 0));   // slot's previous results have left
         rc = run_chunk(c, c->d_in + s * in_slot_floats, zscore, chunk_rows(i),
-                       c->d_logits + s * mb * NCLS, c->d_pred + s * mb, c->d_contacts + s * mb * 4);
+                       logits ? c->d_logits + s * mb * NCLS : nullptr, pred ? c->d_pred + s * mb : nullptr,
+                       contacts ? c->d_contacts + s * mb * 4 : nullptr, packed ? c->d_packed + s * mb * PACKED_ROW : nullptr);
         if (rc) return bail(rc);
         RING_TRY(hipEventRecord(c->ring_ev[s][EV_DONE], c->stream));
         if (i + 1 < nchunks && (rc = stage_in(i + 1))) return rc;
@@ -337,7 +289,7 @@ int run_all(dce_ctx* c, const float* src, int zscore, int64_t n, int64_t src_flo
 
 extern "C" {
 
-int dce_abi_version(void) { return 1; }
+int dce_abi_version(void) { return 2; }
 
 int dce_device_count(void)
 {
@@ -361,6 +313,7 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     if (!c) return fail(nullptr, DCE_ERR_NOMEM, "out of host memory");
     c->device = device_id;
     c->max_batch = max_batch;
+    c->tuning = tuning_from_env();
     if (const char* e = getenv("DCE_CONV")) c->winograd = strcmp(e, "direct") != 0;
     if (const char* e = getenv("DCE_SMALL_BATCH")) c->gemv = strcmp(e, "gemm") != 0;
 #define CREATE_TRY(expr)                                                                        \
@@ -391,11 +344,15 @@ void dce_destroy(dce_ctx* c)
     if (c->stream != c->own_stream) hipStreamSynchronize(c->stream);   // scratch may still be in use there
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
+    (void)dce_comm_destroy(c);
+    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+    if (c->comm_ready) hipEventDestroy(c->comm_ready);
+    for (auto e : c->comm_done) if (e) hipEventDestroy(e);
     if (c->xstream_ev) hipEventDestroy(c->xstream_ev);
     if (c->xfer_stream) { hipStreamSynchronize(c->xfer_stream); hipStreamDestroy(c->xfer_stream); }
     for (auto& slot : c->ring_ev) for (auto e : slot) if (e) hipEventDestroy(e);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2); hipFree(c->part);
-    hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts);
+    hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
     if (c->online_exec) hipGraphExecDestroy(c->online_exec);
     if (c->online_graph) hipGraphDestroy(c->online_graph);
     hipFree(c->d_ring); hipFree(c->d_online_state);
@@ -526,6 +483,48 @@ int dce_infer_sequence(dce_ctx* c, const float* seq, int64_t T, int window, int 
     return run_all(c, seq, 1, n, T * CH, on_device, logits, pred, contacts);
 }
 
+int dce_forward_windows_packed(dce_ctx* c, const float* windows, int64_t n, int on_device, uint8_t* packed)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    DEVICE_GUARD(c);
+    if (n < 0 || (n > 0 && (!windows || !packed))) return fail(c, DCE_ERR_ARG, "dce_forward_windows_packed: bad argument");
+    if (n == 0) return DCE_OK;
+    return run_all(c, windows, 0, n, n * WIN * CH, on_device, nullptr, nullptr, nullptr, packed);
+}
+
+int dce_infer_sequence_packed(dce_ctx* c, const float* seq, int64_t T, int window, int on_device, uint8_t* packed)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    DEVICE_GUARD(c);
+    if (window != WIN) return fail(c, DCE_ERR_ARG, "window_size must be %d (the model hard-codes 4736 = 128*37), got %d", WIN, window);
+    const int64_t n = T - WIN + 1;
+    if (T < 0 || (n > 0 && (!seq || !packed))) return fail(c, DCE_ERR_ARG, "dce_infer_sequence_packed: bad argument");
+    if (n <= 0) return DCE_OK;
+    return run_all(c, seq, 1, n, T * CH, on_device, nullptr, nullptr, nullptr, packed);
+}
+
+int dce_unpack_results(dce_ctx* c, const uint8_t* packed, int64_t n, int on_device,
+                       float* logits, int32_t* pred, uint8_t* contacts)
+{
+    if (n < 0 || (n > 0 && !packed) || (on_device && !c)) return fail(c, DCE_ERR_ARG, "dce_unpack_results: bad argument");
+    if (n == 0) return DCE_OK;
+    if (on_device) {
+        DEVICE_GUARD(c);
+        HIP_TRY(c, launch_unpack_results(packed, n, logits, pred, contacts, c->stream));
+        return DCE_OK;
+    }
+    // host rows: plain byte work, no device involved (a row is 16 little-endian fp32 + 4 bits)
+    for (int64_t i = 0; i < n; ++i) {
+        const uint8_t* r = packed + i * PACKED_ROW;
+        if (logits) memcpy(logits + i * NCLS, r, NCLS * sizeof(float));
+        if (contacts) memcpy(contacts + i * 4, r + 4 * NCLS, 4);
+        if (pred) pred[i] = (r[64] & 1) << 3 | (r[65] & 1) << 2 | (r[66] & 1) << 1 | (r[67] & 1);
+    }
+    return DCE_OK;
+}
+
 int dce_zscore_windows(dce_ctx* c, const float* seq, int64_t T, int64_t first, int64_t n,
                        int on_device, float* windows_out)
 {
@@ -551,15 +550,13 @@ int dce_zscore_windows(dce_ctx* c, const float* seq, int64_t T, int64_t first, i
 }
 
 int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
-                     float* feat, float* h1, float* h2, float* logits)
+                     void* feat, void* h1, float* h2, float* logits)
 {
     int rc = check_ready(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
     if (n <= 0 || n > c->max_batch || !windows)
         return fail(c, DCE_ERR_ARG, "dce_forward_taps: need 0 < n <= max_batch (%lld)", (long long)c->max_batch);
-    if (c->precision != DCE_FP32 && (feat || h1))
-        return fail(c, DCE_ERR_ARG, "dce_forward_taps: feat/h1 taps are fp32-only (they are bf16 scratch in DCE_BF16_FC mode)");
     const float* dsrc = windows;
     float* dl = logits;
     if (!on_device) {
@@ -575,13 +572,46 @@ int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
     c->want_h2 = false;
     if (rc) return rc;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (feat) HIP_TRY(c, hipMemcpyAsync(feat, c->feat, (size_t)n * FEAT * sizeof(float), kind, c->stream));
-    if (h1)   HIP_TRY(c, hipMemcpyAsync(h1, c->h1, (size_t)n * FC1 * sizeof(float), kind, c->stream));
+    // DCE_BF16_FC: the features and ReLU(fc.0) ARE bf16 in that mode -- the taps hand out the (n,4736) / (n,2048)
+    // uint16 bit patterns the next layer consumed
+    const size_t es = c->precision == DCE_BF16_FC ? 2 : sizeof(float);
+    if (feat) HIP_TRY(c, hipMemcpyAsync(feat, c->feat, (size_t)n * FEAT * es, kind, c->stream));
+    if (h1)   HIP_TRY(c, hipMemcpyAsync(h1, c->h1, (size_t)n * FC1 * es, kind, c->stream));
     if (h2)   HIP_TRY(c, hipMemcpyAsync(h2, c->h2, (size_t)n * FC2 * sizeof(float), kind, c->stream));
     if (!on_device) {
         if (logits) HIP_TRY(c, hipMemcpyAsync(logits, dl, (size_t)n * NCLS * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    return DCE_OK;
+}
+
+int dce_conv_layer_taps(dce_ctx* c, const float* windows, int64_t n, int kernel,
+                        float* conv1, float* conv2, float* pool1, float* conv3, float* conv4, float* feat)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    DEVICE_GUARD(c);
+    if (n <= 0 || n > c->max_batch || n > 64 || !windows || !conv1 || !conv2 || !pool1 || !conv3 || !conv4 || !feat)
+        return fail(c, DCE_ERR_ARG, "dce_conv_layer_taps: need 0 < n <= min(64, max_batch) host windows and all six host outputs");
+    // host pointers only (a test hook): stage the windows, run ONE named kernel family with its taps on, copy everything out
+    const size_t in_f = (size_t)n * WIN * CH;
+    const size_t sz[5] = {(size_t)n * 64 * 150, (size_t)n * 64 * 150, (size_t)n * 64 * 75, (size_t)n * 128 * 75, (size_t)n * 128 * 75};
+    size_t total = in_f;
+    for (size_t s : sz) total += s;
+    rc = ensure_in(c, total * sizeof(float));
+    if (rc) return rc;
+    float* d = c->d_in;
+    LayerTaps taps{d + in_f, d + in_f + sz[0], d + in_f + sz[0] + sz[1], d + in_f + sz[0] + sz[1] + sz[2],
+                   d + in_f + sz[0] + sz[1] + sz[2] + sz[3]};
+    HIP_TRY(c, hipMemcpyAsync(d, windows, in_f * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(d + in_f, 0xff, (total - in_f) * sizeof(float), c->stream));      // untouched taps read back as NaN
+    const hipError_t e = launch_conv_taps(kernel, d, n, c->pk, c->feat, taps, c->stream);
+    if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? DCE_ERR_ARG : DCE_ERR_HIP, "dce_conv_layer_taps: kernel %d: %s", kernel, hipGetErrorString(e));
+    float* outs[5] = {conv1, conv2, pool1, conv3, conv4};
+    float* srcs[5] = {taps.conv1, taps.conv2, taps.pool1, taps.conv3, taps.conv4};
+    for (int i = 0; i < 5; ++i) HIP_TRY(c, hipMemcpyAsync(outs[i], srcs[i], sz[i] * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(feat, c->feat, (size_t)n * FEAT * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DCE_OK;
 }
 
@@ -775,6 +805,15 @@ int dce_profile_read(dce_ctx* c, double ms[DCE_PROFILE_SLOTS], int64_t launches[
         if (launches) launches[s] = c->prof_n[s];
         if (reset) { c->prof_ms[s] = 0; c->prof_n[s] = 0; }
     }
+    return DCE_OK;
+}
+
+int dce_last_plan(dce_ctx* c, char* out, int out_len)
+{
+    if (!c || !out || out_len <= 0) return DCE_ERR_ARG;
+    std::string s;
+    for (const char* k : c->plan) { if (!s.empty()) s += ' '; s += k; }
+    snprintf(out, (size_t)out_len, "%s", s.c_str());
     return DCE_OK;
 }
 

@@ -1,0 +1,120 @@
+// dce_ctx.h -- the context behind the opaque dce_ctx of include/dce.h, shared by the translation units that
+// implement the C ABI (dce_api.hip: the path; dce_comm.hip: the RCCL exchange).  Internal to libdce.so.
+#pragma once
+#include "../../include/dce.h"
+#include "dce_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace dce { extern thread_local std::string g_create_error; }   // message of a failing call that has no ctx
+
+struct dce_ctx {
+    int device = 0;
+    int64_t max_batch = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t xstream_ev = nullptr;
+    hipStream_t xfer_stream = nullptr;     // host-buffer callers: chunk copies overlap the kernels of the
+    hipEvent_t ring_ev[3][3] = {};         // neighbouring chunks; per ring slot: staged-in, computed, staged-out
+    std::string err;
+
+    std::vector<float> host_w[14];         // staged state_dict (host, PyTorch layout)
+    bool have[14] = {};
+    bool finalized = false;
+    int precision = DCE_FP32;
+    std::vector<const char*> plan;         // kernel families launched by the most recent kernel sequence (dce_last_plan)
+    dce::Tuning tuning;                    // the A/B switches as they stood in the environment at dce_create
+    bool winograd = true;                  // conv stack algorithm; DCE_CONV=direct selects the direct form
+    bool gemv = true;                      // FC layers of <= 32 windows as weight-streaming GEMV; DCE_SMALL_BATCH=gemm disables
+
+    float* d_weights = nullptr;            // one allocation: conv packs, biases, fc weights
+    dce::ConvPack pk{};
+    const float *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr,
+                *fc3w = nullptr, *fc3b = nullptr;
+    const void *fc1w_bf16 = nullptr, *fc2w_bf16 = nullptr;   // DCE_BF16_FC only
+
+    float *feat = nullptr, *h1 = nullptr, *h2 = nullptr;   // scratch, max_batch rows each
+    float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
+    bool want_h2 = false;                                  // dce_forward_taps: the fused epilogue also writes h2
+
+    // staging for host-pointer callers: a ring of RING_SLOTS chunk-sized slots (run_all), so that
+    // the device footprint is bounded by max_batch, not by the length of the caller's input
+    float* d_in = nullptr;   size_t d_in_bytes = 0;
+    float* d_logits = nullptr; int32_t* d_pred = nullptr; uint8_t* d_contacts = nullptr; uint8_t* d_packed = nullptr;
+    size_t d_out_rows = 0;
+
+    // online mode: linear buffer of ONLINE_ROWS sample rows; the live window is its last 150 rows
+    float* d_ring = nullptr;
+    int64_t ring_rows = 0;
+    float* h_online_pin = nullptr;         // pinned, device-visible: logits(16) | pred | contacts | ... | flag
+    unsigned online_seq = 0;
+    unsigned* done_flag = nullptr;         // set around an online push: the tail kernel publishes done_seq there
+    unsigned done_seq = 0;
+    // online mode as one hipGraph launch per sample (constant launch parameters; see dce_kernels.h)
+    dce::OnlineState* d_online_state = nullptr;
+    const long long* src_row_dev = nullptr;   // set around the graph's kernel sequence
+    unsigned* seq_counter_dev = nullptr;
+    hipGraph_t online_graph = nullptr;
+    hipGraphExec_t online_exec = nullptr;
+    int online_mode = -1;                  // -1 undecided, 0 direct launches, 1 graph
+    bool online_state_dirty = true;        // device state must be zeroed before the next push
+
+    // multi-GPU (dce_comm.hip): one RCCL communicator per ctx, collectives on comm_stream behind the ctx stream
+    void* comm = nullptr;                  // ncclComm_t
+    int comm_rank = 0, comm_world = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ready = nullptr;       // recorded on the ctx stream: the send buffer is complete
+    hipEvent_t comm_done[2] = {};          // recorded on comm_stream after the gathers of even / odd index
+    int64_t comm_issued = 0;               // asynchronous gathers issued so far
+
+    // profiling
+    int prof_period = 0;                   // 0 = off, k = time every k-th kernel sequence
+    int64_t prof_tick = 0;
+    bool prof = false;                     // events are recorded for the CURRENT sequence
+    std::vector<hipEvent_t> ev_pool;
+    struct Span { int slot; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    double prof_ms[DCE_PROFILE_SLOTS] = {};
+    int64_t prof_n[DCE_PROFILE_SLOTS] = {};
+};
+
+inline int fail(dce_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else dce::g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((c), DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+// Every entry point binds the calling thread to the ctx's device for the duration of the call and
+// puts the caller's device back on return (a single-process multi-GPU host must not find its
+// current device changed by a call into this library).
+struct DeviceGuard {
+    int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DEVICE_GUARD(c)                                                                         \
+    DeviceGuard dev_guard_((c)->device);                                                        \
+    if (dev_guard_.err != hipSuccess)                                                           \
+        return fail((c), DCE_ERR_HIP, "hipSetDevice(%d) failed: %s", (c)->device, hipGetErrorString(dev_guard_.err))
+

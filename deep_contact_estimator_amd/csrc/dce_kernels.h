@@ -3,11 +3,45 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace dce {
 
 // ---- geometry of contact_cnn (reference src/contact_cnn.py:8-58) ------------------------
 constexpr int WIN = 150, CH = 54, NCLS = 16, FEAT = 4736, FC1 = 2048, FC2 = 512;
+
+// ---- A/B switches: read from the environment ONCE PER CONTEXT in dce_create and handed to the
+// launchers through a thread-local pointer that every C-ABI entry point sets for the duration of the call, so that two
+// contexts of one process (tests, tools/race_screen.py) can run different kernel variants side by side.
+struct Tuning {
+    bool gemm_tile = false, gemm_lockstep = false;          // DCE_GEMM=tile | lockstep   (default: phased)
+    int phased_min_tiles = 192, phased_min_tiles1 = 128;    // DCE_PHASED_MIN_TILES, DCE_PHASED_MIN_TILES1
+    int phased_min = 1;                                     // DCE_GEMM_PHASED_MIN (2: only the 256x128 tile)
+    bool phased_cost = true;                                // DCE_PHASED_COST=0: tile minimum only, no rounds model
+    int phased_sn = 3;                                      // DCE_PHASED_SN: log2 of the super-tile's N extent
+    int fc23_mode = 0;                                      // DCE_FC23=split (1) | always (2)
+    bool gemm_peel = true, conv_peel = true;                // DCE_GEMM_PEEL=0, DCE_CONV_PEEL=0
+    bool gemm_small_deep = true;                            // DCE_GEMM_SMALL=0
+    long long chain_min = 9, chain_max = 640, chain_max3 = 2048, chain_bn16_max = 64;   // DCE_CHAIN_*
+    long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // DCE_WINO1_MAX / DCE_WINOH_MAX / DCE_WINOQ_MAX (-1: kernel default)
+    bool wino1_w8 = true;                                   // DCE_WINO1_WAVES=4 -> false
+    bool one_per_cu = false, trace_wino1 = false;           // DCE_ONE_PER_CU, DCE_TRACE_WINO1 (trace builds)
+    int conv4 = -1;                                         // DCE_CONV4: four-window conv workgroup on/off (-1: default)
+};
+Tuning tuning_from_env();
+extern thread_local const Tuning* t_tuning;                  // the calling ctx's switches (nullptr: process defaults)
+const Tuning& tune();
+struct TuningScope {                                         // RAII: entry points bind their ctx's switches
+    const Tuning* prev;
+    explicit TuningScope(const Tuning* t) : prev(t_tuning) { t_tuning = t; }
+    ~TuningScope() { t_tuning = prev; }
+};
+
+// ---- which kernels a call ran: every launcher notes the kernel family it picked; dce_last_plan returns the notes of
+// the ctx's most recent kernel sequence (tests assert that an A/B switch or a batch size really selected the kernel
+// they mean to exercise)
+extern thread_local std::vector<const char*>* t_plan;
+inline void plan_note(const char* kernel) { if (t_plan) t_plan->push_back(kernel); }
 
 // ---- packed conv weights (built once in dce_finalize_weights) ---------------------------
 // Layer l has CinPad (multiple of 8) input rows and Cout output channels.  The implicit
@@ -31,6 +65,16 @@ hipError_t init_conv_wino();
 //   position of the live window on the device so that its launch parameters never change
 hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvPack& pk,
                             void* feat, int feat_bf16, hipStream_t st, const long long* src_row = nullptr);
+
+// Per-layer taps of the fused conv stack for parity tests (dce_conv_layer_taps): post-ReLU activations in PyTorch
+// layout, one block per window -- conv1 (n,64,150), conv2 (n,64,150) before the pool, pool1 (n,64,75), conv3 (n,128,75),
+// conv4 (n,128,75) before the pool.  The write-backs of TAPS instantiations of the conv kernels store them next to
+// their LDS / feature stores; the product instantiations carry no trace of it.
+struct LayerTaps { float *conv1, *conv2, *pool1, *conv3, *conv4; };
+// kernel: 0 two-window Winograd, 1 one-window x 8 waves, 2 half-window segments, 3 quarter-window segments,
+//         4 direct form, 5 one-window x 4 waves, 6 four-window Winograd (8 waves)
+hipError_t launch_conv_taps(int kernel, const float* windows, int64_t n, const ConvPack& pk, float* feat,
+                            const LayerTaps& taps, hipStream_t st);
 
 // Per-device one-time setup (dynamic-LDS grants); call after hipSetDevice.
 hipError_t init_conv_stack();
@@ -86,7 +130,7 @@ hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, co
                              float* part, int64_t part_rows, float* h2_out, int64_t M, hipStream_t st);
 // ... and the combine behind it: logits = ordered sum of the 8 chunk sums + b3, argmax, contact bits
 hipError_t launch_fc6_combine(const float* part, int64_t part_rows, const float* b3, int64_t n,
-                              float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st);
+                              float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st, uint8_t* packed = nullptr);
 
 // logits = h2 * W3^T + b3 (same summation tree, fc6_chain.h) ; argmax (first max, NaN-first) ; 4-bit unpack (MSB = leg 0)
 // done_flag (optional, single-block launches only): a system-scope release store of done_seq after the
@@ -94,7 +138,13 @@ hipError_t launch_fc6_combine(const float* part, int64_t part_rows, const float*
 //   seq_counter (optional, device memory, with done_flag): publish ++*seq_counter instead of done_seq.
 hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,
                            float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st,
-                           unsigned* done_flag = nullptr, unsigned done_seq = 0, unsigned* seq_counter = nullptr);
+                           unsigned* done_flag = nullptr, unsigned done_seq = 0, unsigned* seq_counter = nullptr,
+                           uint8_t* packed = nullptr);
+// packed: optional (n,68)-byte rows -- 16 fp32 logits followed by the 4 contact bits -- the row format of the multi-GPU
+// gather (dce_gather_results), written by the same kernels so that no repacking pass exists.
+constexpr int PACKED_ROW = 68;
+// (n,68) packed rows -> logits (n,16) f32, pred (n) i32, contacts (n,4) u8 (any may be NULL)
+hipError_t launch_unpack_results(const uint8_t* packed, int64_t n, float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st);
 
 // online mode: write one (54,) sample, carried in the kernel arguments, to its row of the sample buffer
 struct OnlineSample { float v[54]; };

@@ -368,7 +368,7 @@ constexpr int TAIL_H2_LD = FC2 + 4;     // 516 floats: the 16 rows of a ds_read_
 constexpr int TAIL_PART_FLOATS = FC6_NCHUNK * TAIL_WINDOWS * NCLS;
 constexpr int TAIL_LDS_BYTES = (TAIL_WINDOWS * TAIL_H2_LD + TAIL_PART_FLOATS + TAIL_WINDOWS * NCLS) * (int)sizeof(float);
 __global__ void fc3_tail_kernel(const float*, const float*, const float*, int64_t, float*, int32_t*, uint8_t*,
-                                unsigned*, unsigned, unsigned*);
+                                unsigned*, unsigned, unsigned*, uint8_t*);
 
 hipError_t init_fc_gemm()
 {
@@ -398,6 +398,7 @@ static hipError_t launch_gemm_cfg(const void* A, const void* W, const float* bia
     const int sm = 64 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 64;
+    plan_note(BF16 ? (TM == 2 ? "fc_tile128_bf16" : "fc_tile64_bf16") : (TM == 2 ? "fc_tile128" : "fc_tile64"));
     hipLaunchKernelGGL((fc_gemm_kernel<TM, TN, BF16, OUT_BF16, WGN>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st,
                        A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
     return hipGetLastError();
@@ -417,7 +418,7 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
 {
     if (M <= 0) return hipSuccess;
     if (N % 128 || K % 32 || M > (1 << 30)) return hipErrorInvalidValue;
-    static const bool peel = !(getenv("DCE_GEMM_PEEL") && atoi(getenv("DCE_GEMM_PEEL")) == 0);
+    const bool peel = tune().gemm_peel;
     const int64_t rows1 = (int64_t)(256 / (N / 64)) * 128, rows2 = (int64_t)(256 / (N / 128)) * 256;   // rows of one round
     if (peel && N <= 2048 && 256 % (N / 64) == 0 && M > rows1 && M % rows1 != 0 && fc_gemm_phased_ok(rows1, N, K, 0)) {
         const int64_t big = fc_gemm_phased_ok(rows2, N, K, 0) ? M / rows2 * rows2 : 0;
@@ -447,7 +448,7 @@ static hipError_t launch_fc_gemm_one(const float* A, const float* W, const float
     // 128x128 tiles when they alone fill the chip (512 resident blocks), else 64x64
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
     if (big_blocks >= 384) return launch_gemm_cfg<2, 2, false, false>(A, W, bias, C, M, N, K, relu, st);
-    static const bool deep = !(getenv("DCE_GEMM_SMALL") && atoi(getenv("DCE_GEMM_SMALL")) == 0);
+    const bool deep = tune().gemm_small_deep;
     const int64_t small_blocks = ((M + 63) / 64) * (N / 64);
     if (deep && small_blocks <= 512 && (K * 4 / KT_BYTES) % GS_DEPTH == 0) {
         using Cfg = GemmCfg<1, 1, 2>;
@@ -457,6 +458,7 @@ static hipError_t launch_fc_gemm_one(const float* A, const float* W, const float
         const int sm = 64 >> sn_log2, nsn = ntiles >> sn_log2;
         const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
         const int grid = ((nsuper + 7) / 8) * 8 * 64;
+        plan_note("fc_tile64_deep");
         hipLaunchKernelGGL(fc_gemm_small_kernel, dim3(grid), dim3(256), Cfg::LDS_BYTES, st,
                            A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
         return hipGetLastError();
@@ -482,11 +484,20 @@ hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, 
 // fc.6 (512 -> 16) + torch.max(output,1) + decimal2binary
 // ------------------------------------------------------------------------------------------
 
+// decimal2binary (reference src/inference_one_seq.py:59-62): class -> 4 bits, MSB = leg 0
+__device__ __forceinline__ uchar4 contact_bits(int best)
+{
+    uchar4 c;
+    c.x = (best >> 3) & 1; c.y = (best >> 2) & 1; c.z = (best >> 1) & 1; c.w = best & 1;
+    return c;
+}
+
 __global__ __launch_bounds__(256)
 void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                      const float* __restrict__ b3, int64_t n, float* __restrict__ logits,
                      int32_t* __restrict__ pred, uint8_t* __restrict__ contacts,
-                     unsigned* __restrict__ done_flag, unsigned done_seq, unsigned* __restrict__ seq_counter)
+                     unsigned* __restrict__ done_flag, unsigned done_seq, unsigned* __restrict__ seq_counter,
+                     uint8_t* __restrict__ packed)
 {
     // dynamic LDS (43 KB): the 16 h2 rows of the current window tile [16][516] | chunk sums [8][16][16] | logits [16][16]
     extern __shared__ __attribute__((aligned(16))) float tsm[];
@@ -534,6 +545,7 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
         const float acc = fc6_combine(p, bv);
         lg[wl][cls] = acc;
         if (win < n && logits) logits[win * NCLS + cls] = acc;
+        if (win < n && packed) *reinterpret_cast<float*>(packed + win * PACKED_ROW + 4 * cls) = acc;
         __syncthreads();
         if (tid < TAIL_WINDOWS && base + tid < n) {
             const int best = fc6_argmax16(lg[tid]);
@@ -543,6 +555,7 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                 c.x = (best >> 3) & 1; c.y = (best >> 2) & 1; c.z = (best >> 1) & 1; c.w = best & 1;
                 *reinterpret_cast<uchar4*>(contacts + (base + tid) * 4) = c;
             }
+            if (packed) *reinterpret_cast<uchar4*>(packed + (base + tid) * PACKED_ROW + 4 * NCLS) = contact_bits(best);
         }
     }
     if (done_flag) {
@@ -564,7 +577,8 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void fc6_combine_kernel(const float* __restrict__ part, int64_t part_rows, const float* __restrict__ b3, int64_t n,
-                        float* __restrict__ logits, int32_t* __restrict__ pred, uint8_t* __restrict__ contacts)
+                        float* __restrict__ logits, int32_t* __restrict__ pred, uint8_t* __restrict__ contacts,
+                        uint8_t* __restrict__ packed)
 {
     __shared__ float lg[16][NCLS];
     const int tid = threadIdx.x, cls = tid & 15, wl = tid >> 4;
@@ -576,6 +590,7 @@ void fc6_combine_kernel(const float* __restrict__ part, int64_t part_rows, const
     const float v = fc6_combine(p, b3[cls]);
     lg[wl][cls] = v;
     if (win < n && logits) logits[win * NCLS + cls] = v;
+    if (win < n && packed) *reinterpret_cast<float*>(packed + win * PACKED_ROW + 4 * cls) = v;
     __syncthreads();
     if (tid < 16 && base + tid < n) {
         const int best = fc6_argmax16(lg[tid]);
@@ -585,27 +600,30 @@ void fc6_combine_kernel(const float* __restrict__ part, int64_t part_rows, const
             c.x = (best >> 3) & 1; c.y = (best >> 2) & 1; c.z = (best >> 1) & 1; c.w = best & 1;
             *reinterpret_cast<uchar4*>(contacts + (base + tid) * 4) = c;
         }
+        if (packed) *reinterpret_cast<uchar4*>(packed + (base + tid) * PACKED_ROW + 4 * NCLS) = contact_bits(best);
     }
 }
 
 hipError_t launch_fc6_combine(const float* part, int64_t part_rows, const float* b3, int64_t n,
-                              float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st)
+                              float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st, uint8_t* packed)
 {
     if (n <= 0) return hipSuccess;
+    plan_note("fc6_combine");
     hipLaunchKernelGGL(fc6_combine_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st,
-                       part, part_rows, b3, n, logits, pred, contacts);
+                       part, part_rows, b3, n, logits, pred, contacts, packed);
     return hipGetLastError();
 }
 
 hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, int64_t n,
                            float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st,
-                           unsigned* done_flag, unsigned done_seq, unsigned* seq_counter)
+                           unsigned* done_flag, unsigned done_seq, unsigned* seq_counter, uint8_t* packed)
 {
     if (n <= 0) return hipSuccess;
     int64_t blocks = (n + TAIL_WINDOWS - 1) / TAIL_WINDOWS;
     if (blocks > 1024) blocks = 1024;
+    plan_note("fc3_tail");
     hipLaunchKernelGGL(fc3_tail_kernel, dim3((unsigned)blocks), dim3(256), TAIL_LDS_BYTES, st,
-                       h2, W3, b3, n, logits, pred, contacts, blocks == 1 ? done_flag : nullptr, done_seq, seq_counter);
+                       h2, W3, b3, n, logits, pred, contacts, blocks == 1 ? done_flag : nullptr, done_seq, seq_counter, packed);
     return hipGetLastError();
 }
 
@@ -700,6 +718,36 @@ hipError_t launch_confusion16(const int32_t* pred, const int64_t* label, int64_t
     if (blocks > 4096) blocks = 4096;
     if (vec) hipLaunchKernelGGL(confusion16_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, pred, label, n, counts);
     else     hipLaunchKernelGGL(confusion16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, pred, label, n, counts);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// (n,68)-byte packed rows (the gather's wire format) -> the reference's three arrays.  HBM-bound byte work:
+// 68 B in, 72 B out per window; one thread per (window, 4-byte word), the 17th word carries the contact bits.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void unpack_results_kernel(const uint8_t* __restrict__ packed, int64_t n, float* __restrict__ logits,
+                           int32_t* __restrict__ pred, uint8_t* __restrict__ contacts)
+{
+    const int64_t words = n * (PACKED_ROW / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / (PACKED_ROW / 4);
+        const int w = (int)(i - row * (PACKED_ROW / 4));
+        const unsigned v = reinterpret_cast<const unsigned*>(packed)[i];          // rows are 4-byte aligned: word i of the buffer
+        if (w < NCLS) { if (logits) logits[row * NCLS + w] = __uint_as_float(v); }
+        else {
+            if (contacts) reinterpret_cast<unsigned*>(contacts)[row] = v;
+            if (pred) pred[row] = (int)(((v & 1u) << 3) | (((v >> 8) & 1u) << 2) | (((v >> 16) & 1u) << 1) | ((v >> 24) & 1u));
+        }
+    }
+}
+
+hipError_t launch_unpack_results(const uint8_t* packed, int64_t n, float* logits, int32_t* pred, uint8_t* contacts, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n * (PACKED_ROW / 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(unpack_results_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packed, n, logits, pred, contacts);
     return hipGetLastError();
 }
 

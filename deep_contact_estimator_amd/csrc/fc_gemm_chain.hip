@@ -224,9 +224,10 @@ hipError_t init_fc_gemm_chain()
 // the fused 64x... phased kernel (71 us incl. combine) up to 2048 windows (47 + 7.5 us with the tail kernel).
 bool fc_gemm_chain_ok(int64_t M, int N, int K)
 {
-    static const int64_t lo = getenv("DCE_CHAIN_MIN") ? atoll(getenv("DCE_CHAIN_MIN")) : 9;
-    static const int64_t hi = getenv("DCE_CHAIN_MAX") ? atoll(getenv("DCE_CHAIN_MAX")) : 640;
-    static const int64_t hi3 = getenv("DCE_CHAIN_MAX3") ? atoll(getenv("DCE_CHAIN_MAX3")) : 2048;
+    const Tuning& tu = tune();
+    const int64_t lo = tu.chain_min, hi = tu.chain_max, hi3 = tu.chain_max3;
+    // per-lane global offsets are 32-bit (row * K * 4 bytes): keep every row of the launch inside 4 GiB
+    if ((uint64_t)M * (uint64_t)K * 4 >= (1ull << 32)) return false;
     return M >= lo && M <= (K == FEAT ? hi : hi3) && N % 32 == 0 && (K == FEAT || K == FC1);
 }
 
@@ -235,9 +236,11 @@ hipError_t launch_fc_gemm_chain(const float* A, const float* W, const float* bia
 {
     if (M <= 0) return hipSuccess;
     if (N % 32 || (K != FEAT && K != FC1) || M > 65535 * 32) return hipErrorInvalidValue;
+    if ((uint64_t)M * (uint64_t)K * 4 >= (1ull << 32)) return hipErrorInvalidValue;     // 32-bit per-lane offsets (voffA = row*K*4)
     // 32x16 blocks while even they leave CUs idle (<= 64 windows: fc.0 256 workgroups, fc.3 64): a quarter less staging per chain
-    static const int64_t bn16_max = getenv("DCE_CHAIN_BN16_MAX") ? atoll(getenv("DCE_CHAIN_BN16_MAX")) : 64;
+    const int64_t bn16_max = tune().chain_bn16_max;
     const dim3 block(256);
+    plan_note(M <= bn16_max ? "fc_chain32x16" : "fc_chain32x32");
     if (M <= bn16_max) {
         const dim3 grid(N / 16, (unsigned)((M + 31) / 32));
         if (K == FEAT) hipLaunchKernelGGL((fc_gemm_chain_kernel<FEAT, 16>), grid, block, CH_LDS_BYTES, st, A, W, bias, C, (int)M, N, relu);

@@ -390,8 +390,7 @@ template <> struct PhTile<1> { static constexpr int TM = 1, TN = 1, ROWB = 256; 
 //         result is the stable one; it decides.
 static bool use_lockstep(bool /*bf16*/)
 {
-    static const bool v = getenv("DCE_GEMM") && strcmp(getenv("DCE_GEMM"), "lockstep") == 0;
-    return v;
+    return tune().gemm_lockstep;
 }
 
 template <bool BF16, bool OUT_BF16, int T> static hipError_t grant_phased()
@@ -424,17 +423,16 @@ hipError_t init_fc_gemm_phased()
 // 0 = this shape stays on the tile kernels of fc_gemm.hip.  DCE_GEMM=tile forces 0 (A/B).
 static int phased_tile(int64_t M, int N, int K, int es)
 {
-    static const bool off = getenv("DCE_GEMM") && strcmp(getenv("DCE_GEMM"), "tile") == 0;
-    static const int min_tiles = getenv("DCE_PHASED_MIN_TILES") ? atoi(getenv("DCE_PHASED_MIN_TILES")) : 192;
-    static const int min_tiles1 = getenv("DCE_PHASED_MIN_TILES1") ? atoi(getenv("DCE_PHASED_MIN_TILES1")) : 128;
-    static const int tmin = getenv("DCE_GEMM_PHASED_MIN") ? atoi(getenv("DCE_GEMM_PHASED_MIN")) : 1;   // 2: only the 256x128 tile
+    const Tuning& tu = tune();
+    const bool off = tu.gemm_tile;
+    const int min_tiles = tu.phased_min_tiles, min_tiles1 = tu.phased_min_tiles1, tmin = tu.phased_min;   // tmin 2: only the 256x128 tile
     if (off || (size_t)K * es % 256 || (size_t)K * es < 3 * 256 || M > (1 << 30)) return 0;
     if ((size_t)256 * K * es + 128 >= (1ull << 32)) return 0;                     // per-lane offsets are 32-bit
     // One workgroup per CU: a launch takes ceil(tiles / 256) rounds, and a round of 256 x 128 tiles lasts 3.83 rounds of
     // 128 x 64 tiles (fc.0: 525 vs 137 us).  Between the powers of two the small tile's finer rounds win: 3000 windows
     // are 192 big tiles = one round, 525 us, or 768 small ones = three rounds, 411 us.  (DCE_PHASED_COST=0: the first
     // tile size, from the large one down, that fills its minimum -- the rule before this cost model.)
-    static const bool cost_model = !(getenv("DCE_PHASED_COST") && atoi(getenv("DCE_PHASED_COST")) == 0);
+    const bool cost_model = tu.phased_cost;
     int best = 0;
     double best_cost = 0.0;
     for (int t = 2; t >= tmin; --t) {
@@ -465,12 +463,12 @@ static hipError_t launch_phased_cfg(const void* A, const void* W, const float* b
     // the 32 blocks of one XCD form an sm x sn super-tile: each A panel enters (ntiles/sn) L2s, each W panel
     // (mtiles/sm).  fc.0 (A = 2 W bytes, 16 x 16 tiles): 4 x 8 -> 2 A + 4 W = 310 MB of fabric reads per launch,
     // against 388 MB for 8 x 4 or 2 x 16.  DCE_PHASED_SN overrides log2(sn) (A/B).
-    static const int sn_env = getenv("DCE_PHASED_SN") ? atoi(getenv("DCE_PHASED_SN")) : 3;
-    int sn_log2 = sn_env;
+    int sn_log2 = tune().phased_sn;
     while ((1 << sn_log2) > ntiles) --sn_log2;         // (32/ntiles) x ntiles when N is narrow
     const int sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
+    plan_note(use_lockstep(BF16) ? (T == 2 ? "fc_lockstep256x128" : "fc_lockstep128x64") : (T == 2 ? "fc_phased256x128" : "fc_phased128x64"));
     if (use_lockstep(BF16))
         hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, true>), dim3(grid), dim3(512), Cfg::LDS, st,
                            A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, nullptr, nullptr, 0ll);
@@ -500,7 +498,7 @@ bool fc23_fused_ok(int64_t M, int bf16)
     // take the 256 x 128 tile + the stand-alone tail: forcing the small tile there (DCE_FC23=always) measured 0.8 %
     // slower end to end on the 1e6-window sequence (3.849 vs 3.879 M windows/s) -- twice the phase hand-overs cost
     // more than h2's HBM round trip.  DCE_FC23=split: never fused (A/B).
-    static const int mode = [] { const char* e = getenv("DCE_FC23"); return !e ? 0 : strcmp(e, "split") == 0 ? 1 : strcmp(e, "always") == 0 ? 2 : 0; }();
+    const int mode = tune().fc23_mode;
     if (mode == 1) return false;
     const int t = phased_tile(M, FC2, FC1, bf16 ? 2 : 4);
     if (t == 1) return true;
@@ -520,6 +518,7 @@ hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, co
     const long long pr = (long long)part_rows;
 #define FC23_LAUNCH(BF, LS) hipLaunchKernelGGL((fc_gemm_phased_kernel<BF, false, 1, 1, 256, true, LS>), dim3(grid), dim3(512), Cfg::LDS, st, \
                                                h1, W2, b2, h2v, (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, pr)
+    plan_note(use_lockstep(false) ? "fc23_fused_lockstep128x64" : "fc23_fused_phased128x64");
     if (bf16) { if (use_lockstep(true)) FC23_LAUNCH(true, true); else FC23_LAUNCH(true, false); }
     else      { if (use_lockstep(false)) FC23_LAUNCH(false, true); else FC23_LAUNCH(false, false); }
 #undef FC23_LAUNCH

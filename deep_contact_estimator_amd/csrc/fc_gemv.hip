@@ -128,6 +128,7 @@ hipError_t launch_fc_gemv(const float* A, const float* W, const float* bias, flo
     if (M <= 0) return hipSuccess;
     if (M > FC_GEMV_MAX_M || N % GV_R != 0 || K % GV_CH != 0) return hipErrorInvalidValue;
     const dim3 grid(N / GV_R), block(256);
+    plan_note("fc_gemv");
     if (M <= 8)       hipLaunchKernelGGL((fc_gemv_kernel<1, 8>), grid, block, 0, st, A, W, bias, C, (int)M, N, K, relu);
     else if (M <= 16) hipLaunchKernelGGL((fc_gemv_kernel<2, 8>), grid, block, 0, st, A, W, bias, C, (int)M, N, K, relu);
     else              hipLaunchKernelGGL((fc_gemv_kernel<4, 4>), grid, block, 0, st, A, W, bias, C, (int)M, N, K, relu);

@@ -4,10 +4,17 @@ Windows are independent (no BatchNorm, Dropout off in eval: reference utils/data
 uses only rows [i, i+150)), so rank g of G takes a contiguous range of windows and therefore the
 sequence rows of that range plus a 149-row halo; weights are replicated.  There is no collective
 inside the model.  The one exchange the path has is collecting the results: ONE RCCL gather of
-(n_g,68)-byte rows -- the (n_g,16) fp32 logits and the (n_g,4) u8 contacts packed side by side --
-to rank 0, point-to-point over xGMI, each peer on its own link.  Shard sizes are a pure function of
-(n, world): nothing but the payload is ever exchanged.  One process per GPU; ``torch.distributed`` backend "nccl" (= RCCL) on the
-GPUs, "gloo" in the CPU tests of this logic.
+(n_g,68)-byte rows -- the (n_g,16) fp32 logits and the (n_g,4) u8 contacts side by side, written in
+that form by the last kernel of the path -- to rank 0, point-to-point over xGMI, each peer on its own
+link.  Shard sizes are a pure function of (n, world): nothing but the payload is ever exchanged.
+
+Transport.  On the GPUs the gather is issued by libdce.so itself (include/dce.h dce_gather_results:
+ncclGather / one group of ncclSend+ncclRecv on a communication stream of the ctx; the count all-reduce
+of the accuracy epilogue is dce_allreduce_counts) -- pass the `model` that holds the communicator
+(`comm_bootstrap`).  ``torch.distributed`` is the launcher-side plumbing only: rank environment,
+host barriers, and the store that carries the 128-byte ncclUniqueId.  Without a communicator the same
+functions exchange through ``torch.distributed`` ("gloo" in the CPU tests of this logic and when ranks
+share one GPU, which RCCL refuses).
 """
 from __future__ import annotations
 
@@ -92,7 +99,45 @@ def gather_rows(t, sizes=None, group=None, dst: int = 0):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0).to(home)
 
 
-def infer_sequence_sharded(run, seq, group=None, dst: int = 0, n_windows: int | None = None, row_lo: int = 0):
+def comm_bootstrap(model, rank: int, world: int, key: str = "dce_comm_id"):
+    """Give `model` (one per rank) the node's RCCL communicator: rank 0 draws an ncclUniqueId and the 128 bytes travel
+    through the store of the initialised torch.distributed group (TCP, no GPU collective), or -- with DCE_COMM_ID_FILE
+    set and no process group -- through that file (written atomically by rank 0, polled by the others)."""
+    import os
+    import time
+    path = os.environ.get("DCE_COMM_ID_FILE")
+    store = None
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            from torch.distributed.distributed_c10d import _get_default_store
+            store = _get_default_store()
+    except Exception:
+        store = None
+    if store is not None:
+        if rank == 0:
+            store.set(key, type(model).comm_unique_id())
+        uid = bytes(store.get(key))
+    elif path:
+        if rank == 0:
+            with open(path + ".tmp", "wb") as f:
+                f.write(type(model).comm_unique_id())
+            os.replace(path + ".tmp", path)
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > 120:
+                raise RuntimeError(f"no ncclUniqueId appeared at {path}")
+            time.sleep(0.01)
+        uid = open(path, "rb").read()
+    elif world == 1:
+        uid = type(model).comm_unique_id()
+    else:
+        raise RuntimeError("comm_bootstrap needs an initialised torch.distributed group or DCE_COMM_ID_FILE")
+    model.comm_init(rank, world, uid)
+    return model
+
+
+def infer_sequence_sharded(run, seq, group=None, dst: int = 0, n_windows: int | None = None, row_lo: int = 0, model=None):
     """Run `run(seq_rows) -> {'logits','pred','contacts'}` (e.g. contact_cnn.infer_sequence) on
     this rank's shard of the sequence and gather the results to rank `dst` in window order with a
     single collective (logits + contact bits packed per row).  Returns the full dict on `dst`,
@@ -102,6 +147,16 @@ def infer_sequence_sharded(run, seq, group=None, dst: int = 0, n_windows: int | 
     range), or -- with `n_windows` = windows of the WHOLE sequence and `row_lo` = global index of
     seq's first row -- just this rank's rows (halo included), as when every rank generated or loaded
     only its own slice."""
+    if model is not None and getattr(model, "comm_world", 0):
+        # the product path on GPUs: packed rows straight from the tail kernel, ONE RCCL gather issued by libdce.so
+        world, rank = model.comm_world, model.comm_rank
+        if n_windows is None:
+            n_windows = max(seq.shape[0] - WINDOW + 1, 0)
+        sizes = shard_sizes(n_windows, world)
+        r0, r1, _, _ = shard_rows(n_windows + WINDOW - 1 if n_windows > 0 else 0, rank, world)
+        packed = model.infer_sequence_packed(seq[r0 - row_lo:r1 - row_lo])
+        got = model.gather_results(packed, sizes, root=dst)
+        return model.unpack_results(got) if rank == dst else None
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -114,7 +169,7 @@ def infer_sequence_sharded(run, seq, group=None, dst: int = 0, n_windows: int | 
     return unpack_results(got) if rank == dst else None
 
 
-def confusion_sharded(run, count, seq, labels, group=None):
+def confusion_sharded(run, count, seq, labels, group=None, model=None):
     """The accuracy epilogue of the reference's test loop (src/test.py:19-70,102-104) over the GPUs
     of a node: every rank classifies its shard of windows with ``run(seq_rows) -> {'pred', ...}``,
     forms the 16x16 counts of (label, prediction) pairs with ``count(pred, labels) -> (16,16) int64
@@ -123,8 +178,9 @@ def confusion_sharded(run, count, seq, labels, group=None):
     full matrix; every metric the reference prints is a function of it (metrics.py)."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    rccl = model is not None and getattr(model, "comm_world", 0)
+    world = model.comm_world if rccl else dist.get_world_size(group)
+    rank = model.comm_rank if rccl else dist.get_rank(group)
     r0, r1, w0, w1 = shard_rows(seq.shape[0], rank, world)
     if w1 > w0:
         pred = run(seq[r0:r1])["pred"]
@@ -132,6 +188,8 @@ def confusion_sharded(run, count, seq, labels, group=None):
         C = torch.as_tensor(C).to(torch.int64).reshape(16, 16).clone()
     else:                                      # more ranks than windows: this rank contributes zeros
         C = torch.zeros((16, 16), dtype=torch.int64, device=getattr(seq, "device", None))
+    if rccl:
+        return model.allreduce_counts(C.contiguous())        # ncclAllReduce issued by libdce.so (dce_allreduce_counts)
     if dist.get_backend(group) == "gloo":
         C = C.cpu()
     dist.all_reduce(C, op=dist.ReduceOp.SUM, group=group)
@@ -209,3 +267,32 @@ class AsyncRowGather:
 
     def latest(self):
         return None if self._done is None or self.rank != self.dst else self._bufs[self._done]
+
+
+class PackedStepGather:
+    """The per-step result exchange of bench.py / a serving loop on RCCL through the C ABI: every step the model writes
+    its (rows,68) packed results into one of two device buffers and libdce.so gathers them to rank `dst` on its
+    communication stream (dce_gather_results, async), so step i's gather rides behind step i+1's kernels; the library
+    orders step i+2's writes behind gather i.  `latest()` on `dst` = the (world*rows,68) block of the newest finished step."""
+
+    def __init__(self, model, rows: int, device, dst: int = 0):
+        import torch
+        self.model, self.dst, self.rows = model, dst, rows
+        self.send = [torch.empty((rows, PACK_COLS), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = ([torch.empty((rows * model.comm_world, PACK_COLS), dtype=torch.uint8, device=device) for _ in range(2)]
+                     if model.comm_rank == dst else [None, None])
+        self._i = 0
+        self.bytes_per_step = rows * PACK_COLS * model.comm_world       # what lands on the root per step
+
+    def step(self, windows):
+        s = self._i & 1
+        packed = self.model.predict_packed(windows, out=self.send[s])
+        self.model.gather_results(packed, None, root=self.dst, out=self.recv[s], async_=True)
+        self._i += 1
+        return packed
+
+    def drain(self):
+        self.model.comm_sync()
+
+    def latest(self):
+        return None if self._i == 0 else self.recv[(self._i - 1) & 1]

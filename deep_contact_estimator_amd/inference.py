@@ -52,11 +52,13 @@ def _counts(pred, contacts, gt_label):
     return per_leg, correct, bin_gt
 
 
-def inference_and_compute_acc(dataloader, model, device=None):
-    """-> (infer_results (N,4) u8, acc, acc_per_leg (4,)).  Labels may be (B,) or (B,1); the
-    reference's (B,)==(B,1) broadcast at src/inference_one_seq.py:54 (wrong for B>1, SURVEY
-    8(a) a8) is not reproduced: class accuracy is elementwise for every batch size, which
-    equals the reference at its shipped batch_size 1."""
+def inference_and_compute_acc(dataloader, model, device=None, reference_broadcast: bool = False):
+    """-> (infer_results (N,4) u8, acc, acc_per_leg (4,)).  Labels may be (B,) or (B,1).  By default the class
+    accuracy is elementwise for every batch size, which equals the reference at its shipped batch_size 1.
+    reference_broadcast=True reproduces the reference LITERALLY: at src/inference_one_seq.py:54 it compares the
+    (B,) predictions with the (B,1) labels mat2numpy_one_seq writes, which broadcasts to (B,B) and counts every
+    (prediction j, label i) match of a batch -- a "class accuracy" that can exceed 1 at B>1.  With
+    1-D labels the two modes agree."""
     import torch
     num_data = 0
     per_leg = None
@@ -65,6 +67,8 @@ def inference_and_compute_acc(dataloader, model, device=None):
     for sample in dataloader:
         out = model.predict(sample["data"])
         pl, cr, _ = _counts(out["pred"], out["contacts"], sample["label"])
+        if reference_broadcast:                                 # (prediction==gt_label).sum() with gt_label as the loader gave it
+            cr = (out["pred"].to(torch.int64) == sample["label"].to(out["pred"].device)).sum()
         per_leg = pl if per_leg is None else per_leg + pl       # stays on the device: no per-batch sync
         correct = cr if correct is None else correct + cr
         num_data += out["pred"].shape[0]

@@ -55,15 +55,18 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         from . import metrics
+        from .distributed import comm_bootstrap
+        if dist.get_backend() == "nccl":      # the exchanges below are then issued by libdce.so itself (dce_gather_results)
+            comm_bootstrap(model, rank, world)
         if config["calculate_accuracy"]:
-            C = confusion_sharded(model.infer_sequence, model.confusion_counts, dataset.data, dataset.label)
+            C = confusion_sharded(model.infer_sequence, model.confusion_counts, dataset.data, dataset.label, model=model)
             mt = metrics.metrics_from_confusion16(C.cpu().numpy())
             if rank == 0:
                 print("Accuracy in terms of class: %.4f" % mt["acc"])
                 for leg in range(4):
                     print("Accuracy of leg %d is: %.4f" % (leg, mt["acc_per_leg"][leg]))
                 print("Accuracy is: %.4f" % (np.sum(mt["acc_per_leg"]) / 4.0))
-        res = infer_sequence_sharded(model.infer_sequence, dataset.data, dst=0)
+        res = infer_sequence_sharded(model.infer_sequence, dataset.data, dst=0, model=model)
         dist.barrier()
         if rank != 0:
             dist.destroy_process_group()

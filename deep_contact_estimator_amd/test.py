@@ -52,8 +52,12 @@ def main(argv=None):
     from . import metrics
     if world > 1:
         # sharded evaluation: each rank one fused pass over its windows, one 2 KB all-reduce
+        import torch.distributed as dist
+        from .distributed import comm_bootstrap
+        if dist.get_backend() == "nccl":      # the count all-reduce is then issued by libdce.so (dce_allreduce_counts)
+            comm_bootstrap(model, rank, world)
         C = confusion_sharded(lambda rows: model.infer_sequence(rows), model.confusion_counts,
-                              test_data.data, test_data.label)
+                              test_data.data, test_data.label, model=model)
         mt = metrics.metrics_from_confusion16(C.cpu().numpy())
         if rank == 0:
             print("\n".join(metrics.report_lines(mt)))

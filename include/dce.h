@@ -54,7 +54,8 @@ typedef enum dce_status {
     DCE_ERR_HIP         = -2,  /* a HIP runtime call failed; message has hipGetErrorString */
     DCE_ERR_STATE       = -3,  /* called in the wrong order (e.g. forward before finalize) */
     DCE_ERR_KEY         = -4,  /* unknown or duplicate state_dict key */
-    DCE_ERR_NOMEM       = -5
+    DCE_ERR_NOMEM       = -5,
+    DCE_ERR_COMM        = -6   /* RCCL is unavailable or one of its calls failed; message has ncclGetErrorString */
 } dce_status;
 
 typedef enum dce_precision {
@@ -108,6 +109,18 @@ int  dce_forward_windows(dce_ctx* ctx, const float* windows, int64_t n, int on_d
 int  dce_infer_sequence(dce_ctx* ctx, const float* seq, int64_t T, int window, int on_device,
                         float* logits, int32_t* pred, uint8_t* contacts);
 
+/* The same two calls with the results as ONE array of DCE_PACKED_ROW-byte rows -- the 16 fp32 logits of a window
+ * followed by its 4 contact bits (pred is the four bits read MSB first, src/inference_one_seq.py:59-62 is a
+ * bijection on 0..15) -- written in that form by the last kernel of the path.  This is the row format of the
+ * multi-GPU gather below: what a rank computes is what travels, no repacking pass. */
+#define DCE_PACKED_ROW  68
+int  dce_forward_windows_packed(dce_ctx* ctx, const float* windows, int64_t n, int on_device, uint8_t* packed);
+int  dce_infer_sequence_packed(dce_ctx* ctx, const float* seq, int64_t T, int window, int on_device, uint8_t* packed);
+/* (n,68) packed rows -> logits (n,16) f32, pred (n) i32, contacts (n,4) u8 (any may be NULL); device pointers run
+ * as one kernel on the ctx stream, host pointers are unpacked on the host (ctx may then be NULL). */
+int  dce_unpack_results(dce_ctx* ctx, const uint8_t* packed, int64_t n, int on_device,
+                        float* logits, int32_t* pred, uint8_t* contacts);
+
 /* contact_dataset.__getitem__ for windows [first, first+n): materialise the z-scored
  * windows (n,150,54) from a raw (T,54) sequence (utils/data_handler.py:55-56). */
 int  dce_zscore_windows(dce_ctx* ctx, const float* seq, int64_t T, int64_t first, int64_t n,
@@ -116,9 +129,23 @@ int  dce_zscore_windows(dce_ctx* ctx, const float* seq, int64_t T, int64_t first
 /* Per-layer taps for parity tests: run ONE batch of pre-normalised windows and copy out
  * intermediate activations (device or host pointers per on_device; any may be NULL):
  *   feat (n,4736) = block2 output flattened channel-major (src/contact_cnn.py:64)
- *   h1   (n,2048) = ReLU(fc.0)      h2 (n,512) = ReLU(fc.3) */
+ *   h1   (n,2048) = ReLU(fc.0)      h2 (n,512) = ReLU(fc.3)
+ * fp32 arrays; in the DCE_BF16_FC mode feat and h1 ARE bf16 (the operands of the bf16 GEMMs) and the taps hand out
+ * their uint16 bit patterns -- (n,4736) / (n,2048) uint16 -- while h2 and logits stay fp32. */
 int  dce_forward_taps(dce_ctx* ctx, const float* windows, int64_t n, int on_device,
-                      float* feat, float* h1, float* h2, float* logits);
+                      void* feat, void* h1, float* h2, float* logits);
+
+/* Parity-test hook for the layers INSIDE the fused conv stack (reference src/contact_cnn.py:10-26,28-44; the
+ * forward hooks of tests/golden/make_golden.py): run ONE named conv kernel family on n <= 64 pre-normalised HOST
+ * windows with per-layer taps switched on and return the post-ReLU activations in PyTorch layout (HOST arrays):
+ *   conv1 (n,64,150)  conv2 (n,64,150, before the pool)  pool1 (n,64,75)  conv3 (n,128,75)
+ *   conv4 (n,128,75, before the pool)  feat (n,4736) = pool2 flattened.
+ * kernel: 0 two-window Winograd workgroup (the chip-filling kernel), 1 one window on eight waves, 2 half-window
+ * segments, 3 quarter-window segments, 4 direct form (DCE_CONV=direct), 5 one window on four waves, 6 four windows
+ * on eight waves.  The segment kernels (2, 3) never compute conv4's t = 74 (MaxPool drops it): that column reads NaN.
+ * The tapped kernels are the product kernels instantiated with the extra stores; fp32 mode only. */
+int  dce_conv_layer_taps(dce_ctx* ctx, const float* windows, int64_t n, int kernel,
+                         float* conv1, float* conv2, float* pool1, float* conv3, float* conv4, float* feat);
 
 /* "Next" row after the path (reference src/test.py:19-70,102-104; src/inference_one_seq.py:48-54):
  * accumulate the 16x16 class confusion counts  counts[gt*16 + pred] += 1  over n windows.
@@ -142,6 +169,40 @@ int  dce_confusion_counts(dce_ctx* ctx, const int32_t* pred, const int64_t* labe
 int  dce_online_reset(dce_ctx* ctx);
 int  dce_online_push(dce_ctx* ctx, const float* sample, float* logits, int32_t* pred, uint8_t* contacts);
 
+/* Multi-GPU (not in the reference, which is single-device: src/inference_one_seq.py:139; BASELINE.json configs[3]).
+ * Windows are independent (utils/data_handler.py:55-57), so the GPUs of a node take contiguous window ranges (a
+ * 149-row halo of the sequence per boundary, weights replicated; one process and one ctx per GPU) and the ONLY
+ * exchange is collecting the results: one RCCL gather over xGMI of every rank's packed rows to the root.
+ *
+ *   dce_comm_get_unique_id  rank 0: a fresh ncclUniqueId; the host carries its 128 bytes to the other ranks (file,
+ *                           environment, any store) -- no MPI, no torch needed.
+ *   dce_comm_init           every rank (collective, blocks until all `world` ranks have called): ncclCommInitRank on
+ *                           the ctx's device.  RCCL is bound at run time: $DCE_RCCL_LIB, else the librccl already in
+ *                           the process, else the system one.
+ *   dce_comm_info           what RCCL reports for the communicator (ncclCommUserRank / ncclCommCount / ncclGetVersion)
+ *                           and which library was bound.
+ *   dce_gather_results      rank r's packed_local (n_local,68) DEVICE rows -> the root's packed_all, rank blocks in rank
+ *                           order (rows_per_rank[g] rows of rank g; NULL = every rank holds n_local rows): ONE
+ *                           ncclGather, or -- when the shards differ in length -- one ncclGroup of ncclSend/ncclRecv
+ *                           with the true sizes.  Runs on a ctx-owned communication stream behind everything queued on
+ *                           the ctx stream so far.  async == 0: work queued on the ctx stream afterwards waits for it
+ *                           (stream-ordered, no host block).  async != 0: it overlaps the kernels queued after it; work
+ *                           queued after THIS call waits only for the gather issued by the PREVIOUS async call, so a
+ *                           caller that alternates two send buffers (and two receive buffers on the root) never
+ *                           overwrites rows in flight.  packed_all may be NULL off the root.
+ *   dce_allreduce_counts    sum the 256 confusion counts of dce_confusion_counts over the ranks (ncclAllReduce, int64).
+ *   dce_comm_sync           block until every exchange issued on this ctx has completed; reports asynchronous RCCL errors.
+ *   dce_comm_destroy        ncclCommDestroy (dce_destroy does it too). */
+#define DCE_COMM_ID_BYTES 128
+int  dce_comm_get_unique_id(uint8_t id[DCE_COMM_ID_BYTES]);
+int  dce_comm_init(dce_ctx* ctx, int rank, int world, const uint8_t id[DCE_COMM_ID_BYTES]);
+int  dce_comm_info(dce_ctx* ctx, int* rank, int* world, int* rccl_version, char* library, int library_len);
+int  dce_gather_results(dce_ctx* ctx, const uint8_t* packed_local, int64_t n_local, uint8_t* packed_all,
+                        const int64_t* rows_per_rank, int root, int async);
+int  dce_allreduce_counts(dce_ctx* ctx, int64_t* counts, int on_device);
+int  dce_comm_sync(dce_ctx* ctx);
+int  dce_comm_destroy(dce_ctx* ctx);
+
 /* Kernel timing with HIP events on the ctx's stream, for bench.py's roofline block.
  * on = k > 0 records an event pair around each of the four kernels of every k-th kernel sequence
  * (k = 1: every one; an event costs ~4 us of stream time, so a sparse sample keeps the timed
@@ -152,6 +213,11 @@ int  dce_online_push(dce_ctx* ctx, const float* sample, float* logits, int32_t* 
 #define DCE_PROFILE_SLOTS 4
 int  dce_profile_enable(dce_ctx* ctx, int on);
 int  dce_profile_read(dce_ctx* ctx, double ms[DCE_PROFILE_SLOTS], int64_t launches[DCE_PROFILE_SLOTS], int reset);
+
+/* Which kernels the most recent kernel sequence of this ctx launched, as space-separated family names in launch order
+ * (e.g. "conv_wino2 fc_phased256x128 fc23_fused_phased128x64 fc6_combine"): lets a test assert that a batch size or an
+ * A/B switch (read from the environment once per dce_create) selected the kernel it means to check. */
+int  dce_last_plan(dce_ctx* ctx, char* out, int out_len);
 
 /* Block until everything queued on the ctx stream has finished. */
 int  dce_sync(dce_ctx* ctx);

@@ -46,6 +46,8 @@ def lib():
             build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_argmax16.restype = C.c_int32
+        _lib.oracle_bf16_round.restype = C.c_float
+        _lib.oracle_bf16_round.argtypes = [C.c_float]
     return _lib
 
 
@@ -67,8 +69,15 @@ def _p(a):
 class Oracle:
     """Holds a state_dict (numpy fp32, PyTorch layouts) and evaluates the reference path."""
 
-    def __init__(self, state_dict):
+    def __init__(self, state_dict, bf16_fc: bool = False):
+        """bf16_fc: BASELINE configs[4] -- fc.0 / fc.3 weights rounded to bf16 here (once), their input activations
+        rounded inside the C restatement; everything else fp32."""
         self._keep = []
+        self.bf16_fc = bool(bf16_fc)
+        if self.bf16_fc:
+            state_dict = dict(state_dict)
+            for k in ("fc.0.weight", "fc.3.weight"):
+                state_dict[k] = bf16_round(state_dict[k])
         w = _Weights()
         names = [f[0] for f in _Weights._fields_]
         i = 0
@@ -94,7 +103,8 @@ class Oracle:
             out["feat"] = np.empty((n, 4736), np.float32)
             out["h1"] = np.empty((n, 2048), np.float32)
             out["h2"] = np.empty((n, 512), np.float32)
-        rc = lib().oracle_forward_windows(
+        fn = lib().oracle_forward_windows_bf16fc if self.bf16_fc else lib().oracle_forward_windows
+        rc = fn(
             C.byref(self._w), _p(x), C.c_int64(n), _p(out.get("feat")), _p(out.get("h1")),
             _p(out.get("h2")), _p(out["logits"]), _p(out["pred"]), _p(out["contacts"]))
         assert rc == 0
@@ -131,6 +141,37 @@ class Oracle:
             "conv1", "conv2", "pool1", "conv3", "conv4", "pool2")])
         assert rc == 0
         return out
+
+
+def bf16_round(a):
+    """fp32 array -> fp32 array of bf16-representable values (round-to-nearest-even; oracle_bf16_round)."""
+    x = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+    out = np.empty_like(x)
+    lib().oracle_bf16_round_array(_p(x), C.c_int64(x.size), _p(out))
+    return out
+
+
+def bf16_bits(a):
+    """bf16-representable fp32 array -> its uint16 bit patterns (the upper halves)."""
+    x = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+    return (x.view(np.uint32) >> 16).astype(np.uint16)
+
+
+def bf16_from_bits(u):
+    """uint16 bf16 bit patterns -> fp32 values."""
+    return (np.ascontiguousarray(u, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def linear_rows(x, w, b, relu: bool):
+    """y = act(x W^T + b) row by row, fp64 accumulate (src/contact_cnn.py:48-57)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    y = np.empty((x.shape[0], w.shape[0]), np.float32)
+    rc = lib().oracle_linear_rows(_p(x), C.c_int64(x.shape[0]), C.c_int(x.shape[1]), _p(w), _p(b), C.c_int(w.shape[0]),
+                                  C.c_int(int(relu)), _p(y))
+    assert rc == 0
+    return y
 
 
 def zscore_windows(seq):

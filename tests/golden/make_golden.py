@@ -288,7 +288,48 @@ def ingest_case():
     print("ingest:", data.shape, data.dtype, label.shape, label.dtype)
 
 
+def bf16fc_case():
+    """BASELINE.json configs[4] ("MFMA bf16 on FC layers + fp32 accumulate") has no counterpart in the reference, so
+    its expected values are DERIVED from the reference here: the reference model's own block1/block2 give the fp32
+    features, and its fc layers (src/contact_cnn.py:47-58) are evaluated with torch's bfloat16 conversion of the
+    features, of ReLU(fc.0) and of the fc.0 / fc.3 weights, products and sums in float64 (exact for bf16 operands),
+    one rounding to fp32 per layer; fc.6 and the biases stay fp32.  oracle_forward_windows_bf16fc is pinned on these
+    vectors (tests/test_oracle.py)."""
+    wseed, bias, T, sseed, kind = 1, "uniform", 150 + 63, 7, "normal"
+    sd = synth.make_state_dict(wseed, bias)
+    seq = synth.make_sequence(T, sseed, kind)
+    lab = synth.make_labels(T, sseed, two_d=False)
+    model = build_model(sd)
+    with tempfile.TemporaryDirectory() as d:
+        dp, lp = os.path.join(d, "data.npy"), os.path.join(d, "label.npy")
+        np.save(dp, seq); np.save(lp, lab)
+        ds = contact_dataset(data_path=dp, label_path=lp, window_size=150, device="cpu")
+        x = torch.stack([ds[i]["data"] for i in range(len(ds))])
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    with torch.no_grad():
+        feat = model.block2(model.block1(x.permute(0, 2, 1))).reshape(x.shape[0], -1)          # reference modules, fp32
+        fc0, fc3, fc6 = model.fc[0], model.fc[3], model.fc[6]
+        h1 = torch.relu(bf(feat) @ bf(fc0.weight).T + fc0.bias.double()).float()
+        h2 = torch.relu(bf(h1) @ bf(fc3.weight).T + fc3.bias.double()).float()
+        logits = (h2.double() @ fc6.weight.double().T + fc6.bias.double()).float()
+        fp32_logits = model(x)
+    out = dict(wseed=wseed, bias=bias, T=T, sseed=sseed, kind=kind,
+               seq_checksum=checksum(seq.astype(np.float32)),
+               w_checksum=np.stack([checksum(sd[k]) for k, _ in synth.STATE_DICT_SHAPES]),
+               logits=logits.numpy(), pred=logits.argmax(1).numpy().astype(np.int32),
+               feat_bf16_w0=feat[0].to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16),
+               h1_bf16_w0=h1[0].to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16),
+               h2_w0=h2[0].numpy(), fp32_logits=fp32_logits.numpy())
+    np.savez_compressed(os.path.join(HERE, "bf16fc.npz"), **out)
+    d = (logits - fp32_logits).abs().max().item()
+    print(f"bf16fc: n={x.shape[0]} max|logit| {logits.abs().max().item():.2f} max|bf16-fp32| {d:.3e} "
+          f"flips {(logits.argmax(1) != fp32_logits.argmax(1)).sum().item()}")
+
+
 if __name__ == "__main__":
+    if "--only-bf16fc" in sys.argv:
+        bf16fc_case()
+        sys.exit(0)
     # case A: N(0,1) sequence, biased He weights, batch 30 (config/test_params.yaml:9), 1-D labels
     run_case("seq_normal", wseed=1, bias="uniform", T=150 + 255, sseed=0, kind="normal",
              batch=30, label_2d=False)
@@ -301,3 +342,4 @@ if __name__ == "__main__":
     export_case()
     loop_case()
     ingest_case()
+    bf16fc_case()

@@ -25,7 +25,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dce_abi_version() == 1
+    assert lib.dce_abi_version() == 2
 
 
 def test_no_gpu_fails_loudly(lib):

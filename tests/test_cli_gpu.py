@@ -116,6 +116,29 @@ def test_bench_two_rank_flow():
     assert abs(j["value"] - 2 * 4096 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
 
 
+def test_bench_self_launch_from_the_plain_command_line():
+    """`python bench.py --gpus 2 --steps 5` started PLAINLY (no torch.distributed.run, no WORLD_SIZE): bench.py re-executes
+    itself as two ranks on a free port and rank 0 prints the one JSON line with n_gpus == 2 -- the command the driver will
+    run with an 8 on an 8-GPU node.  Here the two ranks share the one GPU, so the transport is gloo (RCCL refuses two ranks
+    per device); without DCE_DIST_BACKEND=gloo the same command must refuse loudly instead of hanging."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(PYTHONPATH=ROOT, DCE_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["warmup"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["global_batch"] == 2 * j["config"]["batch_per_gpu"] and "rccl" in j
+    assert j["extra"]["sharded_1e6"]["windows_per_s_incl_gather"] > 0
+    del env["DCE_DIST_BACKEND"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "RCCL takes one rank per device" in (r.stdout + r.stderr)
+
+
 def test_config3_full_size_shards_equal_single_call():
     """BASELINE configs[3] at its full size (8e6 windows, 1.73 GB sequence): the 8 halo-sharded ranges
     of a node, computed one after the other on this GPU, equal the single call bit for bit, and the
@@ -158,6 +181,25 @@ ok = ok and torch.equal(g.latest()[0], one["logits"])
 labels = torch.from_numpy(synth.make_labels(150 + 700, 9).reshape(-1)).to(dev)
 C = confusion_sharded(m.infer_sequence, m.confusion_counts, seq, labels)
 ok = ok and int(C.sum().item()) == 701
+# ---- the product's exchange: RCCL issued by libdce.so itself (dce_comm_init / dce_gather_results / dce_allreduce_counts)
+from deep_contact_estimator_amd.distributed import comm_bootstrap, PackedStepGather
+comm_bootstrap(m, rank, world)
+info = m.comm_info()
+ok = ok and info["world"] == 1 and info["rank"] == 0 and info["rccl_version"] > 0 and "rccl" in info["library"]
+got2 = infer_sequence_sharded(m.infer_sequence, seq, dst=0, model=m)            # packed rows, ONE ncclGather (uniform sizes)
+ok = ok and all(torch.equal(got2[k], one[k]) for k in ("logits", "pred", "contacts"))
+packed = m.infer_sequence_packed(seq)
+rag = m.gather_results(packed, [701], root=0)                                    # explicit sizes -> same result
+ok = ok and torch.equal(rag, packed)
+C2 = confusion_sharded(m.infer_sequence, m.confusion_counts, seq, labels, model=m)   # ncclAllReduce int64
+ok = ok and torch.equal(C2.cpu(), C.cpu())
+win = m.zscore_windows(seq, 0, 64)
+psg = PackedStepGather(m, 64, dev, dst=0)
+for _ in range(5):                                                               # two async gathers in flight, buffers alternate
+    psg.step(win)
+psg.drain()
+ok = ok and torch.equal(psg.latest(), m.predict_packed(win)) and psg.bytes_per_step == 64 * 68
+m.comm_sync(); m.comm_destroy()
 t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier(); dist.destroy_process_group()
 print(json.dumps({"ok": bool(ok), "max": float(t.item())}))
@@ -186,8 +228,10 @@ def test_bench_multi_gpu_flow_on_rccl_single_rank():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and "RCCL gather" in j["config"]["sharding"] and j["value"] > 1e6
+    rc = j["rccl"]                                         # the per-step exchange went through libdce.so's own communicator
+    assert rc["world_size_ncclCommCount"] == 1 and rc["gathered_bytes_per_step"] == 4096 * 68 and "dce_gather_results" in rc["backend"]
     sh = j["extra"]["sharded_1e6"]
-    assert sh["windows_per_s_incl_gather"] > 1e6 and abs(sh["gathered_MB"] - 68.0) < 1e-9
+    assert sh["windows_per_s_incl_gather"] > 1e6 and abs(sh["gathered_MB"] - 68.0) < 1e-9 and "dce_gather_results" in sh["transport"]
 
 
 def test_bench_default_line_contract():
@@ -208,7 +252,7 @@ def test_bench_default_line_contract():
     assert abs(j["value"] - 4096 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6 and j["value"] > 1e6
     rf = j["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert 0.5 < rf["frac"] < 1.0 and "traffic" in rf
+    assert 0.5 < rf["frac"] < 1.0 and "traffic" in rf and "traffic_stale" in rf
     cb = j["cpu_baseline"]
     assert cb["value"] > 0 and cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["sample"]
     ex = j["extra"]

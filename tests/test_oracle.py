@@ -109,3 +109,53 @@ def test_oracle_vs_reference_loop_functions(golden, case_inputs):
     assert (out["pred"] == gt).mean() == float(g["acc_B1"])
     assert np.array_equal((out["contacts"] == oracle.decimal2binary(gt)).mean(0), g["acc_per_leg_B1"])
     assert float(g["acc_B30"]) > 1.0          # (B,)==(B,1) broadcast at :54 -- not an accuracy; kept as documentation
+
+
+def test_bf16fc_restatement_pinned_on_reference_derived_vectors(golden, case_inputs):
+    """oracle_forward_windows_bf16fc (BASELINE configs[4]) against tests/golden/bf16fc.npz, which make_golden.py derived
+    from the reference's own modules with torch's bfloat16 conversion and float64 matmuls.  Stage by stage on the
+    golden's own layer inputs the two fp64-accumulated evaluations must agree to the last bf16 / fp32 bit pattern
+    (bf16 products are exact in fp64); end to end (features from the oracle's conv stack instead of MKL-DNN's) a few
+    features round the other way at bf16 boundaries, hence the band."""
+    g = golden("bf16fc")
+    sd, seq = case_inputs(g)
+    w1, w2 = orc.bf16_round(sd["fc.0.weight"]), orc.bf16_round(sd["fc.3.weight"])
+    # torch's own conversion of the weights agrees with the restated rounding, bit for bit
+    import torch
+    for k, w in (("fc.0.weight", w1), ("fc.3.weight", w2)):
+        t = torch.from_numpy(sd[k]).to(torch.bfloat16).float().numpy()
+        assert np.array_equal(t.view(np.uint32), w.view(np.uint32)), k
+    feat = orc.bf16_from_bits(g["feat_bf16_w0"])[None]
+    h1 = orc.linear_rows(feat, w1, sd["fc.0.bias"], relu=True)
+    assert np.array_equal(orc.bf16_bits(orc.bf16_round(h1))[0], g["h1_bf16_w0"])
+    h2 = orc.linear_rows(orc.bf16_round(h1), w2, sd["fc.3.bias"], relu=True)
+    np.testing.assert_allclose(h2[0], g["h2_w0"], rtol=1e-6, atol=1e-6 * np.abs(g["h2_w0"]).max())
+    lg = orc.linear_rows(h2, sd["fc.6.weight"], sd["fc.6.bias"], relu=False)
+    np.testing.assert_allclose(lg[0], g["logits"][0], rtol=1e-6, atol=1e-6 * np.abs(g["logits"]).max())
+    # end to end from the raw sequence
+    o = orc.Oracle(sd, bf16_fc=True)
+    out = o.forward_windows(orc.zscore_windows(seq), taps=True)
+    scale = np.abs(g["logits"]).max()
+    assert np.abs(out["logits"] - g["logits"]).max() <= 1e-3 * scale
+    fb = orc.bf16_bits(out["feat"][0])
+    assert (fb != g["feat_bf16_w0"]).mean() < 5e-3                     # rounding-boundary flips only
+    assert np.array_equal(orc.bf16_round(out["feat"]), out["feat"]) and np.array_equal(orc.bf16_round(out["h1"]), out["h1"])
+    srt = np.sort(g["logits"], axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 1e-2 * scale
+    assert safe.sum() > 0.8 * safe.size and np.array_equal(out["pred"][safe], g["pred"][safe])
+    # and the mode is a real change of arithmetic: it differs from fp32 by ~bf16 epsilon, not by fp32 noise
+    d = np.abs(g["logits"] - g["fp32_logits"]).max()
+    assert 1e-4 * scale < d < 5e-2 * scale
+
+
+def test_bf16_round_edge_cases():
+    x = np.array([1.0, 1.00390625, 1.005859375, 1.01171875, -1.00390625, 3.4e38, np.inf, -np.inf, 0.0, -0.0, 1e-40],
+                 np.float32)
+    r = orc.bf16_round(x)
+    # ties to even: 1 + 2^-8 is half way between 1 and 1 + 2^-7 -> 1 (even); 1 + 3*2^-9 rounds up; 1 + 3*2^-8 ties -> 1 + 2^-6
+    assert r[0] == 1.0 and r[1] == 1.0 and r[2] == 1.0078125 and r[3] == 1.015625 and r[4] == -1.0
+    assert np.isinf(r[5]) and np.isinf(r[6]) and r[7] == -np.inf and r[8] == 0 and np.signbit(r[9])
+    assert np.isnan(orc.bf16_round(np.array([np.nan], np.float32))[0])
+    import torch
+    big = np.random.default_rng(0).standard_normal(200000).astype(np.float32) * np.float32(37.0)
+    assert np.array_equal(orc.bf16_round(big).view(np.uint32), torch.from_numpy(big).to(torch.bfloat16).float().numpy().view(np.uint32))

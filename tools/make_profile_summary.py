@@ -54,6 +54,10 @@ def main(tag):
         latest[NAMES[k]] = {"hbm_bytes_per_launch": hbm, "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
                             "algorithmic_bytes_per_launch": algo, "mfma_busy_frac": busy, "profile": tag,
                             "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 counts 128-B requests as 64 B)"}
+    # the build these counters were taken on (tools/profile_gpu.sh records the hash of the .so's sources on the box):
+    # bench.py marks roofline.traffic stale when the library it times was built from other sources
+    hp = os.path.join(out, f"{tag}_source_hash.txt")
+    latest["_meta"] = {"profile": tag, "source_hash": open(hp).read().strip() if os.path.exists(hp) else None}
     open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
     json.dump(latest, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
     print("\n".join(lines))

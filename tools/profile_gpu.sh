@@ -5,6 +5,7 @@ set -u
 TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
+python -c "from deep_contact_estimator_amd import build; print(build.built_hash())" > $OUT/${TAG}_source_hash.txt
 B="python bench.py --steps 20 --warmup 3 --settle-s 0.2 --no-cpu-baseline --no-extras --no-kernel-timing"
 # long enough for the clocks to settle: the averages then agree with bench.py's HIP-event times to <1 %
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o ${TAG} -- python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extras --no-kernel-timing > $OUT/${TAG}_stats.log 2>&1
