@@ -9,6 +9,8 @@
  *      wherever the oracle's top-2 margin exceeds 1e-3*max|logit|
  *   4. dce_online_push row by row == dce_infer_sequence, bit for bit
  *   5. dce_forward_windows on the oracle's z-scored windows == the fused sequence path (tolerance)
+ *   6. dce_infer_sequence_packed rows == logits + contact bits, dce_unpack_results inverts them
+ *   7. dce_comm_* / dce_gather_results / dce_allreduce_counts in an RCCL world of one rank
  *
  * Build (tests/test_c_client.py does this):
  *   gcc -O2 -std=c11 -fopenmp -Iinclude -Ioracle tests/c/abi_client.c oracle/dce_oracle.c \
@@ -25,6 +27,17 @@
 
 #include "dce.h"
 #include "dce_oracle.h"
+
+/* the client's own device buffers for section 7: four runtime calls, declared here so that the file stays plain C
+ * (hip_runtime_api.h wants a platform macro); libamdhip64 is on the link line */
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipFree(void* p);
+hipError_t hipMemcpy(void* dst, const void* src, size_t n, int kind);
+hipError_t hipMemset(void* p, int v, size_t n);
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static double uniform01(void)
@@ -157,6 +170,54 @@ int main(void)
     for (int e = 0; e < N * DCE_CLASSES; ++e)
         worst = fmax(worst, fabs((double)logits_w[e] - ref_logits[e]) / (1e-5 * maxref + 1e-4 * fabs(ref_logits[e])));
     CHECK(worst <= 1.0, "forward_windows outside tolerance: err/bound = %.3f", worst);
+
+    /* ---- 6. packed rows (16 fp32 logits + 4 contact bits) == the three arrays; unpack on the host */
+    static uint8_t packed[N * DCE_PACKED_ROW];
+    CHECK(dce_infer_sequence_packed(ctx, seq, T, DCE_WINDOW, 0, packed) == DCE_OK, "packed: %s", dce_last_error(ctx));
+    for (int i = 0; i < N; ++i)
+        CHECK(memcmp(packed + i * DCE_PACKED_ROW, logits + i * DCE_CLASSES, 64) == 0 &&
+              memcmp(packed + i * DCE_PACKED_ROW + 64, contacts + 4 * i, 4) == 0, "packed row %d", i);
+    {
+        static float ul[N * DCE_CLASSES]; static int32_t up[N]; static uint8_t uc[N * 4];
+        CHECK(dce_unpack_results(NULL, packed, N, 0, ul, up, uc) == DCE_OK, "host unpack");
+        CHECK(memcmp(ul, logits, sizeof ul) == 0 && memcmp(up, pred, sizeof up) == 0 && memcmp(uc, contacts, sizeof uc) == 0, "unpack");
+    }
+
+    /* ---- 7. the multi-GPU exchange in the only form one GPU allows: an RCCL world of one rank, bootstrapped exactly
+     *         as N processes would (unique id from rank 0 -> dce_comm_init on every rank -> dce_gather_results) */
+    {
+        uint8_t id[DCE_COMM_ID_BYTES];
+        CHECK(dce_gather_results(ctx, NULL, 0, NULL, NULL, 0, 0) == DCE_ERR_STATE, "gather before comm_init");
+        CHECK(dce_comm_get_unique_id(id) == DCE_OK, "unique id: %s", dce_last_error(NULL));
+        CHECK(dce_comm_init(ctx, 1, 1, id) == DCE_ERR_ARG, "rank out of range");
+        CHECK(dce_comm_init(ctx, 0, 1, id) == DCE_OK, "comm_init: %s", dce_last_error(ctx));
+        int rk = -1, wd = -1, ver = 0; char libname[256];
+        CHECK(dce_comm_info(ctx, &rk, &wd, &ver, libname, sizeof libname) == DCE_OK && rk == 0 && wd == 1 && ver > 0, "comm_info");
+        void *d_seq = NULL, *d_local = NULL, *d_all = NULL;
+        CHECK(hipMalloc(&d_seq, sizeof(float) * T * DCE_CHANNELS) == hipSuccess && hipMalloc(&d_local, N * DCE_PACKED_ROW) == hipSuccess &&
+              hipMalloc(&d_all, N * DCE_PACKED_ROW) == hipSuccess, "hipMalloc");
+        CHECK(hipMemcpy(d_seq, seq, sizeof(float) * T * DCE_CHANNELS, hipMemcpyHostToDevice) == hipSuccess, "H2D");
+        CHECK(dce_infer_sequence_packed(ctx, (const float*)d_seq, T, DCE_WINDOW, 1, (uint8_t*)d_local) == DCE_OK, "packed on device");
+        const int64_t rows[1] = {N};
+        const int64_t wrong[1] = {N - 1};
+        CHECK(dce_gather_results(ctx, (const uint8_t*)d_local, N, (uint8_t*)d_all, wrong, 0, 0) == DCE_ERR_ARG, "row-count mismatch");
+        for (int mode = 0; mode < 3; ++mode) {      /* uniform (ncclGather), explicit sizes, asynchronous */
+            CHECK(hipMemset(d_all, 0, N * DCE_PACKED_ROW) == hipSuccess, "memset");
+            CHECK(dce_gather_results(ctx, (const uint8_t*)d_local, N, (uint8_t*)d_all, mode == 1 ? rows : NULL, 0, mode == 2) == DCE_OK,
+                  "gather mode %d: %s", mode, dce_last_error(ctx));
+            CHECK(dce_comm_sync(ctx) == DCE_OK && dce_sync(ctx) == DCE_OK, "comm sync");
+            static uint8_t back[N * DCE_PACKED_ROW];
+            CHECK(hipMemcpy(back, d_all, sizeof back, hipMemcpyDeviceToHost) == hipSuccess, "D2H");
+            CHECK(memcmp(back, packed, sizeof back) == 0, "gathered rows differ (mode %d)", mode);
+        }
+        int64_t counts[256];
+        for (int k = 0; k < 256; ++k) counts[k] = k;
+        CHECK(dce_allreduce_counts(ctx, counts, 0) == DCE_OK, "allreduce: %s", dce_last_error(ctx));
+        for (int k = 0; k < 256; ++k) CHECK(counts[k] == k, "allreduce over one rank changed count %d", k);
+        CHECK(dce_comm_destroy(ctx) == DCE_OK, "comm destroy");
+        hipFree(d_seq); hipFree(d_local); hipFree(d_all);
+        printf("abi_client: RCCL %d (%s), world of 1: ncclGather / grouped send-recv / async gather / all-reduce OK\n", ver, libname);
+    }
 
     CHECK(dce_sync(ctx) == DCE_OK, "sync");
     dce_destroy(ctx);

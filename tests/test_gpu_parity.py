@@ -296,7 +296,7 @@ def test_bf16_fc_precision(models, orc):
     assert (margin[flips] < 4 * err + 1e-6).all()        # only near-ties may flip
     assert np.array_equal(b16["contacts"], ((b16["pred"][:, None] & np.array([8, 4, 2, 1])) != 0).astype(np.uint8))
     taps = m.forward_taps(m.zscore_windows(seq, 0, 8))
-    assert "feat" not in taps and taps["h2"].shape == (8, 512)
+    assert taps["feat"].dtype == np.uint16 and taps["h1"].dtype == np.uint16 and taps["h2"].shape == (8, 512)   # bf16 bit patterns
     print(f"bf16_fc vs fp32: max|dlogit| {err:.3e} (scale {scale:.2f}), argmax flips {int(flips.sum())}/{len(flips)}")
     m.close()
 
