@@ -181,8 +181,10 @@ int dce_gather_results(dce_ctx* c, const uint8_t* packed_local, int64_t n_local,
     hipStream_t cs = c->comm_stream;
     ncclComm_t comm = (ncclComm_t)c->comm;
     if (uniform) {
+        // (off the root the receive pointer is never written; a caller may pass NULL there, RCCL gets a valid pointer anyway)
         if (n_local > 0)
-            NCCL_TRY(c, r, r->Gather(packed_local, packed_all, (size_t)n_local * dce::PACKED_ROW, ncclUint8, root, comm, cs));
+            NCCL_TRY(c, r, r->Gather(packed_local, (me == root || packed_all) ? (void*)packed_all : (void*)packed_local,
+                                     (size_t)n_local * dce::PACKED_ROW, ncclUint8, root, comm, cs));
     } else {
         // ragged shards: ONE group of point-to-point transfers, each block straight into its place on the root
         NCCL_TRY(c, r, r->GroupStart());

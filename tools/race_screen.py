@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Race screen for the phased GEMMs (LDS-DMA ordered against fragment reads only by counted waits + barriers): many
 repeated runs at several batch sizes, in both precisions and both schedules, must return the bits of the tile kernels
-(DCE_GEMM=tile), also while a second stream keeps the memory system busy (uneven load shifts LDS-DMA landing times)."""
+(DCE_GEMM=tile; the switch is read per context, and dce_last_plan is recorded to prove which kernels each context ran), also while a second stream keeps the memory system busy (uneven load shifts LDS-DMA landing times)."""
 import json, os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ def child(precision, sched, sizes, reps):
     import torch
     from deep_contact_estimator_amd import contact_cnn, synth
     sd = synth.make_state_dict(1, "uniform")
-    out = {}
+    out, plans = {}, {}
     noise_src = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     noise_dst = torch.empty_like(noise_src)
     side = torch.cuda.Stream()
@@ -19,7 +19,7 @@ def child(precision, sched, sizes, reps):
         x = torch.randn((n, 150, 54), generator=torch.Generator(device="cuda").manual_seed(n), device="cuda")
         os.environ["DCE_GEMM"] = "tile"
         ref_m = contact_cnn(device=0, max_batch=n, precision=precision); ref_m.load_state_dict(sd)
-        ref = ref_m.predict(x)["logits"].clone(); ref_m.close()
+        ref = ref_m.predict(x)["logits"].clone(); ref_plan = ref_m.last_plan(); ref_m.close()
         os.environ["DCE_GEMM"] = sched
         m = contact_cnn(device=0, max_batch=n, precision=precision); m.load_state_dict(sd)
         bad = 0
@@ -31,9 +31,12 @@ def child(precision, sched, sizes, reps):
             got = m.predict(x)["logits"]
             bad += int(not torch.equal(got, ref))
         torch.cuda.synchronize()
+        plan = m.last_plan()
+        assert plan != ref_plan and not any("tile" not in k and k.startswith("fc_") and "chain" not in k for k in ref_plan if "phased" in k or "lockstep" in k), (plan, ref_plan)
         m.close()
         out[n] = bad
-    print(json.dumps({"precision": precision, "schedule": sched, "reps": reps, "mismatching_runs": out}))
+        plans[n] = {"reference": ref_plan, "screened": plan}
+    print(json.dumps({"precision": precision, "schedule": sched, "reps": reps, "mismatching_runs": out, "kernels": plans}))
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
