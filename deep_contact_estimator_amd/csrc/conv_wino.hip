@@ -617,6 +617,319 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
 }
 
 // ------------------------------------------------------------------------------------------
+// The same two-window workgroup with FOUR row tiles per wave (round 3; conv_wino_rt4_kernel).
+//
+// What limits the kernel above is not the matrix work but what a wave issues between its MFMAs: per column tile one
+// LDS quad read, four transform ops and an address op feed only 8 MFMAs, every wave of a stage recomputes the same V
+// (stage 1: twice, stage 2: four times per workgroup), and a wave that runs alone on its SIMD (its partner workgroup is
+// in a prologue / write-back) issues each of those bunches in order with its MFMAs.  Here a wave holds the same 40
+// accumulator tiles in another shape: TWO full column tiles x 4 row tiles + ONE column tile x 2 row tiles --
+//     stage 1 (64 channels = 4 row tiles, 10 column tiles):  wave w: column tiles 2w, 2w+1 (all rows) + tile 8 + (w>>1), row pair w&1
+//     stage 2 (128 channels, 5 column tiles):                wave w: row group w>>1 (64 channels); column tiles 2b, 2b+1 (b = w&1)
+//                                                             + tile 4, row pair b of the group
+// -- so a K-step is 3 bunches for 40 MFMAs instead of 5 (transform VALU and LDS reads -40 %), at the price of 16 weight
+// registers per K-step instead of 8.  Same MFMAs, same LDS layout, same per-accumulator K order: bit-identical features.
+// MEASURED (profiles/r3b_conv_experiments.txt; 4096 windows, three interleaved rounds): 440.4 us vs 424.9 us for the
+// kernel above -- SLOWER, so it is an opt-in A/B variant (DCE_CONV4=1), not the default.  The phase trace says why: its
+// MFMA phases are 2.6 % shorter (178.8k vs 183.5k cycles per workgroup) but the prologue and the four write-backs of the
+// workgroup that shares the CU grow by 13.6k cycles (28.3k vs 22.1k; 39.5k vs 32.1k): a wave's non-MFMA instructions get
+// to issue in the BREAKS of the MFMA stream of the wave it shares a SIMD with, and runs of 16 MFMAs halve the breaks.
+// Splitting a full tile's run into 8 + 8 around the transform ops (-DWINO4_SPLIT=1) gives back most of it (430.1 us) and
+// still does not beat five runs of 8.  The kernel is issue-bound: a workgroup pair's 238k cycles are its 199.7k cycles of
+// MFMAs plus ~4 cycles for each of the ~9,400 other instructions its two waves per SIMD issue.
+// Register order of a wave's four row tiles: r[0], r[1] = the row pair that also serves the half tile, r[2], r[3] = the
+// other pair of the wave's 64 channels (so the half tile needs no runtime register choice).
+// ------------------------------------------------------------------------------------------
+#ifndef WINO4_SPLIT
+#define WINO4_SPLIT 0
+#endif
+struct A16 { float4 r[4]; };            // this lane's weights for one K-step: [row tile][comp]
+
+__device__ __forceinline__ A16 load_a16(const float4* __restrict__ apH, const float4* __restrict__ apO, int s)
+{   // apH / apO: packed weights of the half-tile pair / the other pair, + 2*lane float4
+    A16 a;
+    a.r[0] = apH[s * 128]; a.r[1] = apH[s * 128 + 1];
+    a.r[2] = apO[s * 128]; a.r[3] = apO[s * 128 + 1];
+    return a;
+}
+
+struct Acc4 { f32x4 f[2][4][4]; f32x4 h[2][4]; };      // [full tile][row tile][comp], half tile [row tile of pair][comp]
+
+template <int RS>
+__device__ __forceinline__ void wino_step4(const float* __restrict__ xs, const float* __restrict__ xn,
+                                           const int (&boff)[3], const A16& a, V4& vcur, Quad& rawb, Acc4& acc)
+{
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const float* pc = nt + 2 < 3 ? xs + boff[nt + 2] : xn + boff[nt + 2 - 3];
+        const float v[4] = {vcur.a.x, vcur.b.x, vcur.b.y, vcur.a.y};
+        auto mfmas = [&](int c0, int c1) {
+#pragma unroll
+            for (int c = c0; c < c1; ++c) {
+#pragma unroll
+                for (int rt = 0; rt < (nt < 2 ? 4 : 2); ++rt) {
+                    const float4 w4 = a.r[rt];
+                    const float av = c == 0 ? w4.x : c == 1 ? w4.y : c == 2 ? w4.z : w4.w;
+                    if (nt < 2) acc.f[nt][rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[c], acc.f[nt][rt][c], 0, 0, 0);
+                    else        acc.h[rt][c]     = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v[c], acc.h[rt][c], 0, 0, 0);
+                }
+            }
+        };
+#if WINO4_SPLIT
+        // a full tile's 16 MFMAs in two runs of 8 with the bookkeeping between them: the wave that shares the SIMD
+        // (the partner workgroup's) gets to issue in the breaks of this wave's MFMA stream, and a run of 16 halves them
+        const Quad rawc = load_quad2(pc);                  // tile i+2 of the (K-step, column tile) sequence
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0, nt < 2 ? 2 : 4);
+        __builtin_amdgcn_sched_barrier(0);
+        const V4 vnxt = wino_v(rawb);                      // tile i+1
+        __builtin_amdgcn_sched_barrier(0);
+        if (nt < 2) mfmas(2, 4);
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        const Quad rawc = load_quad2(pc);                  // tile i+2 of the (K-step, column tile) sequence
+        const V4 vnxt = wino_v(rawb);                      // tile i+1
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        vcur = vnxt;
+        rawb = rawc;
+    }
+}
+
+// One layer's main loop (see wino_mfma): two K-steps per iteration, weights of step s+1 / s+2 requested at the top of
+// step s / s+1.  rowH / rowO: first output channel of the half-tile pair / of the other pair (for the bias).
+template <int RS, int STEPS>
+__device__ __forceinline__ void wino_mfma4(const float* __restrict__ xrow, const int (&boff)[3],
+                                           const float4* __restrict__ apH, const float4* __restrict__ apO, A16 a_even,
+                                           const float* __restrict__ bias_lds, int rowH, int rowO, int lane, Acc4& acc)
+{
+    static_assert(STEPS % 2 == 0 && STEPS >= 4, "two K-steps per iteration");
+    {
+        const int q4 = 4 * (lane >> 4);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            f32x4 b;
+            const int co = (rt < 2 ? rowH : rowO) + 16 * (rt & 1) + q4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[r] = bias_lds[co + r];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc.f[t][rt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.f[t][rt][1] = b;
+                acc.f[t][rt][2] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.f[t][rt][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (rt < 2) {
+                acc.h[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.h[rt][1] = b;
+                acc.h[rt][2] = f32x4{0.f, 0.f, 0.f, 0.f}; acc.h[rt][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    V4 vcur = wino_v(load_quad2(xrow + boff[0]));
+    Quad rawb = load_quad2(xrow + boff[1]);
+#pragma unroll 1
+    for (int s = 0; s < STEPS; s += 2) {
+        const int s2 = s + 2 < STEPS ? s + 2 : s;         // last iteration: harmless re-reads
+        const A16 a_odd = load_a16(apH, apO, s + 1);
+        wino_step4<RS>(xrow + s * 4 * RS, xrow + (s + 1) * 4 * RS, boff, a_even, vcur, rawb, acc);
+        a_even = load_a16(apH, apO, s2);
+        wino_step4<RS>(xrow + (s + 1) * 4 * RS, xrow + s2 * 4 * RS, boff, a_odd, vcur, rawb, acc);
+    }
+}
+
+// Visit every (column tile, row tile) of a wave's accumulators: f(m0..m3 of the 4 r, column tile index ct, first channel co)
+template <class F>
+__device__ __forceinline__ void acc4_for_each(const Acc4& acc, const int (&ct)[3], int rowH, int rowO, F&& f)
+{
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int rt = 0; rt < (t < 2 ? 4 : 2); ++rt) {
+            const int co = (rt < 2 ? rowH : rowO) + 16 * (rt & 1);
+            if (t < 2) f(acc.f[t][rt], ct[t], co); else f(acc.h[rt], ct[2], co);
+        }
+}
+
+template <bool ZS, typename FT, bool TAPS = false>
+__global__ __launch_bounds__(256, 2)
+void conv_wino_rt4_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT* __restrict__ feat,
+                          const long long* __restrict__ src_row, LayerTaps taps)
+{
+    extern __shared__ __attribute__((aligned(16))) float act[];
+    if (src_row) src += *src_row * CH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const int64_t win0 = (int64_t)blockIdx.x * NW;
+    const int nvalid = (n - win0) < NW ? (int)(n - win0) : NW;
+
+    TRACE_MARK(0);
+    for (int i = tid; i < 384; i += 256) {
+        const int l = i < 64 ? 0 : (i < 128 ? 1 : (i < 256 ? 2 : 3));
+        const int o = i < 64 ? i : (i < 128 ? i - 64 : (i < 256 ? i - 128 : i - 256));
+        act[WACT_FLOATS + i] = pk.b[l][o];
+    }
+    if (tid < NW) reinterpret_cast<int*>(act + WACT_FLOATS + 384)[tid] = 0;
+    int* nanflag = reinterpret_cast<int*>(act + WACT_FLOATS + 384);
+    {   // ---- prologue: exactly conv_wino_kernel's
+        float x[NW][38];
+        const int64_t wstride = ZS ? CH : (int64_t)WIN * CH;
+        load_windows<ZS, NW>(src + win0 * wstride, wstride, nvalid, act + WRED_ROW * RS1, x, tid);
+        bool bad0 = false, bad1 = false;
+#pragma unroll
+        for (int m = 0; m < 38; ++m) {
+            bad0 |= !(fabsf(x[0][m]) <= 3.0e38f);
+            bad1 |= !(fabsf(x[1][m]) <= 3.0e38f);
+        }
+        __syncthreads();
+        if (bad0) nanflag[0] = 1;
+        if (bad1) nanflag[1] = 1;
+        if (tid < 4 * CH) {
+            const int c = tid % CH, g = tid / CH;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int m = 0; m < 38; ++m) {
+                    const int t = 4 * m + g;
+                    if (t < WIN) act[c * RS1 + w * WS1 + 1 + t] = x[w][m];
+                }
+        }
+        for (int i = tid; i < 64 * 4; i += 256) {
+            const int c = i >> 2, k = i & 3;
+            act[c * RS1 + (k >> 1) * WS1 + (k & 1) * (WS1 - 1)] = 0.f;
+        }
+        for (int i = tid; i < 2 * RS1; i += 256) act[CH * RS1 + i] = 0.f;
+    }
+    __syncthreads();
+    TRACE_MARK(1);
+    const bool nan0 = __builtin_amdgcn_readfirstlane(nanflag[0]) != 0;
+    const bool nan1 = __builtin_amdgcn_readfirstlane(nanflag[1]) != 0;
+
+    Acc4 acc;
+    int boff[3];
+    const float* bias_lds = act + WACT_FLOATS;
+    const float* xrow1 = act + q * RS1;
+    const float* xrow2 = act + q * RS2;
+    // column n of a stage -> (window, pair), LDS offset of the pair (fillers past the last pair read offset 0)
+    auto col1 = [&](int ct, int& w, int& m) { const int nn = 16 * ct + j; w = nn >= TP1 ? 1 : 0; m = nn - w * TP1; return nn < NW * TP1; };
+    auto col2 = [&](int ct, int& w, int& m) { const int nn = 16 * ct + j; w = nn >= TP2 ? 1 : 0; m = nn - w * TP2; return nn < NW * TP2; };
+
+    // ---- stage 1: wave w = column tiles 2w, 2w+1 (64 channels) + tile 8 + (w>>1), channel pair w&1
+    {
+        const int ct[3] = {2 * wv, 2 * wv + 1, 8 + (wv >> 1)};
+        const int pH = wv & 1, rowH = 32 * pH, rowO = 32 * (pH ^ 1);
+        const float4* ap1H = reinterpret_cast<const float4*>(pk.ww[0]) + pH * (14 * 128) + 2 * lane;
+        const float4* ap1O = reinterpret_cast<const float4*>(pk.ww[0]) + (pH ^ 1) * (14 * 128) + 2 * lane;
+        const float4* ap2H = reinterpret_cast<const float4*>(pk.ww[1]) + pH * (16 * 128) + 2 * lane;
+        const float4* ap2O = reinterpret_cast<const float4*>(pk.ww[1]) + (pH ^ 1) * (16 * 128) + 2 * lane;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { int w, m; boff[t] = col1(ct[t], w, m) ? w * WS1 + 2 * m : 0; }
+        A16 a = load_a16(ap1H, ap1O, 0);
+        wino_mfma4<RS1, 14>(xrow1, boff, ap1H, ap1O, a, bias_lds, rowH, rowO, lane, acc);
+        TRACE_MARK(2);
+        a = load_a16(ap2H, ap2O, 0);
+        __syncthreads();
+        acc4_for_each(acc, ct, rowH, rowO, [&](const f32x4 (&m4)[4], int c_t, int co) {
+            int w, m;
+            if (!col1(c_t, w, m)) return;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* d = act + (co + 4 * q + r) * RS1 + w * WS1 + 1 + 2 * m;
+                d[0] = fmaxf((m4[0][r] + m4[1][r]) + m4[2][r], 0.f);
+                d[1] = fmaxf((m4[1][r] - m4[2][r]) - m4[3][r], 0.f);
+                if constexpr (TAPS) {
+                    float* tp = taps.conv1 + ((win0 + w) * 64 + co + 4 * q + r) * 150 + 2 * m;
+                    tp[0] = d[0]; tp[1] = d[1];
+                }
+            }
+        });
+        __syncthreads();
+        TRACE_MARK(3);
+        wino_mfma4<RS1, 16>(xrow1, boff, ap2H, ap2O, a, bias_lds + 64, rowH, rowO, lane, acc);
+        TRACE_MARK(4);
+    }
+    // ---- stage 2: wave w = channel group w>>1 (64 of 128); column tiles 2b, 2b+1 + tile 4 with channel pair b (b = w&1)
+    {
+        const int g = wv >> 1, b = wv & 1;
+        const int ct2[3] = {2 * b, 2 * b + 1, 4};
+        const int rowH = 64 * g + 32 * b, rowO = 64 * g + 32 * (b ^ 1);
+        const float4* ap3H = reinterpret_cast<const float4*>(pk.ww[2]) + (2 * g + b) * (16 * 128) + 2 * lane;
+        const float4* ap3O = reinterpret_cast<const float4*>(pk.ww[2]) + (2 * g + (b ^ 1)) * (16 * 128) + 2 * lane;
+        const float4* ap4H = reinterpret_cast<const float4*>(pk.ww[3]) + (2 * g + b) * (32 * 128) + 2 * lane;
+        const float4* ap4O = reinterpret_cast<const float4*>(pk.ww[3]) + (2 * g + (b ^ 1)) * (32 * 128) + 2 * lane;
+        A16 a = load_a16(ap3H, ap3O, 0);
+        __syncthreads();                                  // every wave is done reading conv2's input
+        {   // conv2's write-back with the stage-1 tiling: ReLU + MaxPool -> stage-2 layout
+            const int ct[3] = {2 * wv, 2 * wv + 1, 8 + (wv >> 1)};
+            const int pH = wv & 1, rH = 32 * pH, rO = 32 * (pH ^ 1);
+            acc4_for_each(acc, ct, rH, rO, [&](const f32x4 (&m4)[4], int c_t, int co) {
+                int w, m;
+                if (!col1(c_t, w, m)) return;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y0 = (m4[0][r] + m4[1][r]) + m4[2][r], y1 = (m4[1][r] - m4[2][r]) - m4[3][r];
+                    act[(co + 4 * q + r) * RS2 + w * WS2 + 1 + m] = fmaxf(fmaxf(y0, y1), 0.f);
+                    if constexpr (TAPS) {
+                        const int64_t row = (win0 + w) * 64 + co + 4 * q + r;
+                        taps.conv2[row * 150 + 2 * m] = fmaxf(y0, 0.f);
+                        taps.conv2[row * 150 + 2 * m + 1] = fmaxf(y1, 0.f);
+                        taps.pool1[row * 75 + m] = fmaxf(fmaxf(y0, y1), 0.f);
+                    }
+                }
+            });
+        }
+        for (int i = tid; i < 128 * 6; i += 256) {       // stage-2 pads: index 0, 76, 77 of each window segment
+            const int c = i / 6, k = i % 6;
+            act[c * RS2 + (k / 3) * WS2 + (k % 3 == 0 ? 0 : 75 + k % 3)] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { int w, m; boff[t] = col2(ct2[t], w, m) ? w * WS2 + 2 * m : 0; }
+        __syncthreads();
+        TRACE_MARK(5);
+        wino_mfma4<RS2, 16>(xrow2, boff, ap3H, ap3O, a, bias_lds + 128, rowH, rowO, lane, acc);
+        TRACE_MARK(6);
+        a = load_a16(ap4H, ap4O, 0);
+        __syncthreads();
+        acc4_for_each(acc, ct2, rowH, rowO, [&](const f32x4 (&m4)[4], int c_t, int co) {
+            int w, m;
+            if (!col2(c_t, w, m)) return;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* d = act + (co + 4 * q + r) * RS2 + w * WS2 + 1 + 2 * m;
+                d[0] = fmaxf((m4[0][r] + m4[1][r]) + m4[2][r], 0.f);
+                d[1] = 2 * m + 1 < 75 ? fmaxf((m4[1][r] - m4[2][r]) - m4[3][r], 0.f) : 0.f;     // index 76 is a zero pad
+                if constexpr (TAPS) {
+                    float* tp = taps.conv3 + ((win0 + w) * 128 + co + 4 * q + r) * 75 + 2 * m;
+                    tp[0] = d[0];
+                    if (2 * m + 1 < 75) tp[1] = d[1];
+                }
+            }
+        });
+        __syncthreads();
+        TRACE_MARK(7);
+        wino_mfma4<RS2, 32>(xrow2, boff, ap4H, ap4O, a, bias_lds + 256, rowH, rowO, lane, acc);
+        TRACE_MARK(8);
+        const float nanv = __builtin_nanf("");
+        acc4_for_each(acc, ct2, rowH, rowO, [&](const f32x4 (&m4)[4], int c_t, int co) {
+            int w, m;
+            if (!col2(c_t, w, m) || w >= nvalid) return;
+            const bool bad = w ? nan1 : nan0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y0 = (m4[0][r] + m4[1][r]) + m4[2][r], y1 = (m4[1][r] - m4[2][r]) - m4[3][r];
+                if constexpr (TAPS) {
+                    float* tp = taps.conv4 + ((win0 + w) * 128 + co + 4 * q + r) * 75 + 2 * m;
+                    tp[0] = fmaxf(y0, 0.f);
+                    if (2 * m + 1 < 75) tp[1] = fmaxf(y1, 0.f);
+                }
+                if (m < 37) put_feat(feat + (win0 + w) * FEAT + (co + 4 * q + r) * 37 + m, bad ? nanv : fmaxf(fmaxf(y0, y1), 0.f));
+            }
+        });
+        TRACE_MARK(9);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // One window per workgroup: the latency variant for a handful of windows (online mode, the
 // reference's batch_size 1).  Same layers, same LDS layout (window segment 0 only), same per-
 // accumulator K order -> the features are bit-identical to conv_wino_kernel's; only the tiling
@@ -1080,6 +1393,10 @@ hipError_t init_conv_wino()
                           reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 2, 3, 2, true>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 4, 2, 1, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     // the TAPS instantiations (dce_conv_layer_taps: parity tests of the layers inside the fused stack)
+    for (const void* k : {reinterpret_cast<const void*>(&conv_wino_rt4_kernel<true, float>), reinterpret_cast<const void*>(&conv_wino_rt4_kernel<false, float>),
+                          reinterpret_cast<const void*>(&conv_wino_rt4_kernel<true, unsigned short>), reinterpret_cast<const void*>(&conv_wino_rt4_kernel<false, unsigned short>),
+                          reinterpret_cast<const void*>(&conv_wino_rt4_kernel<false, float, true>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, DCE_TRACE ? 100 * 1024 : WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     for (const void* k : {reinterpret_cast<const void*>(&conv_wino_kernel<false, float, true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false, true>),
                           reinterpret_cast<const void*>(&conv_wino1x8_kernel<false, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
@@ -1100,6 +1417,7 @@ hipError_t launch_conv_wino_taps(int kernel, const float* src, int64_t n, const 
     case 1: hipLaunchKernelGGL((conv_wino1x8_kernel<false, true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, none, taps); break;
     case 2: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2, true>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, none, taps); break;
     case 3: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1, true>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, none, taps); break;
+    case 6: hipLaunchKernelGGL((conv_wino_rt4_kernel<false, float, true>), dim3((unsigned)((n + NW - 1) / NW)), dim3(256), lds, st, src, n, pk, f, none, taps); break;
     case 5: hipLaunchKernelGGL((conv_wino1_kernel<false, true>), dim3((unsigned)n), dim3(256), lds, st, src, n, pk, f, none, taps); break;
     default: return hipErrorInvalidValue;
     }
@@ -1157,6 +1475,19 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
         plan_note("conv_wino1x4");
         if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
         else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+        return hipGetLastError();
+    }
+    if (tu.conv4 > 0) {           // DCE_CONV4=1: four row tiles per wave (A/B; measured 3.8 % SLOWER end to end, see the kernel's header)
+        plan_note("conv_wino2_rt4");
+        if (feat_bf16) {
+            unsigned short* f = static_cast<unsigned short*>(feat);
+            if (zscore) hipLaunchKernelGGL((conv_wino_rt4_kernel<true, unsigned short>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+            else        hipLaunchKernelGGL((conv_wino_rt4_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+        } else {
+            float* f = static_cast<float*>(feat);
+            if (zscore) hipLaunchKernelGGL((conv_wino_rt4_kernel<true, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+            else        hipLaunchKernelGGL((conv_wino_rt4_kernel<false, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+        }
         return hipGetLastError();
     }
     plan_note("conv_wino2");

@@ -61,7 +61,7 @@ Tuning tuning_from_env()
     t.wino1_w8 = num("DCE_WINO1_WAVES", 8) != 4;
     t.one_per_cu = getenv("DCE_ONE_PER_CU") != nullptr;
     t.trace_wino1 = getenv("DCE_TRACE_WINO1") != nullptr;
-    t.conv4 = (int)num("DCE_CONV4", -1);
+    t.conv4 = (int)num("DCE_CONV4", 0);
     return t;
 }
 

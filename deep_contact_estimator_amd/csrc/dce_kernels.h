@@ -26,7 +26,7 @@ struct Tuning {
     long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // DCE_WINO1_MAX / DCE_WINOH_MAX / DCE_WINOQ_MAX (-1: kernel default)
     bool wino1_w8 = true;                                   // DCE_WINO1_WAVES=4 -> false
     bool one_per_cu = false, trace_wino1 = false;           // DCE_ONE_PER_CU, DCE_TRACE_WINO1 (trace builds)
-    int conv4 = -1;                                         // DCE_CONV4: four-window conv workgroup on/off (-1: default)
+    int conv4 = 0;                                          // DCE_CONV4=1: four row tiles per wave in the two-window conv kernel (A/B; slower)
 };
 Tuning tuning_from_env();
 extern thread_local const Tuning* t_tuning;                  // the calling ctx's switches (nullptr: process defaults)
@@ -72,7 +72,7 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
 // their LDS / feature stores; the product instantiations carry no trace of it.
 struct LayerTaps { float *conv1, *conv2, *pool1, *conv3, *conv4; };
 // kernel: 0 two-window Winograd, 1 one-window x 8 waves, 2 half-window segments, 3 quarter-window segments,
-//         4 direct form, 5 one-window x 4 waves, 6 four-window Winograd (8 waves)
+//         4 direct form, 5 one-window x 4 waves, 6 two-window Winograd with four row tiles per wave (DCE_CONV4=1)
 hipError_t launch_conv_taps(int kernel, const float* windows, int64_t n, const ConvPack& pk, float* feat,
                             const LayerTaps& taps, hipStream_t st);
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = ["seq_normal", "seq_ar1"]
 # kernel family -> how many windows the test feeds it (the two-window families get two workgroups' worth)
-CONV_KERNELS = {"wino2": 4, "wino1x8": 3, "half": 3, "quarter": 3, "direct": 4, "wino1x4": 2}
+CONV_KERNELS = {"wino2rt4": 4, "wino2": 4, "wino1x8": 3, "half": 3, "quarter": 3, "direct": 4, "wino1x4": 2}
 LAYERS = ("conv1", "conv2", "pool1", "conv3", "conv4")
 
 
@@ -83,7 +83,7 @@ def test_conv_layer_taps_bit_identical_across_winograd_families(golden, model_of
     m = model_of(int(g["wseed"]), str(g["bias"]))
     x = g["zwin"][:3]
     base = m.conv_layer_taps(x, "wino2")
-    for kernel in ("wino1x8", "wino1x4", "half", "quarter"):
+    for kernel in ("wino2rt4", "wino1x8", "wino1x4", "half", "quarter"):
         t = m.conv_layer_taps(x, kernel)
         for k in LAYERS + ("feat",):
             a, b = base[k], t[k]
@@ -97,7 +97,7 @@ def test_tapped_kernels_produce_the_product_features(model_of):
     m = model_of()
     x = np.random.default_rng(3).standard_normal((5, 150, 54), dtype=np.float32)
     feat = m.forward_taps(x)["feat"]
-    for kernel in ("wino2", "wino1x8", "half", "quarter", "wino1x4"):
+    for kernel in ("wino2rt4", "wino2", "wino1x8", "half", "quarter", "wino1x4"):
         assert np.array_equal(m.conv_layer_taps(x, kernel)["feat"], feat), kernel
 
 
@@ -240,12 +240,40 @@ def test_ab_switches_are_per_context(monkeypatch):
     assert plans["phased"][1] == "fc_phased256x128" and plans["phased"][2] == "fc23_fused_phased128x64", plans["phased"]
     assert plans["tile"][1] == "fc_tile128" and "phased" not in " ".join(plans["tile"]), plans["tile"]
     assert plans["lockstep"][1] == "fc_lockstep256x128" and plans["lockstep"][2] == "fc23_fused_lockstep128x64", plans["lockstep"]
-    assert plans["direct"][0] == "conv_direct" and plans["phased"][0].startswith("conv_wino"), (plans["direct"], plans["phased"])
+    assert plans["direct"][0] == "conv_direct" and plans["phased"][0] == "conv_wino2", (plans["direct"], plans["phased"])
     for k in ("tile", "lockstep"):
         assert np.array_equal(outs[k]["logits"], outs["phased"]["logits"]), k
     tol_ok(outs["direct"]["logits"], outs["phased"]["logits"], "direct-form vs Winograd conv stack")
     for m in made.values():
         m.close()
+
+
+def test_conv_rt4_equals_its_predecessor_bitwise(monkeypatch):
+    """The two-window conv workgroup with four row tiles per wave (DCE_CONV4=1, an A/B variant) against the shipped
+    two-row-tile kernel: same MFMAs per accumulator in the same K order -> the same feature bits, for pre-normalised windows
+    and the z-score-fused sequence path, fp32 and bf16 features, odd window counts, NaN containment, repeated runs."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    sd = synth.make_state_dict(1, "uniform")
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2049, 150, 54), dtype=np.float32)
+    x[7, 3, 5] = np.nan; x[1000, 100, 0] = np.inf
+    seq = rng.standard_normal((1500 + 149, 54)).astype(np.float32) * 3 + 1
+    for precision in ("fp32", "bf16_fc"):
+        old = contact_cnn(device=0, max_batch=4096, precision=precision); old.load_state_dict(sd)
+        ref_t = old.forward_taps(x); assert old.last_plan()[0] == "conv_wino2"
+        ref_s = old.infer_sequence(seq)
+        monkeypatch.setenv("DCE_CONV4", "1")
+        new = contact_cnn(device=0, max_batch=4096, precision=precision); new.load_state_dict(sd)
+        for rep in range(3):
+            t = new.forward_taps(x); assert new.last_plan()[0] == "conv_wino2_rt4"
+            for k in ("feat", "logits"):
+                assert np.array_equal(t[k].view(np.uint32 if t[k].dtype == np.float32 else np.uint16),
+                                      ref_t[k].view(np.uint32 if t[k].dtype == np.float32 else np.uint16)), (precision, k, rep)
+            s2 = new.infer_sequence(seq)
+            assert np.array_equal(s2["logits"], ref_s["logits"]) and np.array_equal(s2["pred"], ref_s["pred"])
+        assert np.isnan(t["logits"][7]).all() and np.isnan(t["logits"][1000]).all() and np.isfinite(t["logits"][8]).all()
+        monkeypatch.delenv("DCE_CONV4")
+        old.close(); new.close()
 
 
 def test_plan_by_batch_size(model_of):
@@ -261,7 +289,7 @@ def test_plan_by_batch_size(model_of):
         assert m.last_plan() == plan, (n, m.last_plan())
     m.predict(rng.standard_normal((4096, 150, 54), dtype=np.float32))
     p = m.last_plan()
-    assert p[0] in ("conv_wino2", "conv_wino4") and p[1:] == ["fc_phased256x128", "fc23_fused_phased128x64", "fc6_combine"], p
+    assert p[0] == "conv_wino2" and p[1:] == ["fc_phased256x128", "fc23_fused_phased128x64", "fc6_combine"], p
 
 
 def test_inference_and_compute_acc_reference_broadcast(golden, case_inputs, model_of, tmp_path):
