@@ -145,11 +145,11 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
             // past a round gives that remainder to the chain kernel + tail (same bits, rows are independent) instead
             // of paying a full round for it.
             const bool peel = c->tuning.gemm_peel;
-            const int64_t rest = n % 4096, nf = (peel && n > 4096 && rest && (rest <= 8 || fc_gemm_chain_ok(rest, FC2, FC1))) ? n - rest : n;
+            const int64_t rest = n % 4096, nf = (peel && n > 4096 && rest && (rest <= FC_GEMV_MAX_M || fc_gemm_chain_ok(rest, FC2, FC1))) ? n - rest : n;
             { Timer t(c, 2);
               HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch,
                                            c->want_h2 ? c->h2 : nullptr, nf, c->stream));
-              if (nf < n) HIP_TRY(c, (n - nf <= 8 ? launch_fc_gemv : launch_fc_gemm)(c->h1 + nf * FC1, c->fc2w, c->fc2b, c->h2 + nf * FC2, n - nf, FC2, FC1, 1, c->stream)); }
+              if (nf < n) HIP_TRY(c, (n - nf <= FC_GEMV_MAX_M ? launch_fc_gemv : launch_fc_gemm)(c->h1 + nf * FC1, c->fc2w, c->fc2b, c->h2 + nf * FC2, n - nf, FC2, FC1, 1, c->stream)); }
             { Timer t(c, 3);
               HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, c->stream, packed));
               if (nf < n) HIP_TRY(c, launch_fc3_tail(c->h2 + nf * FC2, c->fc3w, c->fc3b, n - nf, logits ? logits + nf * NCLS : nullptr,

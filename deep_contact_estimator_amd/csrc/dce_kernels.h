@@ -22,7 +22,7 @@ struct Tuning {
     int fc23_mode = 0;                                      // DCE_FC23=split (1) | always (2)
     bool gemm_peel = true, conv_peel = true;                // DCE_GEMM_PEEL=0, DCE_CONV_PEEL=0
     bool gemm_small_deep = true;                            // DCE_GEMM_SMALL=0
-    long long chain_min = 9, chain_max = 640, chain_max3 = 2048, chain_bn16_max = 64;   // DCE_CHAIN_*
+    long long chain_min = 33, chain_max = 640, chain_max3 = 2048, chain_bn16_max = 64;   // DCE_CHAIN_*
     long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // DCE_WINO1_MAX / DCE_WINOH_MAX / DCE_WINOQ_MAX (-1: kernel default)
     bool wino1_w8 = true;                                   // DCE_WINO1_WAVES=4 -> false
     bool one_per_cu = false, trace_wino1 = false;           // DCE_ONE_PER_CU, DCE_TRACE_WINO1 (trace builds)
@@ -98,6 +98,7 @@ hipError_t launch_fc_gemm(const float* A, const float* W, const float* bias, flo
 // faster): weight-streaming GEMV on all CUs,
 // bit-identical to launch_fc_gemm (same K order).  N % 8 == 0, K % 128 == 0.
 constexpr int FC_GEMV_MAX_M = 32;
+hipError_t init_fc_gemv();
 hipError_t launch_fc_gemv(const float* A, const float* W, const float* bias, float* C,
                           int64_t M, int N, int K, int relu, hipStream_t st);
 

@@ -22,6 +22,7 @@
 //    epilogue (fc_gemm_phased.hip) and fc6_combine_kernel adds them up.
 #include "dce_kernels.h"
 #include "fc6_chain.h"
+#include "fc_tree.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -115,6 +116,28 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // fp32: the fixed summation tree of fc_tree.h -- `tot` collects the finished K ranges, acc the running one
+    f32x16 tot[BF16 ? 1 : TM][BF16 ? 1 : TN];
+    if constexpr (!BF16) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[a][b][r] = 0.f;
+    }
+    auto fold = [&]() {
+        if constexpr (!BF16) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { tot[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
+        }
+    };
+    const FcTree tree = fc_tree(BF16 ? 1 : K, KT_BYTES / 4);
+
     static_assert(SA == SB && (SA == 4 || SA == 2 || SA == 1), "staging registers are named: 1, 2 or 4 per operand");
     {   // first K-tile: plain loads
         float4 t[SA + SB];
@@ -205,6 +228,7 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     // LDS bandwidth, 128 B/clk/CU at one ds_read_b128 per MFMA, not by load latency.)
     for (int kt = 0; kt < KT; ++kt) {
         DCE_ISSUE(r, kt + 1)
+        if (!BF16 && fc_tree_cut(tree, kt)) fold();           // a new K range starts with this tile
         compute(kt & 1);
         DCE_WAIT_WRITE(r, (kt & 1) ^ 1, 0, 0, 0)
         __syncthreads();
@@ -223,7 +247,7 @@ void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = acc[a][b][r] + bv;
+                float v = (BF16 ? acc[a][b][r] : tot[a][b][r] + acc[a][b][r]) + bv;
                 if (relu) v = relu_nan(v);
                 if (row < M) {
                     if constexpr (OUT_BF16) static_cast<unsigned short*>(Cv)[(size_t)row * N + col] = f32_to_bf16_rne(v);
@@ -283,10 +307,11 @@ void fc_gemm_small_kernel(const float* __restrict__ Af, const float* __restrict_
     const char* bg1 = W + (size_t)(n0 + srow + RPP) * rowb + 16 * sk4;
     const int sdst = srow * LDR + 16 * sk4;
 
-    f32x16 acc;
+    f32x16 acc, tot;                                     // running K range / finished ranges (fc_tree.h)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; tot[r] = 0.f; }
     const int KT = (int)(rowb / KT_BYTES);               // a multiple of GS_DEPTH (checked by the launcher)
+    const FcTree tree = fc_tree(K, KT_BYTES / 4);
 
     *reinterpret_cast<float4*>(As + sdst) = *reinterpret_cast<const float4*>(ag0);
     *reinterpret_cast<float4*>(As + sdst + RPP * LDR) = *reinterpret_cast<const float4*>(ag1);
@@ -327,6 +352,7 @@ void fc_gemm_small_kernel(const float* __restrict__ Af, const float* __restrict_
     // hand tile kt+1 (the oldest of the four in flight: 12 younger loads may stay outstanding) to LDS
 #define GS_STEP(SFREE, SNEXT, kt)                                                                 \
     { GS_LOAD(SFREE, (kt) + GS_DEPTH)                                                             \
+      if (fc_tree_cut(tree, (kt))) { _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) { tot[r_] += acc[r_]; acc[r_] = 0.f; } } \
       compute((kt) & 1);                                                                          \
       asm volatile("s_waitcnt vmcnt(12)" : "+v"(q##SNEXT##a0), "+v"(q##SNEXT##a1), "+v"(q##SNEXT##b0), "+v"(q##SNEXT##b1)); \
       char* ad = As + (((kt) + 1) & 1) * Cfg::A_BYTES + sdst;                                     \
@@ -350,7 +376,7 @@ void fc_gemm_small_kernel(const float* __restrict__ Af, const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v = acc[r] + bv;
+        float v = (tot[r] + acc[r]) + bv;
         if (relu) v = relu_nan(v);
         if (row < M) C[(size_t)row * N + col] = v;
     }
@@ -384,6 +410,7 @@ hipError_t init_fc_gemm()
     if ((e = grant_lds<1, 1, true, true>()) != hipSuccess) return e;
     if ((e = init_fc_gemm_phased()) != hipSuccess) return e;
     if ((e = init_fc_gemm_chain()) != hipSuccess) return e;
+    if ((e = init_fc_gemv()) != hipSuccess) return e;
     return grant_lds<1, 1, true, false>();
 }
 
@@ -436,7 +463,7 @@ static hipError_t launch_fc_gemm_one(const float* A, const float* W, const float
                                      int64_t M, int N, int K, int relu, hipStream_t st, bool remainder)
 {
     // a handful of rows as the remainder of a cut: the weight-streaming GEMV
-    if (remainder && M <= 8 && N % 8 == 0 && K % 128 == 0) return launch_fc_gemv(A, W, bias, C, M, N, K, relu, st);
+    if (remainder && M <= FC_GEMV_MAX_M && N % 8 == 0 && K % 128 == 0) return launch_fc_gemv(A, W, bias, C, M, N, K, relu, st);
     // a few dozen to a few hundred windows: chain-latency kernel, one 16x16 tile per wave (fc_gemm_chain.hip)
     if (fc_gemm_chain_ok(M, N, K)) return launch_fc_gemm_chain(A, W, bias, C, M, N, K, relu, st);
     // chip-filling sizes: one phased workgroup per CU (fc_gemm_phased.hip); same K order, same bits

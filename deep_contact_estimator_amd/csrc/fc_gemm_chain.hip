@@ -25,6 +25,7 @@
 // 512-byte LDS row are XOR-swizzled with the row number, so that the ds_read_b64 of 16 rows x one slot is conflict-free.
 // Results are bit-identical to the GEMV / tile / phased kernels (tests/test_gpu_parity.py).
 #include "dce_kernels.h"
+#include "fc_tree.h"
 #include <cstdlib>
 
 namespace dce {
@@ -135,7 +136,9 @@ void fc_gemm_chain_kernel(const float* __restrict__ A, const float* __restrict__
         fa[set][s] = *reinterpret_cast<const ch_f32x2*>(b + a_off[s]);
         fb[set][s] = *reinterpret_cast<const ch_f32x2*>(b + b_off[s]);
     };
-    ch_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    ch_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, tot = {0.f, 0.f, 0.f, 0.f};     // running K range / finished ranges (fc_tree.h)
+    constexpr int cut1 = (K / 128) * 1 / 4, cut2 = (K / 128) * 2 / 4, cut3 = (K / 128) * 3 / 4;   // first chunk of ranges 1..3
+    static_assert(CH_K == 128, "the tree's ranges are whole chunks");
     auto mfma2 = [&](int set, int s) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][s].x, fb[set][s].x, acc, 0, 0, 0);    // k = 0,4,1,5
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][s].y, fb[set][s].y, acc, 0, 0, 0);    // k = 2,6,3,7
@@ -165,6 +168,12 @@ void fc_gemm_chain_kernel(const float* __restrict__ A, const float* __restrict__
         const char* pa_ = reinterpret_cast<const char*>(A) + o_;                                      \
         const char* pw_ = reinterpret_cast<const char*>(W) + o_;                                      \
         ch_wait_oldest(NEXT); CH_SB;                                                                  \
+        /* a new K range of the summation tree starts with chunk c: written as selects on a wave-uniform condition -- a   \
+           branch here makes hipcc rotate the loop (body ahead of its header), which the linear asm-load guard of          \
+           tests/test_abi.py cannot follow */                                                                              \
+        { const bool cut_ = ((c) == cut1) | ((c) == cut2) | ((c) == cut3);                                                 \
+          const ch_f32x4 s_ = tot + acc;                                                                                   \
+          _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { tot[e_] = cut_ ? s_[e_] : tot[e_]; acc[e_] = cut_ ? 0.f : acc[e_]; } } \
         CH_A(c, NEXT, 0, 0, 0) CH_SB;                                                                 \
         CH_A(c, NEXT, 1, 0, 1) CH_LD(NEXT.x[0], voffA0, pa_, 0); CH_LD(NEXT.y[0], voffA0, pa_, 16); CH_SB; \
         CH_A(c, NEXT, 2, 1, 0) CH_SB;                                                                 \
@@ -200,7 +209,7 @@ void fc_gemm_chain_kernel(const float* __restrict__ A, const float* __restrict__
     for (int r = 0; r < 4; ++r) {
         const int m = m0 + 16 * wm + 4 * g + r;
         if (m < M) {
-            float v = acc[r] + bv;
+            float v = (tot[r] + acc[r]) + bv;
             if (relu) v = v < 0.f ? 0.f : v;                   // NaN stays NaN, as in fc_gemm.hip
             C[(size_t)m * N + n] = v;
         }

@@ -26,6 +26,7 @@
 // same XOR and are conflict-free for ds_read_b128's 16-lane groups.
 #include "dce_kernels.h"
 #include "fc6_chain.h"
+#include "fc_tree.h"
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -191,6 +192,29 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // fp32: the fixed summation tree of fc_tree.h -- `tot` collects the finished K ranges, acc the running one; a cut
+    // costs a wave TM*TN*16 adds + moves ahead of one tile's MFMAs, three times per tile of C
+    f32x16 tot[BF16 ? 1 : TM][BF16 ? 1 : TN];
+    if constexpr (!BF16) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[a][b][r] = 0.f;
+    }
+    auto fold = [&]() {
+        if constexpr (!BF16) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { tot[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
+        }
+    };
+    const FcTree tree = fc_tree(BF16 ? 1 : K, ROWB / 4);
+
     float4 bw6[4];                                       // FUSE6: this lane's W3 operands of the block's chunk (= column tile tn)
     if constexpr (FUSE6) fc6_load_w3(W3, tn, lane, bw6);
 
@@ -269,6 +293,7 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
             }
             if (t + 1 < KT) { const int nb = (t + 1) % 3; if (nb == 0) load_frags(0, afN, bfN); else if (nb == 1) load_frags(1, afN, bfN); else load_frags(2, afN, bfN); }
             __builtin_amdgcn_sched_barrier(0);           // the LDS reads go out ahead of the MFMAs, not behind them
+            if (!BF16 && fc_tree_cut(tree, t)) fold();
             math(afC, bfC);
             phase_end<NG>(more);
         };
@@ -311,6 +336,7 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
         phase_end<NG>(more);
         // ---- math phase
         PH_MARK(2);
+        if (!BF16 && fc_tree_cut(tree, t)) fold();       // a new K range starts with this tile
         math(af, bf);
         PH_MARK(3);
         phase_end<NG>(more);
@@ -333,7 +359,7 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row_l = wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float v = acc[0][0][r] + bv;
+            float v = (BF16 ? acc[0][0][r] : tot[0][0][r] + acc[0][0][r]) + bv;
             v = v < 0.f ? 0.f : v;                       // fc.3's ReLU; keeps NaN like torch
             ht[row_l * HLD + col_l] = v;
             if (C && m0 + row_l < M) C[(size_t)(m0 + row_l) * N + n0 + col_l] = v;
@@ -359,7 +385,7 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float v = acc[a][b][r] + bv;
+                    float v = (BF16 ? acc[a][b][r] : tot[a][b][r] + acc[a][b][r]) + bv;
                     if (relu) v = v < 0.f ? 0.f : v;              // keeps NaN like torch
                     if (decltype(full)::value || row < M) {
                         if constexpr (OUT_BF16) static_cast<unsigned short*>(Cv)[(size_t)row * N + col] = f32_to_bf16(v);

@@ -33,6 +33,7 @@ int     oracle_forward_windows(const oracle_weights* W, const float* windows, in
 float   oracle_bf16_round(float x);
 void    oracle_bf16_round_array(const float* in, int64_t n, float* out);
 int     oracle_linear_rows(const float* x, int64_t rows, int in, const float* w, const float* b, int out, int relu, float* y);
+int     oracle_linear_rows_tree(const float* x, int64_t rows, int in, const float* w, const float* b, int out, int relu, float* y);
 int     oracle_forward_windows_bf16fc(const oracle_weights* W, const float* windows, int64_t n,
                                       float* feat, float* h1, float* h2,
                                       float* logits, int32_t* pred, uint8_t* contacts);

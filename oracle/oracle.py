@@ -174,6 +174,19 @@ def linear_rows(x, w, b, relu: bool):
     return y
 
 
+def linear_rows_tree(x, w, b, relu: bool):
+    """Bit-level model of libdce.so's fp32 Linear layers (oracle_linear_rows_tree): 4 K ranges, fmaf chains in the
+    matrix pipe's K order, fixed combine -- what every fp32 FC kernel must return bit for bit on the same inputs."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    y = np.empty((x.shape[0], w.shape[0]), np.float32)
+    rc = lib().oracle_linear_rows_tree(_p(x), C.c_int64(x.shape[0]), C.c_int(x.shape[1]), _p(w), _p(b), C.c_int(w.shape[0]),
+                                       C.c_int(int(relu)), _p(y))
+    assert rc == 0
+    return y
+
+
 def zscore_windows(seq):
     """(T,54) raw -> (T-149,150,54) z-scored windows (utils/data_handler.py:55-56)."""
     s = np.ascontiguousarray(seq, dtype=np.float32)

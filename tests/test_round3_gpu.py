@@ -280,7 +280,8 @@ def test_plan_by_batch_size(model_of):
     """The kernel families the dispatch picks at the batch sizes the other tests rely on."""
     m = model_of()
     want = {1: ["conv_wino_quarter", "fc_gemv", "fc_gemv", "fc3_tail"],
-            30: ["conv_wino_quarter", "fc_chain32x16", "fc_chain32x16", "fc3_tail"],
+            30: ["conv_wino_quarter", "fc_gemv", "fc_gemv", "fc3_tail"],
+            40: ["conv_wino_quarter", "fc_chain32x16", "fc_chain32x16", "fc3_tail"],
             100: ["conv_wino_half", "fc_chain32x32", "fc_chain32x32", "fc3_tail"],
             200: ["conv_wino1x8", "fc_chain32x32", "fc_chain32x32", "fc3_tail"]}
     rng = np.random.default_rng(2)
@@ -290,6 +291,26 @@ def test_plan_by_batch_size(model_of):
     m.predict(rng.standard_normal((4096, 150, 54), dtype=np.float32))
     p = m.last_plan()
     assert p[0] == "conv_wino2" and p[1:] == ["fc_phased256x128", "fc23_fused_phased128x64", "fc6_combine"], p
+
+
+@pytest.mark.parametrize("n", [1, 8, 9, 16, 17, 30, 33, 64, 65, 200, 641, 700, 1030, 3000, 4096, 4100])
+def test_fc_layers_bit_exact_against_the_summation_tree(n, model_of, orc):
+    """Every fp32 FC kernel family -- GEMV (<= 32 windows), MFMA chain, 64x64 / 128x128 tiles, phased 128x64 / 256x128,
+    the fused fc.3 + fc.6-chunk epilogue, and the row cuts that mix them -- returns, BIT FOR BIT, the fixed four-range
+    summation tree of csrc/fc_tree.h evaluated on the CPU with fmaf (oracle_linear_rows_tree), on the device's own
+    inputs of each layer: the "same bits at every batch size" property pinned on an independent model, not only on the
+    kernels agreeing with each other."""
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    m = model_of(max_batch=8192)
+    x = np.random.default_rng(100 + n).standard_normal((n, 150, 54), dtype=np.float32)
+    t = m.forward_taps(x)
+    plan = m.last_plan()
+    rows = np.unique(np.concatenate([np.arange(min(n, 40)), np.arange(max(n - 72, 0), n)]))     # first rows + the last (partial tiles, remainders)
+    h1 = orc.linear_rows_tree(t["feat"][rows], sd["fc.0.weight"], sd["fc.0.bias"], relu=True)
+    assert np.array_equal(h1.view(np.uint32), t["h1"][rows].view(np.uint32)), (n, plan, np.abs(h1 - t["h1"][rows]).max())
+    h2 = orc.linear_rows_tree(t["h1"][rows], sd["fc.3.weight"], sd["fc.3.bias"], relu=True)
+    assert np.array_equal(h2.view(np.uint32), t["h2"][rows].view(np.uint32)), (n, plan, np.abs(h2 - t["h2"][rows]).max())
 
 
 def test_inference_and_compute_acc_reference_broadcast(golden, case_inputs, model_of, tmp_path):
