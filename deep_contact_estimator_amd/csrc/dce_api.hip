@@ -51,6 +51,8 @@ Tuning tuning_from_env()
     t.gemm_peel = !off("DCE_GEMM_PEEL");
     t.conv_peel = !off("DCE_CONV_PEEL");
     t.gemm_small_deep = !off("DCE_GEMM_SMALL");
+    t.split_min = num("DCE_SPLIT_MIN", t.split_min);
+    t.split_max = num("DCE_SPLIT_MAX", t.split_max);
     t.chain_min = num("DCE_CHAIN_MIN", t.chain_min);
     t.chain_max = num("DCE_CHAIN_MAX", t.chain_max);
     t.chain_max3 = num("DCE_CHAIN_MAX3", t.chain_max3);
@@ -136,20 +138,20 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream, c->src_row_dev)); }
         // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
         // (from 9 windows up launch_fc_gemm picks the MFMA chain kernel of fc_gemm_chain.hip instead)
-        auto fc = (c->gemv && n <= FC_GEMV_MAX_M && !fc_gemm_chain_ok(n, FC1, FEAT)) ? launch_fc_gemv : launch_fc_gemm;
+        auto fc = (c->gemv && n <= FC_GEMV_MAX_M && !fc_split_ok(n, FC1, FEAT) && !fc_gemm_chain_ok(n, FC1, FEAT)) ? launch_fc_gemv : launch_fc_gemm;
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
-        if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1)) {
+        if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1) && !fc_split_ok(n, FC2, FC1)) {
             // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU
             // unless a tap asks for it); one small kernel adds them up.  Same summation tree as the tail kernel.
             // The fused kernel runs whole rounds of 256 tiles = 4096 windows: a batch that ends up to 2048 windows
             // past a round gives that remainder to the chain kernel + tail (same bits, rows are independent) instead
             // of paying a full round for it.
             const bool peel = c->tuning.gemm_peel;
-            const int64_t rest = n % 4096, nf = (peel && n > 4096 && rest && (rest <= FC_GEMV_MAX_M || fc_gemm_chain_ok(rest, FC2, FC1))) ? n - rest : n;
+            const int64_t rest = n % 4096, nf = (peel && n > 4096 && rest && (rest <= 8 || fc_split_ok(rest, FC2, FC1) || fc_gemm_chain_ok(rest, FC2, FC1))) ? n - rest : n;
             { Timer t(c, 2);
               HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch,
                                            c->want_h2 ? c->h2 : nullptr, nf, c->stream));
-              if (nf < n) HIP_TRY(c, (n - nf <= FC_GEMV_MAX_M ? launch_fc_gemv : launch_fc_gemm)(c->h1 + nf * FC1, c->fc2w, c->fc2b, c->h2 + nf * FC2, n - nf, FC2, FC1, 1, c->stream)); }
+              if (nf < n) HIP_TRY(c, (n - nf <= 8 ? launch_fc_gemv : launch_fc_gemm)(c->h1 + nf * FC1, c->fc2w, c->fc2b, c->h2 + nf * FC2, n - nf, FC2, FC1, 1, c->stream)); }
             { Timer t(c, 3);
               HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, c->stream, packed));
               if (nf < n) HIP_TRY(c, launch_fc3_tail(c->h2 + nf * FC2, c->fc3w, c->fc3b, n - nf, logits ? logits + nf * NCLS : nullptr,

@@ -22,7 +22,8 @@ struct Tuning {
     int fc23_mode = 0;                                      // DCE_FC23=split (1) | always (2)
     bool gemm_peel = true, conv_peel = true;                // DCE_GEMM_PEEL=0, DCE_CONV_PEEL=0
     bool gemm_small_deep = true;                            // DCE_GEMM_SMALL=0
-    long long chain_min = 33, chain_max = 640, chain_max3 = 2048, chain_bn16_max = 64;   // DCE_CHAIN_*
+    long long split_min = 9, split_max = 64;                 // DCE_SPLIT_MIN / DCE_SPLIT_MAX: windows served by the four-range MFMA kernel (fc_gemm_split.hip)
+    long long chain_min = 9, chain_max = 640, chain_max3 = 2048, chain_bn16_max = 64;   // DCE_CHAIN_*
     long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // DCE_WINO1_MAX / DCE_WINOH_MAX / DCE_WINOQ_MAX (-1: kernel default)
     bool wino1_w8 = true;                                   // DCE_WINO1_WAVES=4 -> false
     bool one_per_cu = false, trace_wino1 = false;           // DCE_ONE_PER_CU, DCE_TRACE_WINO1 (trace builds)
@@ -109,6 +110,13 @@ hipError_t init_fc_gemm_chain();
 bool       fc_gemm_chain_ok(int64_t M, int N, int K);
 hipError_t launch_fc_gemm_chain(const float* A, const float* W, const float* bias, float* C,
                                 int64_t M, int N, int K, int relu, hipStream_t st);
+
+// The same layers for 9 .. ~100 windows (fc_gemm_split.hip): one 16x16 tile of C per workgroup, the four K ranges of the
+// summation tree on its four waves -- bound by the longest range's MFMA chain (fc.0: 1280 links), not by 4736.
+hipError_t init_fc_split();
+bool       fc_split_ok(int64_t M, int N, int K);
+hipError_t launch_fc_split(const float* A, const float* W, const float* bias, float* C,
+                           int64_t M, int N, int K, int relu, hipStream_t st);
 
 // Same GEMM on bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate): A[M,K], W[N,K] bf16,
 // C fp32 or bf16 (out_bf16).  N % 128 == 0, K % 64 == 0.  DCE_BF16_FC precision only.

@@ -411,6 +411,7 @@ hipError_t init_fc_gemm()
     if ((e = init_fc_gemm_phased()) != hipSuccess) return e;
     if ((e = init_fc_gemm_chain()) != hipSuccess) return e;
     if ((e = init_fc_gemv()) != hipSuccess) return e;
+    if ((e = init_fc_split()) != hipSuccess) return e;
     return grant_lds<1, 1, true, false>();
 }
 
@@ -463,7 +464,9 @@ static hipError_t launch_fc_gemm_one(const float* A, const float* W, const float
                                      int64_t M, int N, int K, int relu, hipStream_t st, bool remainder)
 {
     // a handful of rows as the remainder of a cut: the weight-streaming GEMV
-    if (remainder && M <= FC_GEMV_MAX_M && N % 8 == 0 && K % 128 == 0) return launch_fc_gemv(A, W, bias, C, M, N, K, relu, st);
+    if (remainder && M <= 8 && N % 8 == 0 && K % 128 == 0) return launch_fc_gemv(A, W, bias, C, M, N, K, relu, st);
+    // 9 .. ~100 windows: the four K ranges of the summation tree side by side on four waves (fc_gemm_split.hip)
+    if (fc_split_ok(M, N, K)) return launch_fc_split(A, W, bias, C, M, N, K, relu, st);
     // a few dozen to a few hundred windows: chain-latency kernel, one 16x16 tile per wave (fc_gemm_chain.hip)
     if (fc_gemm_chain_ok(M, N, K)) return launch_fc_gemm_chain(A, W, bias, C, M, N, K, relu, st);
     // chip-filling sizes: one phased workgroup per CU (fc_gemm_phased.hip); same K order, same bits

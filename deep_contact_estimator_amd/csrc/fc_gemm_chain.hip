@@ -137,7 +137,7 @@ void fc_gemm_chain_kernel(const float* __restrict__ A, const float* __restrict__
         fb[set][s] = *reinterpret_cast<const ch_f32x2*>(b + b_off[s]);
     };
     ch_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, tot = {0.f, 0.f, 0.f, 0.f};     // running K range / finished ranges (fc_tree.h)
-    constexpr int cut1 = (K / 128) * 1 / 4, cut2 = (K / 128) * 2 / 4, cut3 = (K / 128) * 3 / 4;   // first chunk of ranges 1..3
+    constexpr int cut1 = fc_tree_unit(K / 128, 1), cut2 = fc_tree_unit(K / 128, 2), cut3 = fc_tree_unit(K / 128, 3);   // first chunk of ranges 1..3
     static_assert(CH_K == 128, "the tree's ranges are whole chunks");
     auto mfma2 = [&](int set, int s) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][s].x, fb[set][s].x, acc, 0, 0, 0);    // k = 0,4,1,5

@@ -336,15 +336,26 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
         phase_end<NG>(more);
         // ---- math phase
         PH_MARK(2);
-        if (!BF16 && fc_tree_cut(tree, t)) fold();       // a new K range starts with this tile
         math(af, bf);
         PH_MARK(3);
         phase_end<NG>(more);
     };
-    for (int t = 0; t < KT; t += 3) {
-        ktile(t, std::integral_constant<int, 0>{});
-        if (t + 1 < KT) ktile(t + 1, std::integral_constant<int, 1>{});
-        if (t + 2 < KT) ktile(t + 2, std::integral_constant<int, 2>{});
+    // The summation tree's cuts fall on whole rounds of this loop (fc_tree.h: multiples of three K-tiles), so the K walk
+    // is four plain loops with one accumulator fold between them -- no per-tile test between a barrier and the MFMAs.
+    const int seg_end[FC_RANGES] = {(!BF16 && tree.b1 > 0 && tree.b1 % 3 == 0) ? tree.b1 : 0, (!BF16 && tree.b2 > 0 && tree.b2 % 3 == 0) ? tree.b2 : 0,
+                                    (!BF16 && tree.b3 > 0 && tree.b3 % 3 == 0) ? tree.b3 : 0, KT};
+    int t = 0;
+#pragma unroll 1
+    for (int seg = 0; seg < FC_RANGES; ++seg) {
+        const int te = seg_end[seg];
+        if (seg + 1 < FC_RANGES && te <= t) continue;    // no cut here (bf16, or a shape without the tree)
+#pragma unroll 1
+        for (; t < te; t += 3) {
+            ktile(t, std::integral_constant<int, 0>{});
+            if (t + 1 < KT) ktile(t + 1, std::integral_constant<int, 1>{});
+            if (t + 2 < KT) ktile(t + 2, std::integral_constant<int, 2>{});
+        }
+        if (seg + 1 < FC_RANGES) fold();
     }
     if (grp == 0) phase_end<NG>(false);                  // same number of barriers for both groups
     }

@@ -6,7 +6,7 @@
 // walked K as ONE chain of 4736 links (18.5 us for fc.0, the kernel measured 21 us).  With the four-range summation tree
 // of fc_tree.h the ranges run side by side:
 //   * every workgroup owns 8 output neurons (fc.0: 256 workgroups = one per CU; fc.3: 64);
-//   * wave w of its four owns K RANGE w of the tree (fc.0: 1152 / 1152 / 1152 / 1280 links) and runs it alone, start
+//   * wave w of its four owns K RANGE w of the tree (fc.0: 1152 / 1152 / 1152 / 1280 links; fc.3: 384 / 768 / 384 / 512) and runs it alone, start
 //     to end, with no workgroup barrier: it streams its range of the 8 weight rows and of the activation rows in
 //     128-float chunks (coalesced 16-byte loads, DEPTH chunks ahead in registers), passes each chunk through a
 //     wave-private LDS image (rows padded by 16 B) and lets its 64 lanes = 8 windows x 8 neurons extend their chains --
@@ -39,7 +39,7 @@ void fc_gemv_kernel(const float* __restrict__ A, const float* __restrict__ W,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = K range of the tree
     const int n0 = blockIdx.x * GV_R;
     const int U = K / GV_CH;
-    const int u0 = U * wave / FC_RANGES, u1 = U * (wave + 1) / FC_RANGES;
+    const int u0 = fc_tree_unit(U, wave), u1 = fc_tree_unit(U, wave + 1);
     float* img = gv_lds + wave * (8 + 8 * MW) * GV_LD;                  // this wave's image: 8 weight rows, then 8 MW activation rows
     // loader role: lane (lrow = lane / 8, lc = lane % 8) moves float4 lc + 8 j (j = 0..3) of row lrow of every chunk
     const int lrow = lane >> 3, lc = lane & 7;

@@ -280,8 +280,7 @@ def test_plan_by_batch_size(model_of):
     """The kernel families the dispatch picks at the batch sizes the other tests rely on."""
     m = model_of()
     want = {1: ["conv_wino_quarter", "fc_gemv", "fc_gemv", "fc3_tail"],
-            30: ["conv_wino_quarter", "fc_gemv", "fc_gemv", "fc3_tail"],
-            40: ["conv_wino_quarter", "fc_chain32x16", "fc_chain32x16", "fc3_tail"],
+            30: ["conv_wino_quarter", "fc_split16x16", "fc_split16x16", "fc3_tail"],
             100: ["conv_wino_half", "fc_chain32x32", "fc_chain32x32", "fc3_tail"],
             200: ["conv_wino1x8", "fc_chain32x32", "fc_chain32x32", "fc3_tail"]}
     rng = np.random.default_rng(2)
@@ -293,7 +292,7 @@ def test_plan_by_batch_size(model_of):
     assert p[0] == "conv_wino2" and p[1:] == ["fc_phased256x128", "fc23_fused_phased128x64", "fc6_combine"], p
 
 
-@pytest.mark.parametrize("n", [1, 8, 9, 16, 17, 30, 33, 64, 65, 200, 641, 700, 1030, 3000, 4096, 4100])
+@pytest.mark.parametrize("n", [1, 8, 9, 16, 17, 30, 33, 64, 65, 96, 97, 200, 641, 700, 1030, 3000, 4096, 4100, 4130])
 def test_fc_layers_bit_exact_against_the_summation_tree(n, model_of, orc):
     """Every fp32 FC kernel family -- GEMV (<= 32 windows), MFMA chain, 64x64 / 128x128 tiles, phased 128x64 / 256x128,
     the fused fc.3 + fc.6-chunk epilogue, and the row cuts that mix them -- returns, BIT FOR BIT, the fixed four-range

@@ -10,7 +10,8 @@ m = contact_cnn(device=0, max_batch=4096); m.load_state_dict(synth.make_state_di
 seq = torch.from_numpy(synth.make_sequence(4096 + 149, 2).astype(np.float32)).cuda()
 x = m.zscore_windows(seq)
 res = {}
-for B in (1, 2, 30, 64, 128, 256, 512, 1024, 2048, 3000, 4096):
+sizes = [int(v) for v in os.environ.get("DCE_LAT_SIZES", "1,2,30,64,128,256,512,1024,2048,3000,4096").split(",")]
+for B in sizes:
     xb = x[:B].contiguous()
     for _ in range(20): m.predict(xb)
     torch.cuda.synchronize()
@@ -23,4 +24,5 @@ for B in (1, 2, 30, 64, 128, 256, 512, 1024, 2048, 3000, 4096):
     for _ in range(50): m.predict(xb)
     torch.cuda.synchronize(); p = m.profile_read(True); m.profile(0)
     res[B] = {"us_per_call": dt * 1e6, "windows_per_s": B / dt, "kernel_us": {k: round(v["ms"] / v["launches"] * 1e3, 1) for k, v in p.items()}}
+    res[B]["plan"] = " ".join(m.last_plan())
     print(B, json.dumps(res[B]))
