@@ -23,6 +23,6 @@ for B in sizes:
     m.profile(1); m.profile_read(True)
     for _ in range(50): m.predict(xb)
     torch.cuda.synchronize(); p = m.profile_read(True); m.profile(0)
-    res[B] = {"us_per_call": dt * 1e6, "windows_per_s": B / dt, "kernel_us": {k: round(v["ms"] / v["launches"] * 1e3, 1) for k, v in p.items()}}
+    res[B] = {"us_per_call": dt * 1e6, "windows_per_s": B / dt, "kernel_us": {k: round(v["ms"] / v["launches"] * 1e3, 1) for k, v in p.items() if v["launches"]}}
     res[B]["plan"] = " ".join(m.last_plan())
     print(B, json.dumps(res[B]))
