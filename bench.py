@@ -311,8 +311,9 @@ def extra_small_batches(torch, model, windows, sizes=(1, 30, 64, 256, 512, 1024)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         res[str(b)] = {"us_per_call": dt * 1e6, "windows_per_s": b / dt}
-    return {"workload": "model.predict on b pre-normalised device-resident windows, fp32 (GEMV <= 8, MFMA chain kernel 9..640/2048, "
-                        "one-window conv kernel <= 256 windows)", "batches": res}
+    return {"workload": "model.predict on b pre-normalised device-resident windows, fp32 (FC layers: four-range GEMV <= 8 windows, four-range "
+                        "MFMA kernel 9..64, MFMA chain kernel 65..640/2048; conv stack: quarter / half-window segments <= 64 / 128, one window "
+                        "per workgroup <= 256)", "batches": res}
 
 
 def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s=1.5):

@@ -361,6 +361,22 @@ __device__ __forceinline__ void col_offsets(int nt0, int j, int (&boff)[NTW])
     }
 }
 
+// Output transform of two accumulator rows at once (r, r+1 of an MFMA result quad sit in consecutive registers):
+//   y0 = (m0 + m1) + m2,  y1 = (m1 - m2) - m3   as four v_pk_add_f32 for two pairs instead of eight scalar adds.
+// A write-back is ~340 non-MFMA instructions per wave that issue into the breaks of the partner workgroup's MFMA stream
+// (profiles/r3b_conv_experiments.txt): fewer instructions, shorter write-backs.  Same operations in the same order per
+// element: the same bits.
+__device__ __forceinline__ void wino_out2(const f32x4& m0, const f32x4& m1, const f32x4& m2, const f32x4& m3, int h, v2f& y0, v2f& y1)
+{
+    const v2f a0 = h ? v2f{m0[2], m0[3]} : v2f{m0[0], m0[1]}, a1 = h ? v2f{m1[2], m1[3]} : v2f{m1[0], m1[1]};
+    const v2f a2 = h ? v2f{m2[2], m2[3]} : v2f{m2[0], m2[1]}, a3 = h ? v2f{m3[2], m3[3]} : v2f{m3[0], m3[1]};
+    y0 = (a0 + a1) + a2;
+    // (hipcc selects v_pk_add_f32 for the sums but leaves the differences as scalar v_sub_f32: spelled out)
+    v2f u;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(u) : "v"(a1), "v"(a2));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(y1) : "v"(u), "v"(a3));
+}
+
 // output transform + ReLU + in-place write-back, no pooling (conv1: T=150, conv3: T=75)
 template <int RS, int WSEG, int TP, int T, int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW, bool TAPS = false>
 __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const f32x4 (&acc)[MT][NTW][4],
@@ -376,20 +392,24 @@ __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
-                    const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
-                    float* d = act + (co0 + 16 * mt + 4 * q + r) * RS + w * WSEG + 1 + 2 * m;
+                for (int h = 0; h < 2; ++h) {
+                    v2f y0, y1;
+                    wino_out2(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3], h, y0, y1);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 2 * h + e;
+                        float* d = act + (co0 + 16 * mt + 4 * q + r) * RS + w * WSEG + 1 + 2 * m;
 #if WINO_EXP & 16
-                    d[0] = m0; d[1] = m1; asm volatile("" :: "v"(m2), "v"(m3));     // timing probe: no output-transform VALU (WRONG results)
+                        d[0] = acc[mt][nt][0][r]; d[1] = acc[mt][nt][1][r];     // timing probe: no output-transform VALU (WRONG results)
 #else
-                    d[0] = fmaxf((m0 + m1) + m2, 0.f);
-                    d[1] = (T % 2 == 0 || 2 * m + 1 < T) ? fmaxf((m1 - m2) - m3, 0.f) : 0.f;   // index T+1 is a zero pad
+                        d[0] = fmaxf(y0[e], 0.f);
+                        d[1] = (T % 2 == 0 || 2 * m + 1 < T) ? fmaxf(y1[e], 0.f) : 0.f;   // index T+1 is a zero pad
 #endif
-                    if constexpr (TAPS) {
-                        float* tp = tap + ((size_t)w * cout + co0 + 16 * mt + 4 * q + r) * T + 2 * m;
-                        tp[0] = d[0];
-                        if (2 * m + 1 < T) tp[1] = d[1];
+                        if constexpr (TAPS) {
+                            float* tp = tap + ((size_t)w * cout + co0 + 16 * mt + 4 * q + r) * T + 2 * m;
+                            tp[0] = d[0];
+                            if (2 * m + 1 < T) tp[1] = d[1];
+                        }
                     }
                 }
         }
@@ -412,21 +432,24 @@ __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
-                    const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
-                    // max(relu(y0), relu(y1)) = max(y0, y1, 0)
+                for (int h = 0; h < 2; ++h) {
+                    v2f y0, y1;
+                    wino_out2(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3], h, y0, y1);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 2 * h + e;
+                        // max(relu(y0), relu(y1)) = max(y0, y1, 0)
 #if WINO_EXP & 16
-                    act[(co0 + 16 * mt + 4 * q + r) * R2 + w * W2 + 1 + m] = m0; asm volatile("" :: "v"(m1), "v"(m2), "v"(m3));
+                        act[(co0 + 16 * mt + 4 * q + r) * R2 + w * W2 + 1 + m] = acc[mt][nt][0][r];
 #else
-                    act[(co0 + 16 * mt + 4 * q + r) * R2 + w * W2 + 1 + m] =
-                        fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+                        act[(co0 + 16 * mt + 4 * q + r) * R2 + w * W2 + 1 + m] = fmaxf(fmaxf(y0[e], y1[e]), 0.f);
 #endif
-                    if constexpr (TAPS) {
-                        const size_t row = (size_t)w * 64 + co0 + 16 * mt + 4 * q + r;
-                        tap_conv2[row * 150 + 2 * m] = fmaxf((m0 + m1) + m2, 0.f);
-                        tap_conv2[row * 150 + 2 * m + 1] = fmaxf((m1 - m2) - m3, 0.f);
-                        tap_pool1[row * 75 + m] = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+                        if constexpr (TAPS) {
+                            const size_t row = (size_t)w * 64 + co0 + 16 * mt + 4 * q + r;
+                            tap_conv2[row * 150 + 2 * m] = fmaxf(y0[e], 0.f);
+                            tap_conv2[row * 150 + 2 * m + 1] = fmaxf(y1[e], 0.f);
+                            tap_pool1[row * 75 + m] = fmaxf(fmaxf(y0[e], y1[e]), 0.f);
+                        }
                     }
                 }
         }
@@ -469,15 +492,18 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float m0 = acc[mt][nt][0][r], m1 = acc[mt][nt][1][r];
-                    const float m2 = acc[mt][nt][2][r], m3 = acc[mt][nt][3][r];
+                for (int h = 0; h < 2; ++h) {
+                    v2f y0, y1;
+                    wino_out2(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3], h, y0, y1);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
 #if WINO_EXP & 16
-                    const float v = m0; asm volatile("" :: "v"(m1), "v"(m2), "v"(m3));
+                        const float v = acc[mt][nt][0][2 * h + e];
 #else
-                    const float v = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+                        const float v = fmaxf(fmaxf(y0[e], y1[e]), 0.f);
 #endif
-                    put_feat(base + (16 * mt + r) * 37, bad ? nanv : v);
+                        put_feat(base + (16 * mt + 2 * h + e) * 37, bad ? nanv : v);
+                    }
                 }
         }
     }

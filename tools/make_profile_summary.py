@@ -32,8 +32,10 @@ def main(tag):
     for r in csv.DictReader(open(os.path.join(out, f"{tag}_stats", f"{tag}_kernel_stats.csv"))):
         avg_us[pmc_summary.short(r["Name"])] = float(r["AverageNs"]) / 1e3
     ctr = {}
-    for part in ("fetch", "write", "sq", "lds"):
+    for part in ("fetch", "write", "sq", "lds", "tcc1", "tcc2"):
         p = os.path.join(out, f"{tag}_pmc_{part}", f"{tag}_counter_collection.csv")
+        if not os.path.exists(p):
+            continue
         for k, v in pmc_summary.main([p]).items():
             ctr.setdefault(k, {}).update(v)
     lines = [f"rocprofv3 passes of tools/profile_gpu.sh {tag}; {B} windows per launch. Kernel-trace averages: `python bench.py --steps 300 --warmup 50 "
@@ -54,6 +56,21 @@ def main(tag):
         latest[NAMES[k]] = {"hbm_bytes_per_launch": hbm, "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
                             "algorithmic_bytes_per_launch": algo, "mfma_busy_frac": busy, "profile": tag,
                             "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 counts 128-B requests as 64 B)"}
+    # L2 view (optional passes): hit rate and what L2 asks of the fabric.  TCC_EA0_RDREQ counts requests, _32B / _64B the
+    # short ones, the rest are 128-byte requests.  Whether a fabric read is served by the memory-side Infinity Cache (MALL)
+    # or by HBM is NOT visible to these counters (TCC_EA0_RDREQ_DRAM counts reads addressed to DRAM space, cached or not).
+    if any("TCC_HIT" in c for c in ctr.values()):
+        lines += ["", "| kernel | L2 hit rate TCC_HIT / (TCC_HIT + TCC_MISS) | TCC_REQ | fabric read requests TCC_EA0_RDREQ | of them 32 B / 64 B | "
+                      "fabric read bytes (32/64/128-B requests) | algorithmic bytes / launch |", "|---|---|---|---|---|---|---|"]
+        for k, algo in ALGO.items():
+            c = ctr.get(k)
+            if not c or "TCC_HIT" not in c:
+                continue
+            hit = c["TCC_HIT"] / max(c["TCC_HIT"] + c["TCC_MISS"], 1)
+            rd, r32, r64 = c.get("TCC_EA0_RDREQ", 0), c.get("TCC_EA0_RDREQ_32B", 0), c.get("TCC_EA0_RDREQ_64B", 0)
+            rbytes = 32 * r32 + 64 * r64 + 128 * max(rd - r32 - r64, 0)
+            lines.append(f"| {NAMES[k]} | {hit:.3f} | {c.get('TCC_REQ', 0):.3g} | {rd:.3g} | {r32:.3g} / {r64:.3g} | {rbytes / 1e6:.1f} MB | {algo / 1e6:.1f} MB |")
+            latest[NAMES[k]].update({"l2_hit_rate": hit, "fabric_read_bytes_per_launch": rbytes})
     # the build these counters were taken on (tools/profile_gpu.sh records the hash of the .so's sources on the box):
     # bench.py marks roofline.traffic stale when the library it times was built from other sources
     hp = os.path.join(out, f"{tag}_source_hash.txt")

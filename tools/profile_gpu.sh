@@ -13,5 +13,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- $B > $OUT/${TAG}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/${TAG}_pmc_sq -o ${TAG} -- $B > $OUT/${TAG}_pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_lds -o ${TAG} -- $B > $OUT/${TAG}_pmc_lds.log 2>&1
+# L2 (TCC) view of the same step: hit rate, and the read requests it sends on to the fabric (Infinity Fabric -> MALL -> HBM) by size
+rocprofv3 --kernel-trace --pmc TCC_HIT TCC_MISS TCC_REQ TCC_READ --output-format csv -d $OUT/${TAG}_pmc_tcc1 -o ${TAG} -- $B > $OUT/${TAG}_pmc_tcc1.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_DRAM --output-format csv -d $OUT/${TAG}_pmc_tcc2 -o ${TAG} -- $B > $OUT/${TAG}_pmc_tcc2.log 2>&1
 find $OUT -name "${TAG}*" -type f | head -40
 for f in $OUT/${TAG}_*.log; do echo "== $f"; grep -E '"metric"|rror' $f | cut -c1-300; done
