@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Race screen for the MFMA chain kernel (fc_gemm_chain.hip: a register ring of asm loads, a double-buffered LDS image,
-one barrier per chunk): repeated runs at the window counts it serves must return the same bits every time -- and the bits
-of a run with the kernel switched off (DCE_CHAIN_MAX=0, DCE_CHAIN_MAX3=0: GEMV / tile kernels) -- also while a second
-stream keeps the memory system busy (uneven load shifts the landing times of the ring's loads)."""
+"""Race screen for the small-batch FC kernels -- the four-range GEMV (<= 8 windows; wave-private LDS images), the four-range
+MFMA kernel (fc_gemm_split.hip, 9..64 windows; wave-private images, one barrier at the end) and the MFMA chain kernel
+(fc_gemm_chain.hip: a register ring of asm loads, a double-buffered LDS image, one barrier per chunk): repeated runs at the
+window counts they serve must return the same bits every time -- and the bits of a run with all three switched off
+(DCE_CHAIN_MAX=0, DCE_CHAIN_MAX3=0, DCE_SPLIT_MAX=0, DCE_SMALL_BATCH=gemm: tile kernels only) -- also while a second stream
+keeps the memory system busy (uneven load shifts the landing times of the loads)."""
 import json, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SIZES = [9, 30, 33, 64, 255, 256, 300, 640, 1024, 2048]
+SIZES = [1, 8, 9, 30, 33, 64, 65, 255, 256, 300, 640, 1024, 2048]
 
 
 def child(reps):
@@ -36,7 +38,7 @@ if __name__ == "__main__":
         child(int(sys.argv[2])); sys.exit(0)
     reps = int(os.environ.get("REPS", 300))
     res = {}
-    for tag, env in (("chain", {}), ("off", {"DCE_CHAIN_MAX": "0", "DCE_CHAIN_MAX3": "0"})):
+    for tag, env in (("chain", {}), ("off", {"DCE_CHAIN_MAX": "0", "DCE_CHAIN_MAX3": "0", "DCE_SPLIT_MAX": "0", "DCE_SMALL_BATCH": "gemm"})):
         p = subprocess.run([sys.executable, __file__, "child", str(reps if tag == "chain" else 2)], env=dict(os.environ, **env),
                            capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
