@@ -357,6 +357,9 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
         }
         if (seg + 1 < FC_RANGES) fold();
     }
+    // (Measured alternatives, all slower than this fold behind the range's last barrier -- fc.0 530 us, fc.3 67 us: a run-time
+    //  test for the cut in every tile, before its MFMAs 540 / 75 us, after them 535 / 78 us; the range's last round peeled with the
+    //  fold compiled in behind its third tile's MFMAs -- where the partner wave issues no MFMA -- 570 / 76 us: twice the loop code.)
     if (grp == 0) phase_end<NG>(false);                  // same number of barriers for both groups
     }
 

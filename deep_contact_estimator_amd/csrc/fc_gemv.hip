@@ -150,7 +150,9 @@ hipError_t launch_fc_gemv(const float* A, const float* W, const float* bias, flo
                           int64_t M, int N, int K, int relu, hipStream_t st)
 {
     if (M <= 0) return hipSuccess;
-    if (M > FC_GEMV_MAX_M || N % GV_R != 0 || K % GV_CH != 0 || K / GV_CH < FC_RANGES) return hipErrorInvalidValue;
+    if (M > FC_GEMV_MAX_M || N % GV_R != 0 || K % GV_CH != 0) return hipErrorInvalidValue;
+    for (int r = 0; r < FC_RANGES; ++r)                                  // every wave needs a non-empty K range
+        if (fc_tree_unit(K / GV_CH, r + 1) <= fc_tree_unit(K / GV_CH, r)) return hipErrorInvalidValue;
     const dim3 grid(N / GV_R), block(256);
     plan_note("fc_gemv");
     if (M <= 8)       hipLaunchKernelGGL((fc_gemv_kernel<1, 2>), grid, block, gv_lds_floats<1>() * sizeof(float), st, A, W, bias, C, (int)M, N, K, relu);

@@ -165,7 +165,7 @@ int  dce_confusion_counts(dce_ctx* ctx, const int32_t* pred, const int64_t* labe
  * 0 while the ring is still filling, < 0 on error.  dce_online_reset empties the ring.
  * Latency path: no H2D/D2H copies and no stream synchronisation -- the sample is read by the first
  * kernel from pinned host memory, the estimate is written by the last kernel to pinned host memory
- * followed by a sequence number the call polls (~85-90 us per push on MI355X). */
+ * followed by a sequence number the call polls (~60 us per push on MI355X). */
 int  dce_online_reset(dce_ctx* ctx);
 int  dce_online_push(dce_ctx* ctx, const float* sample, float* logits, int32_t* pred, uint8_t* contacts);
 
