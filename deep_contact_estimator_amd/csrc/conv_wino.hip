@@ -348,16 +348,31 @@ __device__ __forceinline__ void wino_mfma_deep(const float* __restrict__ xrow, c
     }
 }
 
-// column n = w*TP + m of a layout with TP pairs per window -> float offset of pair m (0 for fillers)
+// Columns of the implicit GEMMs.  One window per workgroup: column n = pair n.  TWO windows: column n = (TP + 1) w + m --
+// each window brings one DUMMY column (m = TP) behind its TP pairs.  A window segment is WSEG = 2 (TP + 1) floats wide
+// (152 = 2 x 76, 78 = 2 x 39), so pair m of window w sits at float 2 n of the row for EVERY column: the offsets of a wave's
+// column tiles differ by compile-time constants (32 floats per tile) and reach the LDS reads as instruction immediates
+// instead of one v_add per tile (78 K-steps x 4 VALU instructions per wave: this kernel is issue-bound).
+// The dummy column and the fillers past the last one read whatever lies there (still inside the workgroup's LDS) and feed
+// accumulators that are never stored; the tile counts do not change (152 columns = 10 tiles, 78 = 5).
+template <int TP, int NWIN> struct ColMap {
+    static constexpr int TPC = TP + (NWIN > 1 ? 1 : 0);               // columns per window
+    __device__ static __forceinline__ bool valid(int n, int& w, int& m)
+    {
+        w = (NWIN > 1 && n >= TPC) ? 1 : 0;
+        m = n - w * TPC;
+        return n < NWIN * TPC && m < TP;
+    }
+};
 template <int TP, int WSEG, int NTW = dce::NTW, int NWIN = NW>
 __device__ __forceinline__ void col_offsets(int nt0, int j, int (&boff)[NTW])
 {
+    static_assert(NWIN == 1 || WSEG == 2 * (TP + 1), "two windows: the segment width makes the column map linear");
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = 16 * (nt0 + nt) + j;
-        const int w = (NWIN > 1 && n >= TP) ? 1 : 0;
-        const int m = n - w * TP;
-        boff[nt] = n < NWIN * TP ? w * WSEG + 2 * m : 0;
+        if constexpr (NWIN > 1) boff[nt] = 2 * (16 * nt0 + j) + 32 * nt;      // = 2 n, as base + constant
+        else boff[nt] = n < TP ? 2 * n : 0;
     }
 }
 
@@ -386,9 +401,8 @@ __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const 
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = 16 * (nt0 + nt) + j;
-        const int w = (NWIN > 1 && n >= TP) ? 1 : 0;
-        const int m = n - w * TP;
-        if (n < NWIN * TP) {
+        int w, m;
+        if (ColMap<TP, NWIN>::valid(n, w, m)) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -426,9 +440,8 @@ __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, 
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = 16 * (nt0 + nt) + j;
-        const int w = (NWIN > 1 && n >= TP1) ? 1 : 0;
-        const int m = n - w * TP1;
-        if (n < NWIN * TP1) {
+        int w, m;
+        if (ColMap<TP1, NWIN>::valid(n, w, m)) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -470,10 +483,10 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int n = 16 * nt + j;
-        const int w = (NWIN > 1 && n >= TP2) ? 1 : 0;
-        const int m = n - w * TP2;
+        int w, m;
+        const bool colv = ColMap<TP2, NWIN>::valid(n, w, m);
         if constexpr (TAPS) {
-            if (n < NWIN * TP2 && w < nvalid) {
+            if (colv && w < nvalid) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -486,7 +499,7 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
                     }
             }
         }
-        if (n < NWIN * TP2 && m < 37 && w < nvalid) {
+        if (colv && m < 37 && w < nvalid) {
             FT* base = feat + (win0 + w) * FEAT + (co0 + 4 * q) * 37 + m;
             const bool bad = w ? nan1 : nan0;
 #pragma unroll
@@ -837,8 +850,8 @@ void conv_wino_rt4_kernel(const float* __restrict__ src, int64_t n, ConvPack pk,
     const float* xrow1 = act + q * RS1;
     const float* xrow2 = act + q * RS2;
     // column n of a stage -> (window, pair), LDS offset of the pair (fillers past the last pair read offset 0)
-    auto col1 = [&](int ct, int& w, int& m) { const int nn = 16 * ct + j; w = nn >= TP1 ? 1 : 0; m = nn - w * TP1; return nn < NW * TP1; };
-    auto col2 = [&](int ct, int& w, int& m) { const int nn = 16 * ct + j; w = nn >= TP2 ? 1 : 0; m = nn - w * TP2; return nn < NW * TP2; };
+    auto col1 = [&](int ct, int& w, int& m) { return ColMap<TP1, NW>::valid(16 * ct + j, w, m); };
+    auto col2 = [&](int ct, int& w, int& m) { return ColMap<TP2, NW>::valid(16 * ct + j, w, m); };
 
     // ---- stage 1: wave w = column tiles 2w, 2w+1 (64 channels) + tile 8 + (w>>1), channel pair w&1
     {
@@ -849,7 +862,7 @@ void conv_wino_rt4_kernel(const float* __restrict__ src, int64_t n, ConvPack pk,
         const float4* ap2H = reinterpret_cast<const float4*>(pk.ww[1]) + pH * (16 * 128) + 2 * lane;
         const float4* ap2O = reinterpret_cast<const float4*>(pk.ww[1]) + (pH ^ 1) * (16 * 128) + 2 * lane;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { int w, m; boff[t] = col1(ct[t], w, m) ? w * WS1 + 2 * m : 0; }
+        for (int t = 0; t < 3; ++t) boff[t] = 2 * (16 * ct[t] + j);
         A16 a = load_a16(ap1H, ap1O, 0);
         wino_mfma4<RS1, 14>(xrow1, boff, ap1H, ap1O, a, bias_lds, rowH, rowO, lane, acc);
         TRACE_MARK(2);
@@ -909,7 +922,7 @@ void conv_wino_rt4_kernel(const float* __restrict__ src, int64_t n, ConvPack pk,
             act[c * RS2 + (k / 3) * WS2 + (k % 3 == 0 ? 0 : 75 + k % 3)] = 0.f;
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { int w, m; boff[t] = col2(ct2[t], w, m) ? w * WS2 + 2 * m : 0; }
+        for (int t = 0; t < 3; ++t) boff[t] = 2 * (16 * ct2[t] + j);
         __syncthreads();
         TRACE_MARK(5);
         wino_mfma4<RS2, 16>(xrow2, boff, ap3H, ap3O, a, bias_lds + 128, rowH, rowO, lane, acc);

@@ -99,13 +99,21 @@ def gather_rows(t, sizes=None, group=None, dst: int = 0):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0).to(home)
 
 
+_bootstraps = 0
+
+
 def comm_bootstrap(model, rank: int, world: int, key: str = "dce_comm_id"):
     """Give `model` (one per rank) the node's RCCL communicator: rank 0 draws an ncclUniqueId and the 128 bytes travel
     through the store of the initialised torch.distributed group (TCP, no GPU collective), or -- with DCE_COMM_ID_FILE
     set and no process group -- through that file (written atomically by rank 0, polled by the others)."""
     import os
     import time
+    global _bootstraps
+    _bootstraps += 1                       # every rank calls in the same order: the n-th communicator of a process has its own key / file
+    key = f"{key}_{_bootstraps}"
     path = os.environ.get("DCE_COMM_ID_FILE")
+    if path:
+        path = f"{path}.{_bootstraps}"
     store = None
     try:
         import torch.distributed as dist
