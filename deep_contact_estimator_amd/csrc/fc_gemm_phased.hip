@@ -34,6 +34,12 @@
 #ifndef PH_TRACE
 #define PH_TRACE 0
 #endif
+#ifndef PH_FOLD_MFMA
+#define PH_FOLD_MFMA 0       // 1: the summation tree's fold clears the accumulators with an MFMA of zeros instead of 16 v_mov per tile
+                             // (measured: fc.0 533.1 vs 532.1 us, no gain -- the fold's cost is the 32 v_pk_add_f32, which wait for
+                             // breaks in the partner wave's MFMA stream and delay the phase barrier: ~1 us per fold, three per launch;
+                             // with the tree's cuts switched off altogether (-DFC_TREE_OFF, wrong results) fc.0 528.8 / fc.3 65.8 us)
+#endif
 
 
 namespace dce {
@@ -205,12 +211,24 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
     }
     auto fold = [&]() {
         if constexpr (!BF16) {
+            // tot += acc (8 v_pk_add_f32 per 32x32 tile), acc = 0.  PH_FOLD_MFMA=1 clears on the matrix pipe instead (an MFMA
+            // of zeros with the literal 0 as C; the asm is opaque to hipcc's hazard recogniser, hence the spelled-out wait states).
+            const float z = 0.f;
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
+                for (int b = 0; b < TN; ++b) {
+                    tot[a][b] += acc[a][b];
+#if PH_FOLD_MFMA
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %1, 0" : "=&v"(acc[a][b]) : "v"(z));
+#else
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { tot[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = z;
+#endif
+                }
+#if PH_FOLD_MFMA
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
         }
     };
     const FcTree tree = fc_tree(BF16 ? 1 : K, ROWB / 4);

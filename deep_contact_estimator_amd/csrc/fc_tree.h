@@ -28,6 +28,9 @@ struct FcTree { int b1, b2, b3; };
 __host__ __device__ inline FcTree fc_tree(int K, int unit)
 {
     if (K % 128) return FcTree{-1, -1, -1};
+#ifdef FC_TREE_OFF           // timing probe only (WRONG results: one chain in the MFMA GEMMs, four ranges elsewhere)
+    return FcTree{-1, -1, -1};
+#endif
     const int U = K / 128, m = 128 / unit;
     return FcTree{fc_tree_unit(U, 1) * m, fc_tree_unit(U, 2) * m, fc_tree_unit(U, 3) * m};
 }
