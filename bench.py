@@ -316,6 +316,27 @@ def extra_small_batches(torch, model, windows, sizes=(1, 30, 64, 256, 512, 1024)
                         "per workgroup <= 256)", "batches": res}
 
 
+def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000):
+    """SURVEY 8(f) rank 4 / the reference's README.md:67-83: push one (54,) host sample, get one estimate back (dce_online_push:
+    sample in the kernel arguments / pinned memory, the newest window through the small-batch kernels, result polled from pinned
+    memory).  Per-sample latency through the Python binding, plain launches."""
+    m = contact_cnn(device=dev.index, max_batch=64)
+    m.load_state_dict(sd).eval()
+    m.online_reset()
+    pushes = max(min(pushes, seq_np.shape[0] - 350), 0)
+    rows = seq_np[:150 + 200 + pushes]
+    for t in range(150 + 200):
+        m.online_push(rows[t])
+    t0 = time.perf_counter()
+    k = 0
+    for t in range(150 + 200, rows.shape[0]):
+        k += m.online_push(rows[t]) is not None
+    dt = (time.perf_counter() - t0) / max(k, 1)
+    m.close()
+    return {"workload": "dce_online_push: one host sample in -> logits, class, 4 contact bits out, per push (Python binding, plain launches)",
+            "us_per_push": dt * 1e6, "pushes": k, "samples_per_s": 1.0 / dt}
+
+
 def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s=1.5):
     """BASELINE configs[4]: fc.0 / fc.3 on bf16 MFMA (fp32 accumulate), conv stack and fc.6 fp32."""
     m = contact_cnn(device=dev.index, max_batch=B, precision="bf16_fc")
@@ -602,6 +623,7 @@ def main():
         elif args.precision == "fp32":
             res["extra"] = {
                 "small_batches": extra_small_batches(torch, model, windows),
+                "online_push": extra_online(contact_cnn, sd, dev, seq_np),
                 "streaming_1e6": extra_streaming(torch, contact_cnn, sd, dev),
                 "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s),
             }

@@ -257,5 +257,6 @@ def test_bench_default_line_contract():
     assert cb["value"] > 0 and cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["sample"]
     ex = j["extra"]
     assert ex["streaming_1e6"]["hbm_resident_windows_per_s"] > 1e6 and ex["bf16_fc"]["windows_per_s"] > 1e6
+    assert 10 < ex["online_push"]["us_per_push"] < 500 and ex["online_push"]["pushes"] >= 1000
     sb = ex["small_batches"]["batches"]
     assert set(sb) >= {"1", "30"} and 0 < sb["1"]["us_per_call"] < sb["30"]["us_per_call"] < 500
