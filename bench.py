@@ -371,7 +371,7 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
     return res
 
 
-def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per_rank=1_000_000):
+def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per_rank=1_000_000, use_rccl=True):
     """BASELINE configs[3] literally: a (world*n + 149, 54) sequence, rank g holds rows
     [g*n, (g+1)*n + 149) (its 149-row halo regenerated, not communicated), one fused pass per rank,
     ONE gather of the packed (n,68)-byte results to rank 0."""
@@ -379,7 +379,7 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
     from deep_contact_estimator_amd.distributed import comm_bootstrap
     m = contact_cnn(device=dev.index, max_batch=32768)
     m.load_state_dict(sd).eval()
-    if backend == "nccl":
+    if backend == "nccl" and use_rccl:
         comm_bootstrap(m, rank, world, key="dce_comm_id_sharded")
     n_total = world * n_per_rank
     r0, r1, _, _ = shard_rows(n_total + 149, rank, world)
@@ -408,7 +408,7 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
                         "logits+contacts (68 B/window) to rank 0",
             "windows_per_s_incl_gather": n_total / float(t.item()), "ms": float(t.item()) * 1e3,
             "gathered_MB": n_total * 68 / 1e6,
-            "transport": "dce_gather_results (ncclGather issued by libdce.so)" if backend == "nccl" else f"torch.distributed {backend} (functional test)"}
+            "transport": "dce_gather_results (ncclGather issued by libdce.so)" if backend == "nccl" and use_rccl else f"torch.distributed {backend}"}
 
 
 def self_launch(n):
@@ -482,8 +482,20 @@ def main():
     windows = model.zscore_windows(seq, 0, B)
     torch.cuda.synchronize()
 
-    gatherer, rccl_info = None, None
+    gatherer, rccl_info, rccl_fallback = None, None, None
     if multi and backend == "nccl":
+        # can every rank bind RCCL through libdce.so?  A local check (drawing a unique id needs no peer) agreed on by all ranks,
+        # so that a box whose librccl cannot be bound still yields a scaling curve -- over torch.distributed, and SAYS so
+        try:
+            contact_cnn.comm_unique_id()
+            ok, why = 1, ""
+        except Exception as e:                                    # noqa: BLE001
+            ok, why = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            rccl_fallback = f"libdce.so could not bind RCCL on every rank ({why or 'another rank failed'}): the per-step gather runs over torch.distributed (nccl)"
+    if multi and backend == "nccl" and rccl_fallback is None:
         # the data path's one exchange: libdce.so's own RCCL communicator (dce_comm_init / dce_gather_results)
         from deep_contact_estimator_amd.distributed import PackedStepGather, comm_bootstrap
         comm_bootstrap(model, rank, world)
@@ -570,6 +582,8 @@ def main():
         }
         if rccl_info is not None:
             res["rccl"] = rccl_info
+        elif multi and rccl_fallback:
+            res["rccl"] = {"backend": "FALLBACK " + rccl_fallback}
         elif multi:
             res["rccl"] = {"backend": f"none: torch.distributed {backend} with ranks sharing GPUs (functional test of the N>1 flow)"}
         if kernels:
@@ -617,7 +631,7 @@ def main():
     # 5. the other configs + the CPU baseline (N=1: rank 0 alone; N>1: every rank takes part in the sharded pass)
     if not args.no_extras:
         if multi:
-            sh = extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend)
+            sh = extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, use_rccl=rccl_fallback is None)
             if rank == 0:
                 res["extra"] = {"sharded_1e6": sh}
         elif args.precision == "fp32":

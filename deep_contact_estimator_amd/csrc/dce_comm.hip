@@ -49,7 +49,10 @@ void rccl_bind()
 {
     Rccl& r = g_rccl;
     std::vector<std::pair<std::string, int>> cands;     // (name, dlopen flags)
-    if (const char* e = getenv("DCE_RCCL_LIB")) cands.push_back({e, RTLD_NOW | RTLD_LOCAL});
+    if (const char* e = getenv("DCE_RCCL_LIB")) {
+        if (strcmp(e, "none") == 0) { r.error = "switched off by DCE_RCCL_LIB=none"; return; }      // tests of the callers' error paths
+        cands.push_back({e, RTLD_NOW | RTLD_LOCAL});
+    }
     for (const char* n : {"librccl.so", "librccl.so.1"}) cands.push_back({n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD});   // already mapped
     for (const char* n : {"librccl.so.1", "librccl.so"}) cands.push_back({n, RTLD_NOW | RTLD_LOCAL});
     const char* rocm = getenv("ROCM_PATH");

@@ -234,6 +234,20 @@ def test_bench_multi_gpu_flow_on_rccl_single_rank():
     assert sh["windows_per_s_incl_gather"] > 1e6 and abs(sh["gathered_MB"] - 68.0) < 1e-9 and "dce_gather_results" in sh["transport"]
 
 
+def test_bench_reports_a_fallback_when_rccl_cannot_be_bound():
+    """If libdce.so cannot bind RCCL (DCE_RCCL_LIB=none stands in for a box without a usable librccl) the ranks agree on
+    it before any collective of the data path and the per-step gather runs over torch.distributed -- and the line SAYS so
+    (`rccl.backend` starts with FALLBACK); nothing hangs, nothing is silent."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, DCE_FORCE_DIST="1", MASTER_PORT="29585", DCE_RCCL_LIB="none")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--settle-s", "0.2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["rccl"]["backend"].startswith("FALLBACK") and "DCE_RCCL_LIB=none" in j["rccl"]["backend"]
+    assert j["value"] > 1e6 and "torch.distributed" in j["extra"]["sharded_1e6"]["transport"]
+
+
 def test_bench_default_line_contract():
     """The line the driver records: `python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the
     contract's keys, the roofline and cpu_baseline objects, and every other BASELINE config measured under `extra`."""
