@@ -44,6 +44,7 @@ import json
 import os
 import statistics
 import sys
+import threading
 import time
 
 import numpy as np
@@ -376,11 +377,11 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
     [g*n, (g+1)*n + 149) (its 149-row halo regenerated, not communicated), one fused pass per rank,
     ONE gather of the packed (n,68)-byte results to rank 0."""
     from deep_contact_estimator_amd.distributed import infer_sequence_sharded, shard_rows
-    from deep_contact_estimator_amd.distributed import comm_bootstrap
+    from deep_contact_estimator_amd.distributed import comm_bootstrap_checked
     m = contact_cnn(device=dev.index, max_batch=32768)
     m.load_state_dict(sd).eval()
     if backend == "nccl" and use_rccl:
-        comm_bootstrap(m, rank, world, key="dce_comm_id_sharded")
+        use_rccl = comm_bootstrap_checked(m, rank, world, dev, key="dce_comm_id_sharded") is None
     n_total = world * n_per_rank
     r0, r1, _, _ = shard_rows(n_total + 149, rank, world)
     g = torch.Generator(device=dev)
@@ -496,9 +497,14 @@ def main():
         if int(flag.item()) == 0:
             rccl_fallback = f"libdce.so could not bind RCCL on every rank ({why or 'another rank failed'}): the per-step gather runs over torch.distributed (nccl)"
     if multi and backend == "nccl" and rccl_fallback is None:
-        # the data path's one exchange: libdce.so's own RCCL communicator (dce_comm_init / dce_gather_results)
-        from deep_contact_estimator_amd.distributed import PackedStepGather, comm_bootstrap
-        comm_bootstrap(model, rank, world)
+        # the data path's one exchange: libdce.so's own RCCL communicator (dce_comm_init / dce_gather_results), brought up
+        # under a watchdog and proven on a first gather whose bytes rank 0 checks; all ranks agree on the verdict
+        from deep_contact_estimator_amd.distributed import comm_bootstrap_checked
+        why = comm_bootstrap_checked(model, rank, world, dev)
+        if why:
+            rccl_fallback = f"libdce.so's RCCL communicator did not come up on every rank ({why}): the per-step gather runs over torch.distributed (nccl)"
+    if multi and backend == "nccl" and rccl_fallback is None:
+        from deep_contact_estimator_amd.distributed import PackedStepGather
         gatherer = PackedStepGather(model, B, dev, dst=0)
         ci = model.comm_info()
         rccl_info = {"backend": f"RCCL {ci['rccl_version']} through the C ABI (dce_gather_results: one ncclGather per step on the "
@@ -629,9 +635,31 @@ def main():
         }
 
     # 5. the other configs + the CPU baseline (N=1: rank 0 alone; N>1: every rank takes part in the sharded pass)
+    printed, finished = threading.Event(), threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(res), flush=True)
+
     if not args.no_extras:
         if multi:
-            sh = extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, use_rccl=rccl_fallback is None)
+            # the headline above is measured; the sharded pass below must not be able to take it down with it: if a rank
+            # fails or the pass hangs, every rank leaves after the deadline and rank 0 prints the line with the error in it
+            deadline = float(os.environ.get("DCE_EXTRA_TIMEOUT", "240"))
+
+            def bail():
+                if not finished.wait(deadline):
+                    if rank == 0 and not printed.is_set():
+                        res.setdefault("extra", {"sharded_1e6": {"error": f"did not finish within {deadline:.0f} s"}})
+                    emit()
+                    os._exit(0)
+            threading.Thread(target=bail, daemon=True, name="bench-extra-deadline").start()
+            try:
+                sh = extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, use_rccl=rccl_fallback is None)
+            except Exception as e:                                # noqa: BLE001
+                sh = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
+                print(f"bench.py: extra.sharded_1e6 failed on rank {rank}: {e}", file=sys.stderr, flush=True)
             if rank == 0:
                 res["extra"] = {"sharded_1e6": sh}
         elif args.precision == "fp32":
@@ -646,9 +674,10 @@ def main():
             res["cpu_baseline"] = cpu_baseline(sd, windows.cpu().numpy(), seq_np, out["logits"].cpu().numpy(),
                                                out["pred"].cpu().numpy())
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
-        print(json.dumps(res))
+    emit()
     if multi:
         dist.barrier()
+        finished.set()
         dist.destroy_process_group()
 
 

@@ -54,6 +54,13 @@ constexpr int WINO1_MAX_N = 256;                             // <= this many win
 #ifndef WINO_PEEL
 #define WINO_PEEL 0
 #endif
+#ifndef WINO_PKINIT
+#define WINO_PKINIT 0
+#endif
+#ifndef WINO_RELU_ASM
+#define WINO_RELU_ASM 0      // 1: ReLU of the write-backs as asm v_max_f32 -- fmaxf() on a value that came out of inline asm (the
+                             // packed output transform) is preceded by a canonicalising v_max_f32 v, v, v: 40 extra per plain layer
+#endif
 #ifndef WINO1_PF
 #define WINO1_PF 8           // one-window kernels: weight prefetch depth, K-steps
 #endif
@@ -292,10 +299,27 @@ __device__ __forceinline__ void wino_mfma(const float* __restrict__ xrow, const 
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
+#if WINO_PKINIT
+            // accumulator init on 64-bit moves: 80 instructions per layer instead of 160
+            const v2f blo = {bias[mt][0], bias[mt][1]}, bhi = {bias[mt][2], bias[mt][3]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v2f lo, hi;
+                if (c == 1) {
+                    asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "=v"(lo) : "v"(blo));
+                    asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "=v"(hi) : "v"(bhi));
+                } else {
+                    asm volatile("v_pk_mov_b32 %0, 0, 0" : "=v"(lo));
+                    asm volatile("v_pk_mov_b32 %0, 0, 0" : "=v"(hi));
+                }
+                acc[mt][nt][c] = f32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+#else
             acc[mt][nt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[mt][nt][1] = bias[mt];
             acc[mt][nt][2] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[mt][nt][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
         }
 #pragma unroll 1
     for (int s = 0; s < STEPS; s += 2) {
@@ -416,8 +440,16 @@ __device__ __forceinline__ void wino_store_plain(float* __restrict__ act, const 
 #if WINO_EXP & 16
                         d[0] = acc[mt][nt][0][r]; d[1] = acc[mt][nt][1][r];     // timing probe: no output-transform VALU (WRONG results)
 #else
+#if WINO_RELU_ASM
+                        float r0, r1;
+                        asm("v_max_f32 %0, 0, %1" : "=v"(r0) : "v"(y0[e]));
+                        asm("v_max_f32 %0, 0, %1" : "=v"(r1) : "v"(y1[e]));
+                        d[0] = r0;
+                        d[1] = (T % 2 == 0 || 2 * m + 1 < T) ? r1 : 0.f;
+#else
                         d[0] = fmaxf(y0[e], 0.f);
                         d[1] = (T % 2 == 0 || 2 * m + 1 < T) ? fmaxf(y1[e], 0.f) : 0.f;   // index T+1 is a zero pad
+#endif
 #endif
                         if constexpr (TAPS) {
                             float* tp = tap + ((size_t)w * cout + co0 + 16 * mt + 4 * q + r) * T + 2 * m;

@@ -145,6 +145,66 @@ def comm_bootstrap(model, rank: int, world: int, key: str = "dce_comm_id"):
     return model
 
 
+def comm_bootstrap_checked(model, rank: int, world: int, device, key: str = "dce_comm_id", timeout: float | None = None):
+    """comm_bootstrap plus a first exchange whose CONTENT the root checks (four rows per rank, every byte = rank + 1,
+    through dce_gather_results), both under a watchdog, and a verdict every rank of the torch.distributed group agrees on.
+    Returns None when the library's communicator works on every rank; otherwise the reason, with this model's communicator
+    dropped, so that the caller can run its exchange over torch.distributed instead and SAY so.  (A communicator that
+    fails or hangs on one rank would otherwise take the whole job with it; DCE_COMM_TIMEOUT, default 180 s.)"""
+    import os
+    import threading
+    import torch
+    import torch.distributed as dist
+    if timeout is None:
+        timeout = float(os.environ.get("DCE_COMM_TIMEOUT", "180"))
+    verdict = {}
+    given_up = threading.Event()
+
+    def attempt():
+        try:
+            comm_bootstrap(model, rank, world, key=key)
+            if given_up.is_set():
+                raise RuntimeError("answered after the deadline")
+            if os.environ.get("DCE_COMM_SELFTEST") == "fail":       # tests: the path a failed first exchange takes
+                raise RuntimeError("DCE_COMM_SELFTEST=fail")
+            rows = 4
+            mine = torch.full((rows, PACK_COLS), (rank + 1) & 0xFF, dtype=torch.uint8, device=device)
+            got = model.gather_results(mine, None, root=0)
+            model.comm_sync()
+            if rank == 0:
+                want = (torch.arange(world, device=device).repeat_interleave(rows) + 1).to(torch.uint8)
+                if not bool((got == want[:, None]).all()):
+                    raise RuntimeError("the first gather delivered wrong bytes")
+            verdict["ok"] = True
+        except Exception as e:                                    # noqa: BLE001 -- any failure means: fall back
+            verdict["why"] = f"{type(e).__name__}: {e}"
+        if given_up.is_set():                                     # answered after the deadline: nobody uses this communicator
+            try:
+                model.comm_destroy()
+            except Exception:                                     # noqa: BLE001
+                pass
+            model.comm_world = 0
+
+    th = threading.Thread(target=attempt, daemon=True, name="dce-comm-bootstrap")
+    th.start()
+    th.join(timeout)
+    ok = bool(verdict.get("ok"))
+    why = verdict.get("why") or ("" if ok else f"no answer within {timeout:.0f} s")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                        device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()):
+        return None
+    given_up.set()
+    if not th.is_alive():
+        try:
+            model.comm_destroy()
+        except Exception:                                         # noqa: BLE001
+            pass
+    model.comm_world = 0
+    return why or "another rank failed"
+
+
 def infer_sequence_sharded(run, seq, group=None, dst: int = 0, n_windows: int | None = None, row_lo: int = 0, model=None):
     """Run `run(seq_rows) -> {'logits','pred','contacts'}` (e.g. contact_cnn.infer_sequence) on
     this rank's shard of the sequence and gather the results to rank `dst` in window order with a

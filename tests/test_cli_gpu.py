@@ -248,6 +248,23 @@ def test_bench_reports_a_fallback_when_rccl_cannot_be_bound():
     assert j["value"] > 1e6 and "torch.distributed" in j["extra"]["sharded_1e6"]["transport"]
 
 
+def test_bench_falls_back_when_the_first_exchange_fails():
+    """The library's communicator is brought up under a watchdog (comm_bootstrap_checked: init + a first gather whose
+    bytes rank 0 checks).  When that fails on a rank (DCE_COMM_SELFTEST=fail stands in for it) the ranks agree on the
+    verdict, the communicator is dropped and the exchange runs over torch.distributed -- the line says FALLBACK and why,
+    and the measurement itself is unharmed."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, DCE_FORCE_DIST="1", MASTER_PORT="29586", DCE_COMM_SELFTEST="fail")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--settle-s", "0.2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["rccl"]["backend"].startswith("FALLBACK") and "DCE_COMM_SELFTEST=fail" in j["rccl"]["backend"]
+    assert j["value"] > 1e6 and "torch.distributed" in j["extra"]["sharded_1e6"]["transport"]
+
+
 def test_bench_default_line_contract():
     """The line the driver records: `python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the
     contract's keys, the roofline and cpu_baseline objects, and every other BASELINE config measured under `extra`."""
