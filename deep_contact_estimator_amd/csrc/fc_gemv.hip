@@ -20,6 +20,15 @@
 
 namespace dce {
 
+// Chunks in flight per wave (the register ring is written out for 1, 2 and 4).  4 measured SLOWER than 2 at <= 8 windows
+// (fc.0 16.5 vs 15.1 us, 45.1 vs 43.0 us per predict() at one window, profiles/r3c_gemv_depth.txt): the kernel is not short
+// of bytes in flight -- a chunk's pass through LDS and its 128 chained fmaf are what a range costs.
+#ifndef GV_DEPTH1
+#define GV_DEPTH1 2                     // <= 8 windows
+#endif
+#ifndef GV_DEPTH2
+#define GV_DEPTH2 2                     // 9 .. 16 windows
+#endif
 constexpr int GV_R = 8;                 // neurons per workgroup
 constexpr int GV_CH = 128;              // floats of K per chunk
 constexpr int GV_LD = GV_CH + 4;        // padded LDS row
@@ -33,7 +42,7 @@ void fc_gemv_kernel(const float* __restrict__ A, const float* __restrict__ W,
                     const float* __restrict__ bias, float* __restrict__ C,
                     int M, int N, int K, int relu)
 {
-    static_assert(DEPTH == 1 || DEPTH == 2, "the register ring is written out for one or two chunks");
+    static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "the register ring is written out for one, two or four chunks");
     extern __shared__ __attribute__((aligned(16))) float gv_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = K range of the tree
@@ -102,12 +111,15 @@ void fc_gemv_kernel(const float* __restrict__ A, const float* __restrict__ W,
       compute();                                                                              \
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     const float4 *ap0 = ap[0], *ap1 = ap[MW > 1 ? 1 : 0], *ap2 = ap[MW > 2 ? 2 : 0], *ap3 = ap[MW > 2 ? 3 : 0];
-    GV_DECL(A) GV_DECL(B)
+    GV_DECL(A) GV_DECL(B) GV_DECL(C) GV_DECL(D)
     GV_FETCH(A, u0)
-    if constexpr (DEPTH == 2) GV_FETCH(B, u0 + 1)
+    if constexpr (DEPTH >= 2) GV_FETCH(B, u0 + 1)
+    if constexpr (DEPTH == 4) { GV_FETCH(C, u0 + 2) GV_FETCH(D, u0 + 3) }
     for (int u = u0; u < u1; u += DEPTH) {
         GV_STEP(A, u)
-        if constexpr (DEPTH == 2) { if (u + 1 < u1) GV_STEP(B, u + 1) }
+        if constexpr (DEPTH >= 2) { if (u + 1 < u1) GV_STEP(B, u + 1) }
+        if constexpr (DEPTH == 4) { if (u + 2 < u1) GV_STEP(C, u + 2)
+                                    if (u + 3 < u1) GV_STEP(D, u + 3) }
     }
 #undef GV_STEP
 #undef GV_STORE_J
@@ -138,9 +150,9 @@ void fc_gemv_kernel(const float* __restrict__ A, const float* __restrict__ W,
 hipError_t init_fc_gemv()
 {
     hipError_t e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemv_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemv_kernel<1, GV_DEPTH1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  gv_lds_floats<1>() * (int)sizeof(float))) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemv_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemv_kernel<2, GV_DEPTH2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  gv_lds_floats<2>() * (int)sizeof(float))) != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemv_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                gv_lds_floats<4>() * (int)sizeof(float));
@@ -155,8 +167,8 @@ hipError_t launch_fc_gemv(const float* A, const float* W, const float* bias, flo
         if (fc_tree_unit(K / GV_CH, r + 1) <= fc_tree_unit(K / GV_CH, r)) return hipErrorInvalidValue;
     const dim3 grid(N / GV_R), block(256);
     plan_note("fc_gemv");
-    if (M <= 8)       hipLaunchKernelGGL((fc_gemv_kernel<1, 2>), grid, block, gv_lds_floats<1>() * sizeof(float), st, A, W, bias, C, (int)M, N, K, relu);
-    else if (M <= 16) hipLaunchKernelGGL((fc_gemv_kernel<2, 2>), grid, block, gv_lds_floats<2>() * sizeof(float), st, A, W, bias, C, (int)M, N, K, relu);
+    if (M <= 8)       hipLaunchKernelGGL((fc_gemv_kernel<1, GV_DEPTH1>), grid, block, gv_lds_floats<1>() * sizeof(float), st, A, W, bias, C, (int)M, N, K, relu);
+    else if (M <= 16) hipLaunchKernelGGL((fc_gemv_kernel<2, GV_DEPTH2>), grid, block, gv_lds_floats<2>() * sizeof(float), st, A, W, bias, C, (int)M, N, K, relu);
     else              hipLaunchKernelGGL((fc_gemv_kernel<4, 1>), grid, block, gv_lds_floats<4>() * sizeof(float), st, A, W, bias, C, (int)M, N, K, relu);
     return hipGetLastError();
 }
