@@ -71,6 +71,28 @@ def main(tag):
             rbytes = 32 * r32 + 64 * r64 + 128 * max(rd - r32 - r64, 0)
             lines.append(f"| {NAMES[k]} | {hit:.3f} | {c.get('TCC_REQ', 0):.3g} | {rd:.3g} | {r32:.3g} / {r64:.3g} | {rbytes / 1e6:.1f} MB | {algo / 1e6:.1f} MB |")
             latest[NAMES[k]].update({"l2_hit_rate": hit, "fabric_read_bytes_per_launch": rbytes})
+    # bf16-FC mode: per-CU-cycle rates of the GEMMs (GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ counters over all 256 CUs x 4 SIMDs
+    # as the fp32 table's MFMA-busy normalisation has it)
+    b16 = {}
+    for part in ("bf16sq", "bf16lds", "bf16tcc"):
+        p = os.path.join(out, f"{tag}_pmc_{part}", f"{tag}_counter_collection.csv")
+        if os.path.exists(p):
+            for k, v in pmc_summary.main([p]).items():
+                b16.setdefault(k, {}).update(v)
+    if b16:
+        lines += ["", "bf16-FC mode (`--precision bf16_fc`), same step:", "",
+                  "| kernel | MFMA busy | LDS busy: SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE/8) | bank-conflict cycles / LDS active | LDS instructions per launch | L2 hit rate | TCC_REQ |",
+                  "|---|---|---|---|---|---|---|"]
+        for k in ("conv_stack", "fc1_gemm_bf16", "fc2_gemm_bf16"):
+            c = b16.get(k)
+            if not c or "GRBM_GUI_ACTIVE" not in c:
+                continue
+            cyc = c["GRBM_GUI_ACTIVE"] / 8
+            busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc
+            lds = c.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / cyc
+            hit = c.get("TCC_HIT", 0) / max(c.get("TCC_HIT", 0) + c.get("TCC_MISS", 0), 1)
+            lines.append(f"| {k} | {busy:.3f} | {lds:.3f} | {c.get('SQ_LDS_BANK_CONFLICT', 0):.3g} / {c.get('SQ_LDS_IDX_ACTIVE', 0):.3g} | "
+                         f"{c.get('SQ_INSTS_LDS', 0):.3g} | {hit:.3f} | {c.get('TCC_REQ', 0):.3g} |")
     # the build these counters were taken on (tools/profile_gpu.sh records the hash of the .so's sources on the box):
     # bench.py marks roofline.traffic stale when the library it times was built from other sources
     hp = os.path.join(out, f"{tag}_source_hash.txt")

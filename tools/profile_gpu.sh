@@ -16,5 +16,10 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_
 # L2 (TCC) view of the same step: hit rate, and the read requests it sends on to the fabric (Infinity Fabric -> MALL -> HBM) by size
 rocprofv3 --kernel-trace --pmc TCC_HIT TCC_MISS TCC_REQ TCC_READ --output-format csv -d $OUT/${TAG}_pmc_tcc1 -o ${TAG} -- $B > $OUT/${TAG}_pmc_tcc1.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_DRAM --output-format csv -d $OUT/${TAG}_pmc_tcc2 -o ${TAG} -- $B > $OUT/${TAG}_pmc_tcc2.log 2>&1
+# bf16-FC mode (BASELINE configs[4]): what binds its GEMMs -- matrix pipe, LDS, L2
+BB="$B --precision bf16_fc"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_bf16sq -o ${TAG} -- $BB > $OUT/${TAG}_pmc_bf16sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_bf16lds -o ${TAG} -- $BB > $OUT/${TAG}_pmc_bf16lds.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT TCC_MISS TCC_REQ TCC_READ --output-format csv -d $OUT/${TAG}_pmc_bf16tcc -o ${TAG} -- $BB > $OUT/${TAG}_pmc_bf16tcc.log 2>&1
 find $OUT -name "${TAG}*" -type f | head -40
 for f in $OUT/${TAG}_*.log; do echo "== $f"; grep -E '"metric"|rror' $f | cut -c1-300; done
