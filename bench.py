@@ -82,7 +82,14 @@ def kernel_peak(kernel, precision):
     """Peak of the pipe the kernel's dominant arithmetic runs on."""
     if precision == "bf16_fc" and kernel in ("fc1_gemm", "fc2_gemm"):
         return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA"
+    if precision == "fp32_split" and kernel == "fc1_gemm":
+        return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA, six bf16 x bf16 terms per fp32 product (fc_gemm_x3.hip; the launch's operand split is inside the time)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA" if kernel != "fc3_tail" else "fp32 VALU (= fp32 MFMA rate)"
+
+
+def exec_flop(kernel, precision):
+    """Matrix-pipe FLOPs issued per window by the kernel in this precision mode."""
+    return 6 * EXEC_FLOP[kernel] if precision == "fp32_split" and kernel == "fc1_gemm" else EXEC_FLOP[kernel]
 
 
 def kernel_table(prof, B, precision):
@@ -92,7 +99,7 @@ def kernel_table(prof, B, precision):
             continue
         avg_s = v["ms"] / v["launches"] * 1e-3
         peak, pipe = kernel_peak(k, precision)
-        ex = EXEC_FLOP[k] * B / avg_s / 1e12
+        ex = exec_flop(k, precision) * B / avg_s / 1e12
         out[k] = {
             "avg_ms": avg_s * 1e3, "launches": v["launches"], "pipe": pipe, "peak_tflops": peak,
             "executed_tflops": ex, "frac": ex / peak,
@@ -104,7 +111,7 @@ def kernel_table(prof, B, precision):
 
 def path_roof(precision):
     """Windows/s if every kernel ran at the peak of its pipe on the FLOPs it issues."""
-    t = sum(EXEC_FLOP[k] / (kernel_peak(k, precision)[0] * 1e12) for k in ("conv_stack", "fc1_gemm", "fc2_gemm", "fc3_tail"))
+    t = sum(exec_flop(k, precision) / (kernel_peak(k, precision)[0] * 1e12) for k in ("conv_stack", "fc1_gemm", "fc2_gemm", "fc3_tail"))
     return 1.0 / t
 
 
@@ -338,9 +345,17 @@ def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000):
             "us_per_push": dt * 1e6, "pushes": k, "samples_per_s": 1.0 / dt}
 
 
-def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s=1.5):
-    """BASELINE configs[4]: fc.0 / fc.3 on bf16 MFMA (fp32 accumulate), conv stack and fc.6 fp32."""
-    m = contact_cnn(device=dev.index, max_batch=B, precision="bf16_fc")
+MODE_TEXT = {
+    "bf16_fc": "BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; conv stack and fc.6 fp32",
+    "fp32_split": "the bench step ({B} windows) with fc.0 on the bf16 matrix pipe, every fp32 operand as three bf16 terms (six MFMAs per "
+                  "product, fp32 accumulate: fp32 results, not the fp32 path's bits -- opt-in, include/dce.h DCE_FP32_SPLIT); everything else fp32 MFMA",
+}
+
+
+def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s=1.5, precision="bf16_fc"):
+    """BASELINE configs[4]: fc.0 / fc.3 on bf16 MFMA (fp32 accumulate), conv stack and fc.6 fp32 -- or another precision mode
+    of the library on the same step."""
+    m = contact_cnn(device=dev.index, max_batch=B, precision=precision)
     m.load_state_dict(sd).eval()
     settle(torch, lambda: m.predict(windows), settle_s)
     torch.cuda.synchronize()
@@ -354,19 +369,18 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
     torch.cuda.synchronize()
     prof = m.profile_read(reset=True)
     m.profile(0)
-    kern = kernel_table(prof, B, "bf16_fc")
+    kern = kernel_table(prof, B, precision)
     lg, lr = out["logits"], ref_out["logits"]
     flips = int((out["pred"] != ref_out["pred"]).sum().item())
     res = {
-        "workload": f"BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; "
-                    "conv stack and fc.6 fp32",
+        "workload": MODE_TEXT[precision].format(B=B),
         "windows_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
         "vs_fp32_same_input": {"max_abs_dlogit": float((lg - lr).abs().max().item()),
                                "max_abs_logit": float(lr.abs().max().item()),
                                "argmax_flips": flips, "argmax_flip_rate": flips / B},
         "kernels": kern,
-        "path_roof_windows_per_s": path_roof("bf16_fc"),
-        "path_frac_of_roof": (B * steps / dt) / path_roof("bf16_fc"),
+        "path_roof_windows_per_s": path_roof(precision),
+        "path_frac_of_roof": (B * steps / dt) / path_roof(precision),
     }
     m.close()
     return res
@@ -435,8 +449,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip extra.* (configs[2]/[3]/[4] measurements)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the profiled pass (no roofline block)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc"],
-                    help="fp32 = the headline (exact fp32 MFMA); bf16_fc = BASELINE configs[4] as the main workload")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "fp32_split"],
+                    help="fp32 = the headline (exact fp32 MFMA); bf16_fc = BASELINE configs[4] as the main workload; "
+                         "fp32_split = fc.0 on three-term bf16 operands (fp32 results on the bf16 matrix pipe)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -576,7 +591,8 @@ def main():
             "metric": METRIC, "value": wps, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 conv + bf16 FC (f32 accumulate)", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16_fc": "f32 conv + bf16 FC (f32 accumulate)",
+                      "fp32_split": "f32 (fc.0: f32 operands as three bf16 terms on bf16 MFMA, f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: {B} pre-normalised windows (B,150,54) fp32 per GPU per step, "
                             "HBM-resident -> fused conv stack + fc1/fc2/fc3 -> logits+argmax+contact bits "
@@ -668,6 +684,7 @@ def main():
                 "online_push": extra_online(contact_cnn, sd, dev, seq_np),
                 "streaming_1e6": extra_streaming(torch, contact_cnn, sd, dev),
                 "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s),
+                "fp32_split": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s, precision="fp32_split"),
             }
     if rank == 0:
         if world == 1 and not multi and not args.no_cpu_baseline:

@@ -25,7 +25,7 @@ from .synth import STATE_DICT_SHAPES
 
 WINDOW, CHANNELS, CLASSES = 150, 54, 16
 PACKED_ROW = 68                        # include/dce.h DCE_PACKED_ROW: 16 fp32 logits + 4 contact bits
-PRECISIONS = {"fp32": 0, "bf16_fc": 1}
+PRECISIONS = {"fp32": 0, "bf16_fc": 1, "fp32_split": 2}   # fp32_split: fc.0 on three-term bf16 operands (include/dce.h DCE_FP32_SPLIT)
 
 
 def _is_torch(x) -> bool:
@@ -375,7 +375,7 @@ class contact_cnn:
         self._check_windows(a)
         n = a.shape[0]
         out = {"h2": np.empty((n, 512), np.float32), "logits": np.empty((n, CLASSES), np.float32)}
-        act = np.float32 if self._precision == "fp32" else np.uint16     # bf16-FC mode: the bf16 bit patterns
+        act = np.uint16 if self._precision == "bf16_fc" else np.float32     # bf16-FC mode: the bf16 bit patterns
         out["feat"] = np.empty((n, 4736), act)
         out["h1"] = np.empty((n, 2048), act)
         p = lambda k: out[k].ctypes.data_as(C.c_void_p) if k in out else None

@@ -64,6 +64,7 @@ Tuning tuning_from_env()
     t.one_per_cu = getenv("DCE_ONE_PER_CU") != nullptr;
     t.trace_wino1 = getenv("DCE_TRACE_WINO1") != nullptr;
     t.conv4 = (int)num("DCE_CONV4", 0);
+    t.x3_min_tiles = (int)num("DCE_X3_MIN_TILES", t.x3_min_tiles);
     return t;
 }
 
@@ -139,6 +140,12 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
         // (from 9 windows up launch_fc_gemm picks the MFMA chain kernel of fc_gemm_chain.hip instead)
         auto fc = (c->gemv && n <= FC_GEMV_MAX_M && !fc_split_ok(n, FC1, FEAT) && !fc_gemm_chain_ok(n, FC1, FEAT)) ? launch_fc_gemv : launch_fc_gemm;
+        if (c->precision == DCE_FP32_SPLIT && fc_gemm_x3_ok(n, FC1, FEAT)) {
+            // fc.0 on the bf16 matrix pipe with three-term operands (fc_gemm_x3.hip); everything else as in DCE_FP32
+            Timer t(c, 1);
+            HIP_TRY(c, launch_split3(c->feat, c->feat3, n, FEAT, c->stream));
+            HIP_TRY(c, launch_fc_gemm_x3(c->feat3, c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream));
+        } else
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
         if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1) && !fc_split_ok(n, FC2, FC1)) {
             // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU
@@ -329,6 +336,7 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     CREATE_TRY(init_conv_stack());
     CREATE_TRY(init_conv_wino());
     CREATE_TRY(init_fc_gemm());
+    CREATE_TRY(init_fc_gemm_x3());
     CREATE_TRY(hipMalloc(&c->feat, (size_t)max_batch * FEAT * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h1, (size_t)max_batch * FC1 * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h2, (size_t)max_batch * FC2 * sizeof(float)));
@@ -353,7 +361,7 @@ void dce_destroy(dce_ctx* c)
     if (c->xstream_ev) hipEventDestroy(c->xstream_ev);
     if (c->xfer_stream) { hipStreamSynchronize(c->xfer_stream); hipStreamDestroy(c->xfer_stream); }
     for (auto& slot : c->ring_ev) for (auto e : slot) if (e) hipEventDestroy(e);
-    hipFree(c->d_weights); hipFree(c->feat); hipFree(c->h1); hipFree(c->h2); hipFree(c->part);
+    hipFree(c->d_weights); hipFree(c->feat); hipFree(c->feat3); hipFree(c->h1); hipFree(c->h2); hipFree(c->part);
     hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
     if (c->online_exec) hipGraphExecDestroy(c->online_exec);
     if (c->online_graph) hipGraphDestroy(c->online_graph);
@@ -403,8 +411,8 @@ int dce_load_weight(dce_ctx* c, const char* key, const float* host, const int64_
 int dce_finalize_weights(dce_ctx* c, int precision)
 {
     if (!c) return DCE_ERR_ARG;
-    if (precision != DCE_FP32 && precision != DCE_BF16_FC)
-        return fail(c, DCE_ERR_ARG, "unknown precision %d (0 = fp32, 1 = bf16 FC)", precision);
+    if (precision != DCE_FP32 && precision != DCE_BF16_FC && precision != DCE_FP32_SPLIT)
+        return fail(c, DCE_ERR_ARG, "unknown precision %d (0 = fp32, 1 = bf16 FC, 2 = fp32 with fc.0 on three-term bf16 operands)", precision);
     for (int k = 0; k < 14; ++k)
         if (!c->have[k]) return fail(c, DCE_ERR_STATE, "missing state_dict key '%s'", kKeys[k].name);
     DEVICE_GUARD(c);
@@ -444,6 +452,14 @@ int dce_finalize_weights(dce_ctx* c, int precision)
             }
         }
     }
+    size_t off_x3 = 0;
+    if (precision == DCE_FP32_SPLIT) {
+        // fc.0's weights as three bf16 planes [3][2048][4736]: w = w1 + w2 + w3 exactly
+        const auto& v = c->host_w[8];
+        off_x3 = reserve((3 * v.size() + 1) / 2);
+        split3_host(v.data(), FC1, FEAT, reinterpret_cast<unsigned short*>(img.data() + off_x3));
+        if (!c->feat3) HIP_TRY(c, hipMalloc(&c->feat3, (size_t)(c->max_batch + 1) * FEAT * 3 * sizeof(unsigned short)));
+    }
     if (c->d_weights) { HIP_TRY(c, hipFree(c->d_weights)); c->d_weights = nullptr; }
     HIP_TRY(c, hipMalloc(&c->d_weights, img.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -456,6 +472,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     c->fc3w = c->d_weights + off_fc[4]; c->fc3b = c->d_weights + off_fc[5];
     c->fc1w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[0] : nullptr;
     c->fc2w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[1] : nullptr;
+    c->fc1w_x3 = precision == DCE_FP32_SPLIT ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3) : nullptr;
     c->precision = precision;
     c->finalized = true;
     return DCE_OK;

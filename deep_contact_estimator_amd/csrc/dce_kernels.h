@@ -27,6 +27,7 @@ struct Tuning {
     long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // DCE_WINO1_MAX / DCE_WINOH_MAX / DCE_WINOQ_MAX (-1: kernel default)
     bool wino1_w8 = true;                                   // DCE_WINO1_WAVES=4 -> false
     bool one_per_cu = false, trace_wino1 = false;           // DCE_ONE_PER_CU, DCE_TRACE_WINO1 (trace builds)
+    int x3_min_tiles = 192;                                 // DCE_X3_MIN_TILES: 256x128 tiles a launch needs for the split-bf16 fc.0 kernel
     int conv4 = 0;                                          // DCE_CONV4=1: four row tiles per wave in the two-window conv kernel (A/B; slower)
 };
 Tuning tuning_from_env();
@@ -122,6 +123,15 @@ hipError_t launch_fc_split(const float* A, const float* W, const float* bias, fl
 // C fp32 or bf16 (out_bf16).  N % 128 == 0, K % 64 == 0.  DCE_BF16_FC precision only.
 hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, void* C, int out_bf16,
                                int64_t M, int N, int K, int relu, hipStream_t st);
+
+// fc.0 with fp32 operands carried as three bf16 terms each (fc_gemm_x3.hip, precision DCE_FP32_SPLIT): A3 = [3][M][K],
+// W3 = [3][N][K] bf16 planes (launch_split3 / split3_host make them), C fp32.  256x128 tiles that fill the chip only.
+hipError_t init_fc_gemm_x3();
+bool       fc_gemm_x3_ok(int64_t M, int N, int K);
+void       split3_host(const float* x, size_t rows, size_t cols, unsigned short* planes);
+hipError_t launch_split3(const float* x, unsigned short* planes, int64_t rows, int cols, hipStream_t st);
+hipError_t launch_fc_gemm_x3(const unsigned short* A3, const unsigned short* W3, const float* bias, float* C,
+                             int64_t M, int N, int K, int relu, hipStream_t st);
 
 // The same GEMMs at chip-filling sizes (fc_gemm_phased.hip): one workgroup per CU, 256x128 or 128x64 tiles,
 // LDS-DMA staging, two wave groups one phase apart; fp32 (bit-identical to the tile kernels: same K order) and

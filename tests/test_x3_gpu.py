@@ -1,0 +1,135 @@
+"""GPU (-m gpu): the DCE_FP32_SPLIT precision ("fp32_split") -- fc.0 of reference src/contact_cnn.py:48-49 at chip-filling
+batches on the bf16 matrix pipe, every fp32 operand as three bf16 terms (csrc/fc_gemm_x3.hip).
+
+The mode claims fp32 results, so it is held to the SAME contract as the fp32 path: |got - ref| <= 1e-5 max|ref| +
+1e-4 |ref| against the oracle (fp64 accumulation of the reference's arithmetic), argmax exact outside the noise margin.
+It does not claim the fp32 path's bits; what it must keep is everything that is not fc.0 at a large batch.
+"""
+import numpy as np
+import pytest
+
+from conftest import tol_ok
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def pair():
+    """(fp32 model, fp32_split model) on the bench checkpoint."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    sd = synth.make_state_dict(1, "uniform")
+    a = contact_cnn(device=0, max_batch=8192); a.load_state_dict(sd).eval()
+    b = contact_cnn(device=0, max_batch=8192, precision="fp32_split"); b.load_state_dict(sd).eval()
+    yield sd, a, b
+    a.close(); b.close()
+
+
+def _argmax_ok(got_pred, ref_logits, ref_pred):
+    srt = np.sort(ref_logits, axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 1e-3 * np.abs(ref_logits).max()
+    assert np.array_equal(got_pred[safe], ref_pred[safe])
+    flips = int((got_pred != ref_pred).sum())
+    assert flips <= max(1, int(2e-3 * len(ref_pred))), flips
+    return flips
+
+
+def test_split_terms_are_exact():
+    """a = a1 + a2 + a3 with bf16 terms, exactly, for normal fp32 values (the host routine that splits fc.0's weights is
+    the device routine that splits the features)."""
+    import ctypes as C
+    from deep_contact_estimator_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(4000).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, 4000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.17549435e-38, 65504.0, 1 + 2.0 ** -23, 1 - 2.0 ** -24], np.float32)])
+    planes = np.zeros((3, x.size), np.uint16)
+    lib.dce_debug_split3(x.ctypes.data_as(C.c_void_p), C.c_size_t(x.size), planes.ctypes.data_as(C.c_void_p))
+    terms = (planes.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    s = terms.sum(0)
+    ok = np.abs(x) < 3.3e38
+    assert np.array_equal(s[ok], x.astype(np.float64)[ok])
+    # every term is a bf16 number by construction; the first is the value rounded to nearest-even
+    u = x.view(np.uint32).astype(np.uint64)
+    rne = (((u + 0x7fff + ((u >> 16) & 1)) >> 16) & 0xffff).astype(np.uint16)
+    assert np.array_equal(planes[0][ok], rne[ok])
+
+
+@pytest.mark.parametrize("n", [3072, 4096, 4100, 8192])
+def test_split_mode_meets_the_fp32_contract(n, pair, orc):
+    """Every row of a chip-filling batch against the oracle, with the tolerance of the fp32 path; the plan shows that fc.0
+    really ran on the split kernel (and that 4100 = a ragged last tile went through it too)."""
+    from deep_contact_estimator_amd import synth
+    sd, a, b = pair
+    seq = synth.make_sequence(n + 149, seed=2).astype(np.float32)
+    w = b.zscore_windows(seq, 0, n)
+    out = b.predict(w)
+    assert "fc_x3_256x128" in b.last_plan() and "split3" in b.last_plan(), b.last_plan()
+    ref = orc.Oracle(sd).forward_windows(w if isinstance(w, np.ndarray) else w.cpu().numpy())
+    tol_ok(out["logits"], ref["logits"], f"fp32_split, {n} rows vs oracle")
+    flips = _argmax_ok(out["pred"], ref["logits"], ref["pred"])
+    assert np.array_equal(out["contacts"], orc.decimal2binary(out["pred"]))
+    # against the fp32 MFMA path on the same input: both are fp32 evaluations, a few ulps of the largest logit apart
+    nat = a.predict(w)
+    d = np.abs(out["logits"].astype(np.float64) - nat["logits"]).max()
+    scale = np.abs(ref["logits"]).max()
+    e_split = np.abs(out["logits"].astype(np.float64) - ref["logits"]).max()
+    e_nat = np.abs(nat["logits"].astype(np.float64) - ref["logits"]).max()
+    print(f"n={n}: max|split - oracle| {e_split:.2e}, max|fp32 - oracle| {e_nat:.2e}, max|split - fp32| {d:.2e}, scale {scale:.2f}, flips {flips}")
+    assert d < 2e-5 * scale
+    assert e_split < 4 * max(e_nat, 1e-6 * scale)            # same error class as the fp32 fmaf chains, not a bf16-sized one
+
+
+def test_split_mode_h1_against_fp64_on_the_device_features(pair):
+    """fc.0 alone: ReLU(feat W1^T + b1) of the split kernel against an fp64 evaluation on the features the device itself
+    produced -- the layer the mode replaces, isolated from everything around it."""
+    from deep_contact_estimator_amd import synth
+    sd, a, b = pair
+    n = 3072
+    x = np.random.default_rng(77).standard_normal((n, 150, 54), dtype=np.float32)
+    t = b.forward_taps(x)
+    assert "fc_x3_256x128" in b.last_plan()
+    feat = t["feat"].astype(np.float64)
+    w1 = np.asarray(sd["fc.0.weight"], np.float64)
+    b1 = np.asarray(sd["fc.0.bias"], np.float64)
+    rows = np.r_[0:40, 1500:1540, n - 40:n]                  # first / middle / last tiles
+    ref = np.maximum(feat[rows] @ w1.T + b1, 0.0)
+    tol_ok(t["h1"][rows], ref, "h1 of the split kernel vs fp64")
+    # and the features themselves are the fp32 path's bits (the conv stack is untouched)
+    assert np.array_equal(t["feat"], a.forward_taps(x)["feat"])
+
+
+@pytest.mark.parametrize("n", [1, 30, 700, 2800])
+def test_split_mode_below_the_tile_threshold_is_the_fp32_path(n, pair):
+    """Batches whose 256x128 tiles do not fill the chip run the fp32 kernels: the same bits as DCE_FP32."""
+    sd, a, b = pair
+    x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
+    ra, rb = a.predict(x), b.predict(x)
+    assert "fc_x3_256x128" not in b.last_plan()
+    for k in ("logits", "pred", "contacts"):
+        assert np.array_equal(ra[k], rb[k]), k
+
+
+def test_split_mode_nan_window_and_sequence_path(pair, orc):
+    """A window with a NaN sample yields NaN logits / class 0 for that window only (torch's behaviour, pinned for the fp32
+    path by edge.npz); and the streaming entry (dce_infer_sequence, chunks of max_batch) runs the same kernels."""
+    from deep_contact_estimator_amd import synth
+    sd, a, b = pair
+    n = 4096
+    x = np.random.default_rng(3).standard_normal((n, 150, 54), dtype=np.float32)
+    x[100, 7, 3] = np.nan
+    out = b.predict(x)
+    assert np.isnan(out["logits"][100]).all() and out["pred"][100] == 0
+    keep = np.ones(n, bool); keep[100] = False
+    assert np.isfinite(out["logits"][keep]).all()
+    seq = synth.make_sequence(8192 + 4096 + 149, seed=11).astype(np.float32)     # chunks of 8192 and 4096 windows
+    s = b.infer_sequence(seq)
+    assert "fc_x3_256x128" in b.last_plan()
+    ref = a.infer_sequence(seq)
+    assert np.abs(s["logits"] - ref["logits"]).max() < 2e-5 * np.abs(ref["logits"]).max()
+    assert (s["pred"] != ref["pred"]).sum() <= 2
