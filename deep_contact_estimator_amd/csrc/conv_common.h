@@ -34,6 +34,30 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
 __device__ __forceinline__ void put_feat(float* p, float v) { *p = v; }
 __device__ __forceinline__ void put_feat(unsigned short* p, float v) { *p = f32_to_bf16_rne(v); }
 
+// DCE_FP32_SPLIT: the features as THREE bf16 planes, v = t1 + t2 + t3 exactly, in the pair-interleaved layout the
+// split-bf16 fc.0 kernel reads (fc_gemm_x3.hip: element (r, k) of a plane at (r >> 1) * 2K + (k >> 5) * 64 + (r & 1) * 32
+// + (k & 31); plane stride = rows rounded up to even, times K).
+struct Feat3 { unsigned short u; };
+typedef __bf16 cc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float cc_f32x2 __attribute__((ext_vector_type(2)));
+// two values at once: v_cvt_pk_bf16_f32 (round-to-nearest-even, as split3_kernel and the host routine round) turns a pair
+// into its three terms in 9 VALU instructions; the six 16-bit stores go to (row, k0) and (row, k1)
+__device__ __forceinline__ void put_feat3(Feat3* planes, size_t plane_elems, int64_t row, int k0, int k1, float v0, float v1)
+{
+    const cc_f32x2 v = {v0, v1};
+    const cc_bf16x2 t1 = __builtin_convertvector(v, cc_bf16x2);
+    const cc_f32x2 r1 = v - __builtin_convertvector(t1, cc_f32x2);          // exact
+    const cc_bf16x2 t2 = __builtin_convertvector(r1, cc_bf16x2);
+    const cc_f32x2 r2 = r1 - __builtin_convertvector(t2, cc_f32x2);         // exact
+    const cc_bf16x2 t3 = __builtin_convertvector(r2, cc_bf16x2);
+    const unsigned p1 = __builtin_bit_cast(unsigned, t1), p2 = __builtin_bit_cast(unsigned, t2), p3 = __builtin_bit_cast(unsigned, t3);
+    unsigned short* base = reinterpret_cast<unsigned short*>(planes) + (size_t)(row >> 1) * (2 * FEAT) + (int)(row & 1) * 32;
+    unsigned short* d0 = base + (k0 >> 5) * 64 + (k0 & 31);
+    unsigned short* d1 = base + (k1 >> 5) * 64 + (k1 & 31);
+    d0[0] = (unsigned short)p1; d0[plane_elems] = (unsigned short)p2; d0[2 * plane_elems] = (unsigned short)p3;
+    d1[0] = (unsigned short)(p1 >> 16); d1[plane_elems] = (unsigned short)(p2 >> 16); d1[2 * plane_elems] = (unsigned short)(p3 >> 16);
+}
+
 // Load NWIN windows (rows t = 4m + g of channel c per thread, tid = g*54 + c < 216) and, if ZS,
 // z-score them per channel over time exactly as utils/data_handler.py:55-56 does on fp32 data:
 //   (x - mean) / std,  mean = sum/150 rounded to fp32,  std = sqrt(sum((x-mean)^2)/149) (unbiased,

@@ -30,6 +30,7 @@
 //   stage 1 (T=150): WSEG 152, RS 306, 75 pairs/window       stage 2 (T=75): WSEG 78, RS 156, 38 pairs
 #include "conv_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace dce {
 
@@ -505,7 +506,7 @@ __device__ __forceinline__ void wino_store_pool_stage2(float* __restrict__ act, 
 template <typename FT, int MT = dce::MT, int NTW = dce::NTW, int NWIN = NW, bool TAPS = false>
 __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t win0, int nvalid,
                                                 const f32x4 (&acc)[MT][NTW][4], int co0, int lane,
-                                                bool nan0, bool nan1, float* __restrict__ tap_conv4 = nullptr)
+                                                bool nan0, bool nan1, float* __restrict__ tap_conv4 = nullptr, size_t plane_elems = 0)
 {
     const int j = lane & 15, q = lane >> 4;
     // one 64-bit address per column tile; the 8 (row tile, r) outputs of a lane sit at compile-time offsets from it
@@ -532,7 +533,7 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
             }
         }
         if (colv && m < 37 && w < nvalid) {
-            FT* base = feat + (win0 + w) * FEAT + (co0 + 4 * q) * 37 + m;
+            FT* base = feat + (std::is_same<FT, Feat3>::value ? 0 : (win0 + w) * FEAT + (co0 + 4 * q) * 37 + m);
             const bool bad = w ? nan1 : nan0;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -540,14 +541,22 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
                 for (int h = 0; h < 2; ++h) {
                     v2f y0, y1;
                     wino_out2(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3], h, y0, y1);
+                    float vv[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
 #if WINO_EXP & 16
-                        const float v = acc[mt][nt][0][2 * h + e];
+                        vv[e] = acc[mt][nt][0][2 * h + e];
 #else
-                        const float v = fmaxf(fmaxf(y0[e], y1[e]), 0.f);
+                        vv[e] = fmaxf(fmaxf(y0[e], y1[e]), 0.f);
 #endif
-                        put_feat(base + (16 * mt + 2 * h + e) * 37, bad ? nanv : v);
+                        if (bad) vv[e] = nanv;
+                    }
+                    if constexpr (std::is_same<FT, Feat3>::value) {
+                        const int k0 = (co0 + 4 * q + 16 * mt + 2 * h) * 37 + m;
+                        put_feat3(base, plane_elems, win0 + w, k0, k0 + 37, vv[0], vv[1]);
+                    } else {
+                        put_feat(base + (16 * mt + 2 * h) * 37, vv[0]);
+                        put_feat(base + (16 * mt + 2 * h + 1) * 37, vv[1]);
                     }
                 }
         }
@@ -682,7 +691,8 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
         TRACE_MARK(7);
         wino_mfma<RS2, 32>(xrow2, boff, ap4, a, bias_lds + 256, co2, lane, acc);
         TRACE_MARK(8);
-        wino_store_feat<FT, MT, NTW, NW, TAPS>(feat, win0, nvalid, acc, co2, lane, nan0, nan1, TAPS ? taps.conv4 + win0 * 128 * 75 : nullptr);
+        wino_store_feat<FT, MT, NTW, NW, TAPS>(feat, win0, nvalid, acc, co2, lane, nan0, nan1, TAPS ? taps.conv4 + win0 * 128 * 75 : nullptr,
+                                               (size_t)((n + 1) & ~(int64_t)1) * FEAT);
         TRACE_MARK(9);
     }
 }
@@ -1456,6 +1466,8 @@ hipError_t init_conv_wino()
     if ((e = grant_wino_lds<false, float>()) != hipSuccess) return e;
     if ((e = grant_wino_lds<true, unsigned short>()) != hipSuccess) return e;
     if ((e = grant_wino_lds<false, unsigned short>()) != hipSuccess) return e;
+    if ((e = grant_wino_lds<true, Feat3>()) != hipSuccess) return e;
+    if ((e = grant_wino_lds<false, Feat3>()) != hipSuccess) return e;
     for (const void* k : {reinterpret_cast<const void*>(&conv_wino1_kernel<true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false>),
                           reinterpret_cast<const void*>(&conv_wino1x8_kernel<true>), reinterpret_cast<const void*>(&conv_wino1x8_kernel<false>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
@@ -1548,7 +1560,7 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
         else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
         return hipGetLastError();
     }
-    if (tu.conv4 > 0) {           // DCE_CONV4=1: four row tiles per wave (A/B; measured 3.8 % SLOWER end to end, see the kernel's header)
+    if (tu.conv4 > 0 && feat_bf16 != 2) {           // DCE_CONV4=1: four row tiles per wave (A/B; measured 3.8 % SLOWER end to end, see the kernel's header)
         plan_note("conv_wino2_rt4");
         if (feat_bf16) {
             unsigned short* f = static_cast<unsigned short*>(feat);
@@ -1559,6 +1571,13 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
             if (zscore) hipLaunchKernelGGL((conv_wino_rt4_kernel<true, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
             else        hipLaunchKernelGGL((conv_wino_rt4_kernel<false, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
         }
+        return hipGetLastError();
+    }
+    if (feat_bf16 == 2) {                                // DCE_FP32_SPLIT: the features leave as three bf16 planes (conv_common.h put_feat3)
+        plan_note("conv_wino2_feat3");
+        Feat3* f = static_cast<Feat3*>(feat);
+        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, Feat3>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+        else        hipLaunchKernelGGL((conv_wino_kernel<false, Feat3>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
         return hipGetLastError();
     }
     plan_note("conv_wino2");

@@ -65,6 +65,7 @@ Tuning tuning_from_env()
     t.trace_wino1 = getenv("DCE_TRACE_WINO1") != nullptr;
     t.conv4 = (int)num("DCE_CONV4", 0);
     t.x3_min_tiles = (int)num("DCE_X3_MIN_TILES", t.x3_min_tiles);
+    t.x3_unfused = getenv("DCE_X3_UNFUSED") != nullptr;
     return t;
 }
 
@@ -136,14 +137,20 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         }
         { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, c->stream)); }
     } else {
-        { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream, c->src_row_dev)); }
+        // DCE_FP32_SPLIT at a chip-filling batch: the conv stack writes the features straight as three bf16 planes
+        // (unless a tap wants them in fp32, or the direct-form conv kernel is selected: then a kernel of its own splits them)
+        const bool x3 = c->precision == DCE_FP32_SPLIT && fc_gemm_x3_ok(n, FC1, FEAT);
+        const bool x3_fused = x3 && c->winograd && !c->want_feat && !c->tuning.x3_unfused;
+        { Timer t(c, 0);
+          if (x3_fused) HIP_TRY(c, launch_conv_wino(src, zscore, n, c->pk, c->feat3, 2, c->stream, c->src_row_dev));
+          else HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream, c->src_row_dev)); }
         // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
         // (from 9 windows up launch_fc_gemm picks the MFMA chain kernel of fc_gemm_chain.hip instead)
         auto fc = (c->gemv && n <= FC_GEMV_MAX_M && !fc_split_ok(n, FC1, FEAT) && !fc_gemm_chain_ok(n, FC1, FEAT)) ? launch_fc_gemv : launch_fc_gemm;
-        if (c->precision == DCE_FP32_SPLIT && fc_gemm_x3_ok(n, FC1, FEAT)) {
+        if (x3) {
             // fc.0 on the bf16 matrix pipe with three-term operands (fc_gemm_x3.hip); everything else as in DCE_FP32
             Timer t(c, 1);
-            HIP_TRY(c, launch_split3(c->feat, c->feat3, n, FEAT, c->stream));
+            if (!x3_fused) HIP_TRY(c, launch_split3(c->feat, c->feat3, n, FEAT, c->stream));
             HIP_TRY(c, launch_fc_gemm_x3(c->feat3, c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream));
         } else
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
@@ -587,8 +594,9 @@ int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
         dsrc = c->d_in; dl = c->d_logits;
     }
     c->want_h2 = h2 != nullptr;
+    c->want_feat = feat != nullptr;
     rc = run_chunk(c, dsrc, 0, n, dl, nullptr, nullptr);
-    c->want_h2 = false;
+    c->want_h2 = c->want_feat = false;
     if (rc) return rc;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     // DCE_BF16_FC: the features and ReLU(fc.0) ARE bf16 in that mode -- the taps hand out the (n,4736) / (n,2048)

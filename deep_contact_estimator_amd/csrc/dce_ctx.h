@@ -40,6 +40,7 @@ struct dce_ctx {
     unsigned short* feat3 = nullptr;                        // DCE_FP32_SPLIT: the features as three bf16 planes [3][n][4736]
     const unsigned short* fc1w_x3 = nullptr;                // ... and fc.0's weights, [3][2048][4736] (inside d_weights)
     float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
+    bool want_feat = false;                                // dce_forward_taps: DCE_FP32_SPLIT keeps the fp32 features (split by a kernel of its own)
     bool want_h2 = false;                                  // dce_forward_taps: the fused epilogue also writes h2
 
     // staging for host-pointer callers: a ring of RING_SLOTS chunk-sized slots (run_all), so that

@@ -27,6 +27,7 @@ struct Tuning {
     long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // DCE_WINO1_MAX / DCE_WINOH_MAX / DCE_WINOQ_MAX (-1: kernel default)
     bool wino1_w8 = true;                                   // DCE_WINO1_WAVES=4 -> false
     bool one_per_cu = false, trace_wino1 = false;           // DCE_ONE_PER_CU, DCE_TRACE_WINO1 (trace builds)
+    bool x3_unfused = false;                                // DCE_X3_UNFUSED: fp32 features + split3 kernel instead of the conv kernel's three-plane output (A/B)
     int x3_min_tiles = 192;                                 // DCE_X3_MIN_TILES: 256x128 tiles a launch needs for the split-bf16 fc.0 kernel
     int conv4 = 0;                                          // DCE_CONV4=1: four row tiles per wave in the two-window conv kernel (A/B; slower)
 };
@@ -85,7 +86,8 @@ hipError_t init_fc_gemm();
 // Fused z-score + conv1..conv4 + ReLU + 2x MaxPool for n windows -> feat (n,4736).
 //   zscore != 0: src is a raw (T,54) sequence; window i = rows [first+i, first+i+150)
 //   zscore == 0: src is (n,150,54) pre-normalised windows, window i at src + i*8100
-//   feat_bf16 != 0: feat is (n,4736) bf16 (round-to-nearest-even) for the bf16 FC path
+//   feat_bf16 == 1: feat is (n,4736) bf16 (round-to-nearest-even) for the bf16 FC path; == 2 (Winograd two-window kernel
+//   only): three bf16 planes, v = t1 + t2 + t3, in fc_gemm_x3.hip's layout (DCE_FP32_SPLIT)
 hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const ConvPack& pk,
                              void* feat, int feat_bf16, hipStream_t st, const long long* src_row = nullptr);
 

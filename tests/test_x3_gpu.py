@@ -69,7 +69,7 @@ def test_split_mode_meets_the_fp32_contract(n, pair, orc):
     seq = synth.make_sequence(n + 149, seed=2).astype(np.float32)
     w = b.zscore_windows(seq, 0, n)
     out = b.predict(w)
-    assert "fc_x3_256x128" in b.last_plan() and "split3" in b.last_plan(), b.last_plan()
+    assert "fc_x3_256x128" in b.last_plan() and "conv_wino2_feat3" in b.last_plan(), b.last_plan()
     ref = orc.Oracle(sd).forward_windows(w if isinstance(w, np.ndarray) else w.cpu().numpy())
     tol_ok(out["logits"], ref["logits"], f"fp32_split, {n} rows vs oracle")
     flips = _argmax_ok(out["pred"], ref["logits"], ref["pred"])
@@ -133,3 +133,25 @@ def test_split_mode_nan_window_and_sequence_path(pair, orc):
     ref = a.infer_sequence(seq)
     assert np.abs(s["logits"] - ref["logits"]).max() < 2e-5 * np.abs(ref["logits"]).max()
     assert (s["pred"] != ref["pred"]).sum() <= 2
+
+
+@pytest.mark.parametrize("n", [3072, 4099])
+def test_split_in_the_conv_kernel_equals_the_split_kernel(n, pair, monkeypatch):
+    """By default the two-window conv kernel writes the features straight as three bf16 planes (plan conv_wino2_feat3);
+    DCE_X3_UNFUSED=1 (read per context) keeps fp32 features and splits them with split3_kernel.  Same terms, same layout:
+    the same bits downstream.  (4099: an odd number of rows -- the planes' stride is rounded up to even.)"""
+    from deep_contact_estimator_amd import contact_cnn
+    sd, a, b = pair
+    monkeypatch.setenv("DCE_X3_UNFUSED", "1")
+    u = contact_cnn(device=0, max_batch=8192, precision="fp32_split"); u.load_state_dict(sd).eval()
+    u.predict(np.zeros((1, 150, 54), np.float32))            # the context (and its switches) exist from the first call on
+    monkeypatch.delenv("DCE_X3_UNFUSED")
+    x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
+    x[5, 3, 2] = np.inf                                     # a non-finite window goes through both routes as NaN features
+    rb, ru = b.predict(x), u.predict(x)
+    assert "conv_wino2_feat3" in b.last_plan() and "split3" not in b.last_plan()
+    assert "split3" in u.last_plan() and "conv_wino2_feat3" not in u.last_plan()
+    u.close()
+    for k in ("logits", "pred", "contacts"):
+        assert np.array_equal(rb[k], ru[k], equal_nan=True) if k == "logits" else np.array_equal(rb[k], ru[k]), k
+    assert np.isnan(rb["logits"][5]).all()

@@ -15,7 +15,8 @@ if KIND == "normal":
     seq = np.random.default_rng(3).standard_normal((N + 149, 54)).astype(np.float32)
 else:                                   # AR(1) + per-channel offset/scale: stresses the z-score
     seq = synth.make_sequence(N + 149, 5, "ar1").astype(np.float32)
-m = contact_cnn(device=0)
+PRECISION = os.environ.get("PRECISION", "fp32")     # fp32 | fp32_split (fc.0 on three-term bf16 operands): same contract
+m = contact_cnn(device=0, precision=PRECISION)
 m.load_state_dict(sd)
 t0 = time.time(); out = m.infer_sequence(seq); tg = time.time() - t0
 t0 = time.time(); ref = orc.Oracle(sd).infer_sequence(seq); tc = time.time() - t0
@@ -24,7 +25,7 @@ srt = np.sort(ref["logits"], axis=1); margin = srt[:, -1] - srt[:, -2]
 err = np.abs(out["logits"] - ref["logits"])
 bound = 1e-5 * np.abs(ref["logits"]).max() + 1e-4 * np.abs(ref["logits"])
 print(json.dumps({
-    "windows": N, "kind": KIND, "gpu_s_incl_pcie": tg, "oracle_s": tc, "oracle_threads": os.cpu_count(),
+    "windows": N, "kind": KIND, "precision": PRECISION, "plan_of_last_chunk": m.last_plan(), "gpu_s_incl_pcie": tg, "oracle_s": tc, "oracle_threads": os.cpu_count(),
     "argmax_flips": int(flips.size), "flip_margins": margin[flips][:20].tolist(),
     "contacts_equal_rows": int((out["contacts"] == ref["contacts"]).all(axis=1).sum()),
     "max_abs_logit_err": float(err.max()), "max_err_over_bound": float((err / bound).max()),
