@@ -219,6 +219,44 @@ int main(void)
         printf("abi_client: RCCL %d (%s), world of 1: ncclGather / grouped send-recv / async gather / all-reduce OK\n", ver, libname);
     }
 
+    /* ---- 8. DCE_FP32_SPLIT (fc.0 on the bf16 matrix pipe, fp32 operands as three bf16 terms): a batch large enough for
+     *         the split kernel, held to the same tolerance against the same oracle as the fp32 path */
+    {
+        enum { N2 = 3072, T2 = N2 + DCE_WINDOW - 1 };
+        dce_ctx* c2 = NULL;
+        CHECK(dce_create(&c2, 0, N2) == DCE_OK, "dce_create (split): %s", dce_last_error(NULL));
+        for (int k = 0; k < 14; ++k)
+            CHECK(dce_load_weight(c2, KEYS[k].key, w[k], KEYS[k].shape, KEYS[k].ndim) == DCE_OK, "%s", KEYS[k].key);
+        CHECK(dce_finalize_weights(c2, 7) == DCE_ERR_ARG, "unknown precision must be rejected");
+        CHECK(dce_finalize_weights(c2, DCE_FP32_SPLIT) == DCE_OK, "finalize (split): %s", dce_last_error(c2));
+        float* seq2 = (float*)malloc(sizeof(float) * T2 * DCE_CHANNELS);
+        for (int c = 0; c < DCE_CHANNELS; ++c) {
+            const double scale = pow(10.0, 3.0 * uniform01() - 2.0), offset = 10.0 * uniform01() - 5.0;
+            double x = 0.0;
+            for (int t = 0; t < T2; ++t) { x = 0.9 * x + (2.0 * uniform01() - 1.0); seq2[t * DCE_CHANNELS + c] = (float)(offset + scale * x); }
+        }
+        float* lg2 = (float*)malloc(sizeof(float) * N2 * DCE_CLASSES);
+        float* rl2 = (float*)malloc(sizeof(float) * N2 * DCE_CLASSES);
+        int32_t* pr2 = (int32_t*)malloc(sizeof(int32_t) * N2); int32_t* rp2 = (int32_t*)malloc(sizeof(int32_t) * N2);
+        uint8_t* rc2 = (uint8_t*)malloc(4 * N2);
+        float* zw2 = (float*)malloc(sizeof(float) * (size_t)N2 * DCE_WINDOW * DCE_CHANNELS);
+        CHECK(dce_infer_sequence(c2, seq2, T2, DCE_WINDOW, 0, lg2, pr2, NULL) == DCE_OK, "infer (split): %s", dce_last_error(c2));
+        char plan[256];
+        CHECK(dce_last_plan(c2, plan, sizeof plan) == DCE_OK && strstr(plan, "fc_x3_256x128") != NULL, "split kernel not in the plan: %s", plan);
+        CHECK(oracle_infer_sequence(&ow, seq2, T2, zw2, rl2, rp2, rc2) == 0, "oracle (split)");
+        double mr = 0.0, wst = 0.0;
+        for (int e = 0; e < N2 * DCE_CLASSES; ++e) mr = fmax(mr, fabs(rl2[e]));
+        for (int e = 0; e < N2 * DCE_CLASSES; ++e)
+            wst = fmax(wst, fabs((double)lg2[e] - rl2[e]) / (1e-5 * mr + 1e-4 * fabs(rl2[e])));
+        CHECK(wst <= 1.0, "split mode: logits outside tolerance: err/bound = %.3f", wst);
+        int flips = 0;
+        for (int i = 0; i < N2; ++i) flips += pr2[i] != rp2[i];
+        CHECK(flips <= 6, "split mode: %d argmax differences of %d", flips, N2);
+        printf("abi_client: DCE_FP32_SPLIT, %d windows: err/bound %.3f, %d sub-margin argmax differences, plan %s\n", N2, wst, flips, plan);
+        dce_destroy(c2);
+        free(seq2); free(lg2); free(rl2); free(pr2); free(rp2); free(rc2); free(zw2);
+    }
+
     CHECK(dce_sync(ctx) == DCE_OK, "sync");
     dce_destroy(ctx);
     dce_destroy(NULL);
