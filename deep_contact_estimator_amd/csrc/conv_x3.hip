@@ -1,0 +1,298 @@
+// conv_x3.hip -- the conv stack (z-score + 4 x [Conv1d k3 p1 + ReLU] + 2 x MaxPool1d(2) + flatten; reference
+// src/contact_cnn.py:10-44,61,64 and utils/data_handler.py:55-56) with fp32 results on the bf16 matrix pipe: every fp32
+// operand -- activations and weights -- enters the MFMAs as THREE bf16 terms (a = a1 + a2 + a3 exactly), six bf16 x bf16
+// MFMAs per product, fp32 accumulate.  Precision DCE_FP32_SPLIT (opt-in), see fc_gemm_x3.hip for the arithmetic.
+//
+// Why not Winograd here: its input transform would have to produce three-term operands on the fly (six more VALU
+// operations per transformed value, on a kernel that is already bound by what it issues between MFMAs).  In the direct form
+// the operands of a layer ARE the previous layer's outputs: they are split once, in the write-back, and every MFMA operand
+// is one 16-byte LDS read.  The direct form issues 1.5x the MACs of F(2,3); six bf16 MFMAs per product at 16x the fp32 rate
+// still make it 2.4x fewer matrix-pipe cycles than the fp32 Winograd kernel (28.8k per SIMD and window against 49.9k x 2 / 2).
+//
+// One workgroup = 4 waves = ONE window; 63 KB of LDS -> two workgroups per CU.  Activations live in LDS as three bf16
+// planes, [position][channel] (position p = t + 1; rows 0 and T + 1 are the zero padding): the B operand of
+// v_mfma_f32_16x16x32_bf16 -- lane (j = column = position, g): 8 consecutive channels -- is then ONE ds_read_b128 per plane,
+// for every tap (tap k reads row t + k).  16-byte slot s of row r is stored at s ^ swz(r) (128-byte rows: (r >> 1) & 7,
+// 256-byte rows: r & 15) so that the 16 rows a read touches spread over all banks; the swizzle of row t + k + 16 ct does
+// not depend on the column tile ct, so a K-step needs one address register and 15 immediates.
+// GEMM per layer: M = Cout (16-row tiles), N = positions (16-column tiles: 150 -> 10, 75 -> 5), K = 3 taps x Cin in steps
+// of 32 channels.  A wave holds 2 row tiles x 5 column tiles (40 accumulator registers); per K-step it reads 6 weight
+// fragments (packed per lane on the host, three planes, streamed from L2) and 15 activation fragments and issues 60 MFMAs;
+// the fragments of step s+1 are requested before the MFMAs of step s.  Write-back (in place, between two barriers): bias,
+// ReLU, MaxPool (neighbouring columns sit in neighbouring lanes: one DPP quad_perm), split into the three terms
+// (v_cvt_pk_bf16_f32), 8-byte stores.  conv4 + pool leave the workgroup as three planes in the layout fc_gemm_x3.hip reads.
+#include "conv_common.h"
+#include <cfloat>
+#include <cstring>
+#include <type_traits>
+
+namespace dce {
+
+typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float cx_f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CX_ROWS1 = 16 * 10 + 2, CX_ROWS2 = 16 * 5 + 2;      // LDS rows a stage reads: every column tile x every tap
+constexpr int CX_PLANE = CX_ROWS2 * 256;                          // 20,992 B >= 162 rows x 128 B
+constexpr int CX_LDS = 3 * CX_PLANE;                              // 62,976 B
+static_assert(CX_ROWS1 * 128 <= CX_PLANE && 2 * CX_LDS <= 160 * 1024 - 2048, "two workgroups per CU");
+constexpr int CX_NT = 5;                                          // column tiles per wave
+
+static const int cxCin[4]  = {54, 64, 64, 128};
+static const int cxCinP[4] = {64, 64, 64, 128};
+static const int cxCout[4] = {64, 64, 128, 128};
+
+template <int ROWB> __device__ __forceinline__ int cx_swz(int row) { return ROWB == 128 ? (row >> 1) & 7 : row & 15; }
+
+// byte offset of channel ch (bf16) of row `row` inside a plane
+template <int ROWB> __device__ __forceinline__ int cx_addr(int row, int ch)
+{
+    return row * ROWB + (((ch >> 3) ^ cx_swz<ROWB>(row)) << 4) + (ch & 7) * 2;
+}
+
+// three terms of two values: p[k] = (term k of v0) | (term k of v1) << 16
+__device__ __forceinline__ void cx_split2(float v0, float v1, unsigned (&p)[3])
+{
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {v0, v1};
+    const b2 t1 = __builtin_convertvector(v, b2);
+    const f2 r1 = v - __builtin_convertvector(t1, f2);
+    const b2 t2 = __builtin_convertvector(r1, b2);
+    const f2 r2 = r1 - __builtin_convertvector(t2, f2);
+    const b2 t3 = __builtin_convertvector(r2, b2);
+    p[0] = __builtin_bit_cast(unsigned, t1); p[1] = __builtin_bit_cast(unsigned, t2); p[2] = __builtin_bit_cast(unsigned, t3);
+}
+
+// One layer's GEMM for one wave: acc[rt][ct] += sum over K-steps s = (channel block kb, tap) of W(rt, s) x X(ct, s).
+//   ROWB : bytes per LDS row of the layer's input (2 x input channels)      NKB : 32-channel blocks of K
+//   xrow : cx_lds + (16 ct0 + j) * ROWB  (this lane's row of column tile 0, tap 0)     sw[tap] = swz(16 ct0 + j + tap)
+//   wp   : this wave's packed weights: [step][row tile (2)][plane (3)][lane (64)] x 16 bytes
+template <int ROWB, int NKB>
+__device__ __forceinline__ void cx_layer(const char* __restrict__ xrow, const int (&sw)[3], int g,
+                                         const uint4* __restrict__ wp, cx_f32x4 (&acc)[2][CX_NT])
+{
+    constexpr int S = 3 * NKB;
+    uint4 af[2][2][3], bf[2][CX_NT][3];                               // [buffer][...][plane]
+    auto fetch = [&](int s, int b) {                                  // s, b compile-time at every call
+        const int kb = s / 3, tap = s % 3;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[b][rt][p] = wp[((s * 2 + rt) * 3 + p) * 64];
+        const char* x = xrow + tap * ROWB + (((4 * kb + g) ^ sw[tap]) << 4);
+#pragma unroll
+        for (int ct = 0; ct < CX_NT; ++ct)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[b][ct][p] = *reinterpret_cast<const uint4*>(x + ct * 16 * ROWB + p * CX_PLANE);
+    };
+    // (Requesting the NEXT layer's first weight fragments before the write-back, so that its barriers do not stand in front
+    //  of an L2 round trip, was tried: 24 more live registers, 84-100 B of scratch, 394 us instead of 350.)
+    fetch(0, 0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int b = s & 1;
+        if (s + 1 < S) fetch(s + 1, b ^ 1);
+        // (left alone, hipcc sinks every fetch to just before its first use and the MFMA stream waits on each of them:
+        //  388 us per 4096 windows instead of 350)
+        __builtin_amdgcn_sched_barrier(0);
+        // six terms per product, small ones first; consecutive MFMAs go to different accumulators
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CX_NT; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(cx_bf16x8, af[b][rt][TA[t]]), __builtin_bit_cast(cx_bf16x8, bf[b][ct][TB[t]]), acc[rt][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ float cx_neighbour(float v)                // the value of lane ^ 1 (the other column of the pool pair)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+}
+
+// bias + ReLU (+ MaxPool over column pairs) of a wave's tiles -> three-term planes of the next layer's input, in LDS
+//   T : columns of this layer; POOL: the next layer sees T / 2 positions
+template <int ROWB_OUT, bool POOL, int T>
+__device__ __forceinline__ void cx_store(char* __restrict__ lds, const cx_f32x4 (&acc)[2][CX_NT], const float* __restrict__ bias,
+                                         int co0, int ct0, int j, int g)
+{
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int co = co0 + 16 * rt + 4 * g;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+#pragma unroll
+        for (int ct = 0; ct < CX_NT; ++ct) {
+            const int t = 16 * (ct0 + ct) + j;
+            float v[4] = {acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = fmaxf(v[r], 0.f);
+                if (POOL) v[r] = fmaxf(v[r], cx_neighbour(v[r]));
+            }
+            const bool ok = POOL ? ((j & 1) == 0 && (t >> 1) < T / 2) : t < T;
+            const int row = (POOL ? (t >> 1) : t) + 1;
+            unsigned lo[3], hi[3];
+            cx_split2(v[0], v[1], lo);
+            cx_split2(v[2], v[3], hi);
+            if (ok) {
+                char* d = lds + cx_addr<ROWB_OUT>(row, co);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * CX_PLANE) = make_uint2(lo[p], hi[p]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Host: a layer's weights (cout, cin, 3) fp32 -> [row-tile pair P][step s = 3 kb + tap][row tile (2)][plane (3)][lane (64)][8 bf16]:
+// lane (i, g) of row tile rt holds W[32 P + 16 rt + i][32 kb + 8 g + e][tap], e = 0..7 (zero beyond cin), as its three terms
+size_t conv_x3_pack_halfs(int l) { return (size_t)cxCout[l] * cxCinP[l] * 3 * 3; }
+
+void conv_x3_pack_host(int l, const float* w, unsigned short* out)
+{
+    const int cin = cxCin[l], nkb = cxCinP[l] / 32, cout = cxCout[l];
+    size_t o = 0;
+    for (int P = 0; P < cout / 32; ++P)
+        for (int s = 0; s < 3 * nkb; ++s)
+            for (int rt = 0; rt < 2; ++rt)
+                for (int p = 0; p < 3; ++p)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = 32 * P + 16 * rt + (lane & 15), ci = 32 * (s / 3) + 8 * (lane >> 4) + e, tap = s % 3;
+                            const float v = ci < cin ? w[((size_t)co * cin + ci) * 3 + tap] : 0.f;
+                            unsigned short t[3];
+                            split3_host(&v, 1, 0, t);
+                            out[o++] = t[p];
+                        }
+}
+
+template <bool ZS>
+__global__ __launch_bounds__(256, 2)
+void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems)
+{
+    extern __shared__ __attribute__((aligned(16))) char cx_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t win = blockIdx.x;
+
+    // ---- prologue: the window (z-scored if ZS) -> three-term planes, [t + 1][channel], channels 54..63 and the pad rows zero
+    float x[1][38];
+    load_windows<ZS, 1>(src + win * (ZS ? (int64_t)CH : (int64_t)WIN * CH), 0, 1, reinterpret_cast<float*>(cx_lds), x, tid);
+    bool bad = false;
+#pragma unroll
+    for (int m = 0; m < 38; ++m) bad |= !(fabsf(x[0][m]) <= FLT_MAX);
+    const int window_bad = __syncthreads_or(bad);                      // (also: every thread is done with the z-score scratch)
+    for (int i = tid; i < CX_LDS / 16; i += 256) reinterpret_cast<uint4*>(cx_lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (tid < 4 * CH) {
+        const int c = tid % CH, gq = tid / CH;
+#pragma unroll
+        for (int m = 0; m < 38; m += 2) {                              // rows t = 4 m + gq and 4 (m + 1) + gq
+            unsigned p[3];
+            cx_split2(x[0][m], x[0][m + 1], p);
+            const int t0 = 4 * m + gq, t1 = t0 + 4;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                *reinterpret_cast<unsigned short*>(cx_lds + k * CX_PLANE + cx_addr<128>(t0 + 1, c)) = (unsigned short)p[k];
+                if (t1 < WIN) *reinterpret_cast<unsigned short*>(cx_lds + k * CX_PLANE + cx_addr<128>(t1 + 1, c)) = (unsigned short)(p[k] >> 16);
+            }
+        }
+    }
+    __syncthreads();
+
+    cx_f32x4 acc[2][CX_NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CX_NT; ++ct) acc[rt][ct] = cx_f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    const uint4* w0 = reinterpret_cast<const uint4*>(pk.w[0]) + lane;
+    const uint4* w1 = reinterpret_cast<const uint4*>(pk.w[1]) + lane;
+    const uint4* w2 = reinterpret_cast<const uint4*>(pk.w[2]) + lane;
+    const uint4* w3 = reinterpret_cast<const uint4*>(pk.w[3]) + lane;
+
+    // ---- stage 1 (T = 150, 64 channels in and out): wave = row-tile pair wv & 1, column tiles 5 (wv >> 1) ..
+    {
+        const int P = wv & 1, ct0 = 5 * (wv >> 1), base = 16 * ct0 + j;
+        const int sw[3] = {cx_swz<128>(base), cx_swz<128>(base + 1), cx_swz<128>(base + 2)};
+        const char* xrow = cx_lds + base * 128;
+        zero_acc();
+        cx_layer<128, 2>(xrow, sw, g, w0 + (size_t)P * (6 * 2 * 3 * 64), acc);
+        __syncthreads();                                               // every wave has read conv1's input
+        cx_store<128, false, WIN>(cx_lds, acc, pk.b[0], 32 * P, ct0, j, g);
+        __syncthreads();
+        zero_acc();
+        cx_layer<128, 2>(xrow, sw, g, w1 + (size_t)P * (6 * 2 * 3 * 64), acc);
+        __syncthreads();
+        cx_store<128, true, WIN>(cx_lds, acc, pk.b[1], 32 * P, ct0, j, g);     // pooled: rows 1..75 of the stage-2 layout (64 channels)
+        if (tid < 24) reinterpret_cast<uint4*>(cx_lds + (tid >> 3) * CX_PLANE + 76 * 128)[tid & 7] = make_uint4(0, 0, 0, 0);   // row 76 = right pad
+        __syncthreads();
+    }
+    // ---- stage 2 (T = 75): wave = row-tile pair wv, all five column tiles
+    {
+        const int sw[3] = {cx_swz<128>(j), cx_swz<128>(j + 1), cx_swz<128>(j + 2)};
+        zero_acc();
+        cx_layer<128, 2>(cx_lds + j * 128, sw, g, w2 + (size_t)wv * (6 * 2 * 3 * 64), acc);
+        __syncthreads();
+        cx_store<256, false, 75>(cx_lds, acc, pk.b[2], 32 * wv, 0, j, g);      // 128 channels: 256-byte rows, rows 1..75
+        if (tid < 96) {                                                        // rows 0 and 76 of the new layout = the zero padding
+            const int p = tid >> 5, r = (tid >> 4) & 1, s = tid & 15;
+            reinterpret_cast<uint4*>(cx_lds + p * CX_PLANE + (r ? 76 : 0) * 256)[s] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        const int sw4[3] = {cx_swz<256>(j), cx_swz<256>(j + 1), cx_swz<256>(j + 2)};
+        zero_acc();
+        cx_layer<256, 4>(cx_lds + j * 256, sw4, g, w3 + (size_t)wv * (12 * 2 * 3 * 64), acc);
+        // ---- conv4 + bias + ReLU + MaxPool (t = 74 dropped) + flatten c * 37 + t' -> three planes in HBM (fc_gemm_x3.hip's layout)
+        const float nanv = __builtin_nanf("");
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int co = 32 * wv + 16 * rt + 4 * g;
+            const float4 bv = *reinterpret_cast<const float4*>(pk.b[3] + co);
+#pragma unroll
+            for (int ct = 0; ct < CX_NT; ++ct) {
+                const int t = 16 * ct + j;
+                float v[4] = {acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = fmaxf(v[r], 0.f);
+                    v[r] = fmaxf(v[r], cx_neighbour(v[r]));
+                    if (window_bad) v[r] = nanv;
+                }
+                if ((j & 1) == 0 && (t >> 1) < 37) {
+                    const int k0 = co * 37 + (t >> 1);
+                    put_feat3(reinterpret_cast<Feat3*>(feat3), plane_elems, win, k0, k0 + 37, v[0], v[1]);
+                    put_feat3(reinterpret_cast<Feat3*>(feat3), plane_elems, win, k0 + 74, k0 + 111, v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+hipError_t init_conv_x3()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+}
+
+hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t plane_elems = (size_t)((n + 1) & ~(int64_t)1) * FEAT;
+    plan_note("conv_x3");
+    if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems);
+    else        hipLaunchKernelGGL((conv_x3_kernel<false>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems);
+    return hipGetLastError();
+}
+
+}  // namespace dce

@@ -66,6 +66,7 @@ Tuning tuning_from_env()
     t.conv4 = (int)num("DCE_CONV4", 0);
     t.x3_min_tiles = (int)num("DCE_X3_MIN_TILES", t.x3_min_tiles);
     t.x3_unfused = getenv("DCE_X3_UNFUSED") != nullptr;
+    t.x3_conv = num("DCE_X3_CONV", t.x3_conv ? 1 : 0) != 0;
     return t;
 }
 
@@ -142,7 +143,8 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         const bool x3 = c->precision == DCE_FP32_SPLIT && fc_gemm_x3_ok(n, FC1, FEAT);
         const bool x3_fused = x3 && c->winograd && !c->want_feat && !c->tuning.x3_unfused;
         { Timer t(c, 0);
-          if (x3_fused) HIP_TRY(c, launch_conv_wino(src, zscore, n, c->pk, c->feat3, 2, c->stream, c->src_row_dev));
+          if (x3_fused && c->tuning.x3_conv && !c->src_row_dev) HIP_TRY(c, launch_conv_x3(src, zscore, n, c->pkx3, c->feat3, c->stream));
+          else if (x3_fused) HIP_TRY(c, launch_conv_wino(src, zscore, n, c->pk, c->feat3, 2, c->stream, c->src_row_dev));
           else HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream, c->src_row_dev)); }
         // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
         // (from 9 windows up launch_fc_gemm picks the MFMA chain kernel of fc_gemm_chain.hip instead)
@@ -344,6 +346,7 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     CREATE_TRY(init_conv_wino());
     CREATE_TRY(init_fc_gemm());
     CREATE_TRY(init_fc_gemm_x3());
+    CREATE_TRY(init_conv_x3());
     CREATE_TRY(hipMalloc(&c->feat, (size_t)max_batch * FEAT * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h1, (size_t)max_batch * FC1 * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h2, (size_t)max_batch * FC2 * sizeof(float)));
@@ -459,7 +462,12 @@ int dce_finalize_weights(dce_ctx* c, int precision)
             }
         }
     }
-    size_t off_x3 = 0;
+    size_t off_x3 = 0, off_cx[4] = {0, 0, 0, 0};
+    if (precision == DCE_FP32_SPLIT)
+        for (int l = 0; l < 4; ++l) {                     // conv weights as three-term planes, packed per lane (conv_x3.hip)
+            off_cx[l] = reserve((conv_x3_pack_halfs(l) + 1) / 2);
+            conv_x3_pack_host(l, c->host_w[2 * l].data(), reinterpret_cast<unsigned short*>(img.data() + off_cx[l]));
+        }
     if (precision == DCE_FP32_SPLIT) {
         // fc.0's weights as three bf16 planes [3][2048][4736]: w = w1 + w2 + w3 exactly
         const auto& v = c->host_w[8];
@@ -479,6 +487,10 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     c->fc3w = c->d_weights + off_fc[4]; c->fc3b = c->d_weights + off_fc[5];
     c->fc1w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[0] : nullptr;
     c->fc2w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[1] : nullptr;
+    for (int l = 0; l < 4; ++l) {
+        c->pkx3.w[l] = precision == DCE_FP32_SPLIT ? reinterpret_cast<const unsigned short*>(c->d_weights + off_cx[l]) : nullptr;
+        c->pkx3.b[l] = c->pk.b[l];
+    }
     c->fc1w_x3 = precision == DCE_FP32_SPLIT ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3) : nullptr;
     c->precision = precision;
     c->finalized = true;

@@ -38,6 +38,7 @@ struct dce_ctx {
 
     float *feat = nullptr, *h1 = nullptr, *h2 = nullptr;   // scratch, max_batch rows each
     unsigned short* feat3 = nullptr;                        // DCE_FP32_SPLIT: the features as three bf16 planes [3][n][4736]
+    dce::ConvPackX3 pkx3{};                                      // ... and the conv weights, packed per lane (conv_x3.hip)
     const unsigned short* fc1w_x3 = nullptr;                // ... and fc.0's weights, [3][2048][4736] (inside d_weights)
     float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
     bool want_feat = false;                                // dce_forward_taps: DCE_FP32_SPLIT keeps the fp32 features (split by a kernel of its own)

@@ -27,6 +27,7 @@ struct Tuning {
     long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // DCE_WINO1_MAX / DCE_WINOH_MAX / DCE_WINOQ_MAX (-1: kernel default)
     bool wino1_w8 = true;                                   // DCE_WINO1_WAVES=4 -> false
     bool one_per_cu = false, trace_wino1 = false;           // DCE_ONE_PER_CU, DCE_TRACE_WINO1 (trace builds)
+    bool x3_conv = true;                                    // DCE_X3_CONV=0: DCE_FP32_SPLIT keeps the fp32 Winograd conv stack (three-plane feature output) instead of conv_x3.hip (A/B)
     bool x3_unfused = false;                                // DCE_X3_UNFUSED: fp32 features + split3 kernel instead of the conv kernel's three-plane output (A/B)
     int x3_min_tiles = 192;                                 // DCE_X3_MIN_TILES: 256x128 tiles a launch needs for the split-bf16 fc.0 kernel
     int conv4 = 0;                                          // DCE_CONV4=1: four row tiles per wave in the two-window conv kernel (A/B; slower)
@@ -134,6 +135,14 @@ void       split3_host(const float* x, size_t rows, size_t cols, unsigned short*
 hipError_t launch_split3(const float* x, unsigned short* planes, int64_t rows, int cols, hipStream_t st);
 hipError_t launch_fc_gemm_x3(const unsigned short* A3, const unsigned short* W3, const float* bias, float* C,
                              int64_t M, int N, int K, int relu, hipStream_t st);
+
+// The conv stack with three-term bf16 operands (conv_x3.hip, precision DCE_FP32_SPLIT): direct-form implicit GEMM on
+// v_mfma_f32_16x16x32_bf16, one window per workgroup; features leave as the three planes fc_gemm_x3.hip reads.
+struct ConvPackX3 { const unsigned short* w[4]; const float* b[4]; };
+size_t     conv_x3_pack_halfs(int layer);
+void       conv_x3_pack_host(int layer, const float* w, unsigned short* out);
+hipError_t init_conv_x3();
+hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st);
 
 // The same GEMMs at chip-filling sizes (fc_gemm_phased.hip): one workgroup per CU, 256x128 or 128x64 tiles,
 // LDS-DMA staging, two wave groups one phase apart; fp32 (bit-identical to the tile kernels: same K order) and

@@ -69,7 +69,7 @@ def test_split_mode_meets_the_fp32_contract(n, pair, orc):
     seq = synth.make_sequence(n + 149, seed=2).astype(np.float32)
     w = b.zscore_windows(seq, 0, n)
     out = b.predict(w)
-    assert "fc_x3_256x128" in b.last_plan() and "conv_wino2_feat3" in b.last_plan(), b.last_plan()
+    assert "fc_x3_256x128" in b.last_plan() and "conv_x3" in b.last_plan(), b.last_plan()
     ref = orc.Oracle(sd).forward_windows(w if isinstance(w, np.ndarray) else w.cpu().numpy())
     tol_ok(out["logits"], ref["logits"], f"fp32_split, {n} rows vs oracle")
     flips = _argmax_ok(out["pred"], ref["logits"], ref["pred"])
@@ -141,17 +141,49 @@ def test_split_in_the_conv_kernel_equals_the_split_kernel(n, pair, monkeypatch):
     DCE_X3_UNFUSED=1 (read per context) keeps fp32 features and splits them with split3_kernel.  Same terms, same layout:
     the same bits downstream.  (4099: an odd number of rows -- the planes' stride is rounded up to even.)"""
     from deep_contact_estimator_amd import contact_cnn
-    sd, a, b = pair
+    sd, a, _ = pair
+    monkeypatch.setenv("DCE_X3_CONV", "0")                   # both contexts: the fp32 Winograd conv stack
+    b = contact_cnn(device=0, max_batch=8192, precision="fp32_split"); b.load_state_dict(sd).eval()
+    b.predict(np.zeros((1, 150, 54), np.float32))            # the context (and its switches) exist from the first call on
     monkeypatch.setenv("DCE_X3_UNFUSED", "1")
     u = contact_cnn(device=0, max_batch=8192, precision="fp32_split"); u.load_state_dict(sd).eval()
-    u.predict(np.zeros((1, 150, 54), np.float32))            # the context (and its switches) exist from the first call on
-    monkeypatch.delenv("DCE_X3_UNFUSED")
+    u.predict(np.zeros((1, 150, 54), np.float32))
+    monkeypatch.delenv("DCE_X3_UNFUSED"); monkeypatch.delenv("DCE_X3_CONV")
     x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
     x[5, 3, 2] = np.inf                                     # a non-finite window goes through both routes as NaN features
     rb, ru = b.predict(x), u.predict(x)
     assert "conv_wino2_feat3" in b.last_plan() and "split3" not in b.last_plan()
     assert "split3" in u.last_plan() and "conv_wino2_feat3" not in u.last_plan()
-    u.close()
+    u.close(); b.close()
     for k in ("logits", "pred", "contacts"):
         assert np.array_equal(rb[k], ru[k], equal_nan=True) if k == "logits" else np.array_equal(rb[k], ru[k]), k
     assert np.isnan(rb["logits"][5]).all()
+
+
+@pytest.mark.parametrize("n,zs", [(3072, False), (4099, False), (4096, True)])
+def test_conv_stack_on_three_term_operands(n, zs, pair, orc, monkeypatch):
+    """The mode's conv stack too runs on the bf16 matrix pipe with three-term operands (csrc/conv_x3.hip: direct-form
+    implicit GEMM on v_mfma_f32_16x16x32_bf16, one window per workgroup, activations re-split at every write-back).  Same
+    contract: every row against the oracle at the fp32 tolerance -- pre-normalised windows and the fused z-score of the
+    sequence entry -- and a non-finite window stays one all-NaN row."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    sd, a, b = pair
+    m = b                                                    # conv_x3 is the mode's default conv stack
+    seq = synth.make_sequence(n + 149, seed=21 + n, kind="ar1" if zs else "normal").astype(np.float32)
+    if zs:
+        out = m.infer_sequence(seq)
+        ref = orc.Oracle(sd).infer_sequence(seq)
+    else:
+        w = m.zscore_windows(seq, 0, n)
+        w = w if isinstance(w, np.ndarray) else w.cpu().numpy()
+        w[7, 11, 5] = np.nan
+        out = m.predict(w)
+        ref = orc.Oracle(sd).forward_windows(np.delete(w, 7, axis=0))
+        assert np.isnan(out["logits"][7]).all() and out["pred"][7] == 0
+        out = {k: np.delete(v, 7, axis=0) for k, v in out.items()}
+    assert "conv_x3" in m.last_plan() and "fc_x3_256x128" in m.last_plan(), m.last_plan()
+    tol_ok(out["logits"], ref["logits"], f"conv_x3, {n} rows vs oracle")
+    flips = _argmax_ok(out["pred"], ref["logits"], ref["pred"])
+    err = np.abs(out["logits"].astype(np.float64) - ref["logits"])
+    bound = 1e-5 * np.abs(ref["logits"]).max() + 1e-4 * np.abs(ref["logits"])
+    print(f"conv_x3 n={n} zs={zs}: max err/bound {(err / bound).max():.3f}, max |err| {err.max():.2e}, flips {flips}")
