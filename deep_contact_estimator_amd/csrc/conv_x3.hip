@@ -18,8 +18,8 @@
 // GEMM per layer: M = Cout (16-row tiles), N = positions (16-column tiles: 150 -> 10, 75 -> 5), K = 3 taps x Cin in steps
 // of 32 channels.  A wave holds 2 row tiles x 5 column tiles (40 accumulator registers); per K-step it reads 6 weight
 // fragments (packed per lane on the host, three planes, streamed from L2) and 15 activation fragments and issues 60 MFMAs;
-// the fragments of step s+1 are requested before the MFMAs of step s.  Write-back (in place, between two barriers): bias,
-// ReLU, MaxPool (neighbouring columns sit in neighbouring lanes: one DPP quad_perm), split into the three terms
+// the fragments of step s+1 are requested before the MFMAs of step s.  Write-back (in place, between two barriers; the bias
+// is the accumulators' initial value): ReLU, MaxPool (neighbouring columns sit in neighbouring lanes: one DPP quad_perm), split into the three terms
 // (v_cvt_pk_bf16_f32), 8-byte stores.  conv4 + pool leave the workgroup as three planes in the layout fc_gemm_x3.hip reads.
 #include "conv_common.h"
 #include <cfloat>
@@ -119,22 +119,18 @@ __device__ __forceinline__ float cx_neighbour(float v)                // the val
 // bias + ReLU (+ MaxPool over column pairs) of a wave's tiles -> three-term planes of the next layer's input, in LDS
 //   T : columns of this layer; POOL: the next layer sees T / 2 positions
 template <int ROWB_OUT, bool POOL, int T>
-__device__ __forceinline__ void cx_store(char* __restrict__ lds, const cx_f32x4 (&acc)[2][CX_NT], const float* __restrict__ bias,
+__device__ __forceinline__ void cx_store(char* __restrict__ lds, const cx_f32x4 (&acc)[2][CX_NT],
                                          int co0, int ct0, int j, int g)
 {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const int co = co0 + 16 * rt + 4 * g;
-        const float4 bv = *reinterpret_cast<const float4*>(bias + co);
 #pragma unroll
         for (int ct = 0; ct < CX_NT; ++ct) {
             const int t = 16 * (ct0 + ct) + j;
-            float v[4] = {acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w};
+            float v[4] = {acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};      // the bias is the accumulators' initial value
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = fmaxf(v[r], 0.f);
-                if (POOL) v[r] = fmaxf(v[r], cx_neighbour(v[r]));
-            }
+            for (int r = 0; r < 4; ++r) v[r] = POOL ? fmaxf(fmaxf(v[r], cx_neighbour(v[r])), 0.f) : fmaxf(v[r], 0.f);
             const bool ok = POOL ? ((j & 1) == 0 && (t >> 1) < T / 2) : t < T;
             const int row = (POOL ? (t >> 1) : t) + 1;
             unsigned lo[3], hi[3];
@@ -183,37 +179,69 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
     const int j = lane & 15, g = lane >> 4;
     const int64_t win = blockIdx.x;
 
+    TRACE_MARK(0);
     // ---- prologue: the window (z-scored if ZS) -> three-term planes, [t + 1][channel], channels 54..63 and the pad rows zero
-    float x[1][38];
-    load_windows<ZS, 1>(src + win * (ZS ? (int64_t)CH : (int64_t)WIN * CH), 0, 1, reinterpret_cast<float*>(cx_lds), x, tid);
-    bool bad = false;
+    int window_bad;
+    if constexpr (ZS) {
+        float x[1][38];
+        load_windows<ZS, 1>(src + win * (int64_t)CH, 0, 1, reinterpret_cast<float*>(cx_lds), x, tid);
+        bool bad = false;
 #pragma unroll
-    for (int m = 0; m < 38; ++m) bad |= !(fabsf(x[0][m]) <= FLT_MAX);
-    const int window_bad = __syncthreads_or(bad);                      // (also: every thread is done with the z-score scratch)
-    for (int i = tid; i < CX_LDS / 16; i += 256) reinterpret_cast<uint4*>(cx_lds)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    if (tid < 4 * CH) {
-        const int c = tid % CH, gq = tid / CH;
+        for (int m = 0; m < 38; ++m) bad |= !(fabsf(x[0][m]) <= FLT_MAX);
+        window_bad = __syncthreads_or(bad);                            // (also: every thread is done with the z-score scratch)
+        for (int i = tid; i < CX_LDS / 16; i += 256) reinterpret_cast<uint4*>(cx_lds)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        if (tid < 4 * CH) {
+            const int c = tid % CH, gq = tid / CH;
 #pragma unroll
-        for (int m = 0; m < 38; m += 2) {                              // rows t = 4 m + gq and 4 (m + 1) + gq
-            unsigned p[3];
-            cx_split2(x[0][m], x[0][m + 1], p);
-            const int t0 = 4 * m + gq, t1 = t0 + 4;
+            for (int m = 0; m < 38; m += 2) {                          // rows t = 4 m + gq and 4 (m + 1) + gq
+                unsigned p[3];
+                cx_split2(x[0][m], x[0][m + 1], p);
+                const int t0 = 4 * m + gq, t1 = t0 + 4;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                *reinterpret_cast<unsigned short*>(cx_lds + k * CX_PLANE + cx_addr<128>(t0 + 1, c)) = (unsigned short)p[k];
-                if (t1 < WIN) *reinterpret_cast<unsigned short*>(cx_lds + k * CX_PLANE + cx_addr<128>(t1 + 1, c)) = (unsigned short)(p[k] >> 16);
+                for (int k = 0; k < 3; ++k) {
+                    *reinterpret_cast<unsigned short*>(cx_lds + k * CX_PLANE + cx_addr<128>(t0 + 1, c)) = (unsigned short)p[k];
+                    if (t1 < WIN) *reinterpret_cast<unsigned short*>(cx_lds + k * CX_PLANE + cx_addr<128>(t1 + 1, c)) = (unsigned short)(p[k] >> 16);
+                }
             }
+        }
+    } else {
+        // pre-normalised window: 4050 pairs of neighbouring channels, 16 per thread -- one 8-byte load, one split, three
+        // 4-byte LDS stores each (the per-channel mapping of load_windows costs 38 loads and 114 two-byte stores per thread)
+        const float2* wsrc = reinterpret_cast<const float2*>(src + win * (int64_t)(WIN * CH));
+        float2 v[16];
+        int t = tid / 27, c2 = tid % 27;                               // pair i = tid + 256 q: row i / 27, channels 2 (i % 27), + 1
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = wsrc[tid + 256 * q < WIN * CH / 2 ? tid + 256 * q : 0];
+        for (int i = tid; i < CX_LDS / 16; i += 256) reinterpret_cast<uint4*>(cx_lds)[i] = make_uint4(0, 0, 0, 0);
+        bool bad = false;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bad |= !(fabsf(v[q].x) <= FLT_MAX) || !(fabsf(v[q].y) <= FLT_MAX);
+        window_bad = __syncthreads_or(bad);                            // (also: the zero fill is complete)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            unsigned p[3];
+            cx_split2(v[q].x, v[q].y, p);
+            if (tid + 256 * q < WIN * CH / 2) {
+                char* d = cx_lds + cx_addr<128>(t + 1, 2 * c2);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(d + k * CX_PLANE) = p[k];
+            }
+            t += 9; c2 += 13;                                          // 256 = 9 x 27 + 13
+            if (c2 >= 27) { c2 -= 27; t += 1; }
         }
     }
     __syncthreads();
+    TRACE_MARK(1);
 
     cx_f32x4 acc[2][CX_NT];
-    auto zero_acc = [&]() {
+    auto bias_acc = [&](const float* __restrict__ bias, int co0) {     // the accumulators start from the bias of their four channels
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + co0 + 16 * rt + 4 * g);
 #pragma unroll
-            for (int ct = 0; ct < CX_NT; ++ct) acc[rt][ct] = cx_f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < CX_NT; ++ct) acc[rt][ct] = cx_f32x4{bv.x, bv.y, bv.z, bv.w};
+        }
     };
     const uint4* w0 = reinterpret_cast<const uint4*>(pk.w[0]) + lane;
     const uint4* w1 = reinterpret_cast<const uint4*>(pk.w[1]) + lane;
@@ -225,57 +253,80 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         const int P = wv & 1, ct0 = 5 * (wv >> 1), base = 16 * ct0 + j;
         const int sw[3] = {cx_swz<128>(base), cx_swz<128>(base + 1), cx_swz<128>(base + 2)};
         const char* xrow = cx_lds + base * 128;
-        zero_acc();
+        bias_acc(pk.b[0], 32 * P);
         cx_layer<128, 2>(xrow, sw, g, w0 + (size_t)P * (6 * 2 * 3 * 64), acc);
+        TRACE_MARK(2);
         __syncthreads();                                               // every wave has read conv1's input
-        cx_store<128, false, WIN>(cx_lds, acc, pk.b[0], 32 * P, ct0, j, g);
+        cx_store<128, false, WIN>(cx_lds, acc, 32 * P, ct0, j, g);
         __syncthreads();
-        zero_acc();
+        TRACE_MARK(3);
+        bias_acc(pk.b[1], 32 * P);
         cx_layer<128, 2>(xrow, sw, g, w1 + (size_t)P * (6 * 2 * 3 * 64), acc);
+        TRACE_MARK(4);
         __syncthreads();
-        cx_store<128, true, WIN>(cx_lds, acc, pk.b[1], 32 * P, ct0, j, g);     // pooled: rows 1..75 of the stage-2 layout (64 channels)
+        cx_store<128, true, WIN>(cx_lds, acc, 32 * P, ct0, j, g);     // pooled: rows 1..75 of the stage-2 layout (64 channels)
         if (tid < 24) reinterpret_cast<uint4*>(cx_lds + (tid >> 3) * CX_PLANE + 76 * 128)[tid & 7] = make_uint4(0, 0, 0, 0);   // row 76 = right pad
         __syncthreads();
+        TRACE_MARK(5);
     }
     // ---- stage 2 (T = 75): wave = row-tile pair wv, all five column tiles
     {
         const int sw[3] = {cx_swz<128>(j), cx_swz<128>(j + 1), cx_swz<128>(j + 2)};
-        zero_acc();
+        bias_acc(pk.b[2], 32 * wv);
         cx_layer<128, 2>(cx_lds + j * 128, sw, g, w2 + (size_t)wv * (6 * 2 * 3 * 64), acc);
+        TRACE_MARK(6);
         __syncthreads();
-        cx_store<256, false, 75>(cx_lds, acc, pk.b[2], 32 * wv, 0, j, g);      // 128 channels: 256-byte rows, rows 1..75
+        cx_store<256, false, 75>(cx_lds, acc, 32 * wv, 0, j, g);      // 128 channels: 256-byte rows, rows 1..75
         if (tid < 96) {                                                        // rows 0 and 76 of the new layout = the zero padding
             const int p = tid >> 5, r = (tid >> 4) & 1, s = tid & 15;
             reinterpret_cast<uint4*>(cx_lds + p * CX_PLANE + (r ? 76 : 0) * 256)[s] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
+        TRACE_MARK(7);
         const int sw4[3] = {cx_swz<256>(j), cx_swz<256>(j + 1), cx_swz<256>(j + 2)};
-        zero_acc();
+        bias_acc(pk.b[3], 32 * wv);
         cx_layer<256, 4>(cx_lds + j * 256, sw4, g, w3 + (size_t)wv * (12 * 2 * 3 * 64), acc);
-        // ---- conv4 + bias + ReLU + MaxPool (t = 74 dropped) + flatten c * 37 + t' -> three planes in HBM (fc_gemm_x3.hip's layout)
+        TRACE_MARK(8);
+        // ---- conv4 + bias + ReLU + MaxPool (t = 74 dropped) + flatten k = c * 37 + t' -> three planes [k] in LDS (the layer's
+        //      input is dead once every wave is through its MFMAs), then 16-byte stores into fc_gemm_x3.hip's layout: 7 per
+        //      thread, where storing from the accumulators' layout took 120 two-byte stores per lane (9.6k cycles per workgroup)
+        __syncthreads();
         const float nanv = __builtin_nanf("");
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int co = 32 * wv + 16 * rt + 4 * g;
-            const float4 bv = *reinterpret_cast<const float4*>(pk.b[3] + co);
 #pragma unroll
             for (int ct = 0; ct < CX_NT; ++ct) {
                 const int t = 16 * ct + j;
-                float v[4] = {acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w};
+                float v[4] = {acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = fmaxf(v[r], 0.f);
-                    v[r] = fmaxf(v[r], cx_neighbour(v[r]));
+                    v[r] = fmaxf(fmaxf(v[r], cx_neighbour(v[r])), 0.f);
                     if (window_bad) v[r] = nanv;
                 }
+                unsigned lo[3], hi[3];
+                cx_split2(v[0], v[1], lo);
+                cx_split2(v[2], v[3], hi);
                 if ((j & 1) == 0 && (t >> 1) < 37) {
-                    const int k0 = co * 37 + (t >> 1);
-                    put_feat3(reinterpret_cast<Feat3*>(feat3), plane_elems, win, k0, k0 + 37, v[0], v[1]);
-                    put_feat3(reinterpret_cast<Feat3*>(feat3), plane_elems, win, k0 + 74, k0 + 111, v[2], v[3]);
+                    unsigned short* d = reinterpret_cast<unsigned short*>(cx_lds) + co * 37 + (t >> 1);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        d[p * FEAT] = (unsigned short)lo[p];       d[p * FEAT + 37] = (unsigned short)(lo[p] >> 16);
+                        d[p * FEAT + 74] = (unsigned short)hi[p];  d[p * FEAT + 111] = (unsigned short)(hi[p] >> 16);
+                    }
                 }
             }
         }
+        __syncthreads();
+        // row `win` of a pair-interleaved plane: runs of 32 k (64 bytes) at stride 128 bytes
+        unsigned short* out = feat3 + (size_t)(win >> 1) * (2 * FEAT) + (int)(win & 1) * 32;
+        for (int q = tid; q < 3 * (FEAT / 8); q += 256) {
+            const int p = q / (FEAT / 8), k8 = (q % (FEAT / 8)) * 8;
+            *reinterpret_cast<uint4*>(out + p * plane_elems + (k8 >> 5) * 64 + (k8 & 31)) =
+                *reinterpret_cast<const uint4*>(cx_lds + ((size_t)p * FEAT + k8) * 2);
+        }
     }
+    TRACE_MARK(9);
 }
 
 hipError_t init_conv_x3()
@@ -296,3 +347,10 @@ hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPac
 }
 
 }  // namespace dce
+
+#if DCE_TRACE
+extern "C" int dce_debug_trace_read_x3(unsigned long long* out, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dce::g_trace), sizeof(unsigned long long) * 16 * nblocks);
+}
+#endif

@@ -61,10 +61,10 @@ typedef enum dce_status {
 typedef enum dce_precision {
     DCE_FP32            = 0,   /* fp32 MFMA everywhere (exact fp32 fmaf chains) -- the headline path */
     DCE_BF16_FC         = 1,   /* bf16 MFMA (fp32 accumulate) on the FC layers; conv stays fp32 */
-    DCE_FP32_SPLIT      = 2    /* fp32 results, fc.0 at chip-filling batches on the bf16 matrix pipe: every fp32 operand enters as
-                                  three bf16 terms (a = a1 + a2 + a3 exactly), six bf16 MFMAs per product, fp32 accumulate.  Same
-                                  tolerance against the reference as DCE_FP32, NOT the same bits; smaller batches run the DCE_FP32
-                                  kernels.  Opt-in (csrc/fc_gemm_x3.hip) */
+    DCE_FP32_SPLIT      = 2    /* fp32 results with the conv stack and fc.0 of chip-filling batches on the bf16 matrix pipe: every fp32
+                                  operand enters as three bf16 terms (a = a1 + a2 + a3 exactly), six bf16 MFMAs per product, fp32
+                                  accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; smaller batches run
+                                  the DCE_FP32 kernels.  Opt-in (csrc/conv_x3.hip, csrc/fc_gemm_x3.hip) */
 } dce_precision;
 
 typedef struct dce_ctx dce_ctx;   /* opaque; owns device weights, scratch and (by default) a stream */
