@@ -384,7 +384,7 @@ class contact_cnn:
                                               p("feat"), p("h1"), p("h2"), p("logits")), self._ctx)
         return out
 
-    CONV_KERNELS = {"wino2": 0, "wino1x8": 1, "half": 2, "quarter": 3, "direct": 4, "wino1x4": 5, "wino2rt4": 6}
+    CONV_KERNELS = {"wino2": 0, "wino1x8": 1, "half": 2, "quarter": 3, "direct": 4, "wino1x4": 5, "wino2rt4": 6, "x3": 7}
 
     def conv_layer_taps(self, x, kernel="wino2"):
         """Parity-test hook (dce_conv_layer_taps): numpy (n<=64,150,54) pre-normalised windows through ONE named conv

@@ -118,10 +118,11 @@ __device__ __forceinline__ float cx_neighbour(float v)                // the val
 
 // bias + ReLU (+ MaxPool over column pairs) of a wave's tiles -> three-term planes of the next layer's input, in LDS
 //   T : columns of this layer; POOL: the next layer sees T / 2 positions
-template <int ROWB_OUT, bool POOL, int T>
+template <int ROWB_OUT, bool POOL, int T, bool TAPS = false>
 __device__ __forceinline__ void cx_store(char* __restrict__ lds, const cx_f32x4 (&acc)[2][CX_NT],
-                                         int co0, int ct0, int j, int g)
-{
+                                         int co0, int ct0, int j, int g,
+                                         float* __restrict__ tap = nullptr, float* __restrict__ tap_pool = nullptr)
+{   // tap / tap_pool (TAPS only): this window's (cout, T) block of the layer's output after ReLU / its (cout, T/2) pooled block
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const int co = co0 + 16 * rt + 4 * g;
@@ -129,10 +130,20 @@ __device__ __forceinline__ void cx_store(char* __restrict__ lds, const cx_f32x4 
         for (int ct = 0; ct < CX_NT; ++ct) {
             const int t = 16 * (ct0 + ct) + j;
             float v[4] = {acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};      // the bias is the accumulators' initial value
+            if constexpr (TAPS) {
+                if (t < T)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tap[(size_t)(co + r) * T + t] = fmaxf(v[r], 0.f);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = POOL ? fmaxf(fmaxf(v[r], cx_neighbour(v[r])), 0.f) : fmaxf(v[r], 0.f);
             const bool ok = POOL ? ((j & 1) == 0 && (t >> 1) < T / 2) : t < T;
             const int row = (POOL ? (t >> 1) : t) + 1;
+            if constexpr (TAPS && POOL) {
+                if (ok)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tap_pool[(size_t)(co + r) * (T / 2) + (t >> 1)] = v[r];
+            }
             unsigned lo[3], hi[3];
             cx_split2(v[0], v[1], lo);
             cx_split2(v[2], v[3], hi);
@@ -169,10 +180,11 @@ void conv_x3_pack_host(int l, const float* w, unsigned short* out)
                         }
 }
 
-template <bool ZS>
+template <bool ZS, bool TAPS = false>
 __global__ __launch_bounds__(256, 2)
-void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems)
-{
+void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems,
+                    LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr)
+{   // TAPS (dce_conv_layer_taps, parity tests): every layer's output also goes to HBM in fp32, and so do the features
     extern __shared__ __attribute__((aligned(16))) char cx_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,14 +269,14 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         cx_layer<128, 2>(xrow, sw, g, w0 + (size_t)P * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(2);
         __syncthreads();                                               // every wave has read conv1's input
-        cx_store<128, false, WIN>(cx_lds, acc, 32 * P, ct0, j, g);
+        cx_store<128, false, WIN, TAPS>(cx_lds, acc, 32 * P, ct0, j, g, TAPS ? taps.conv1 + win * 64 * 150 : nullptr);
         __syncthreads();
         TRACE_MARK(3);
         bias_acc(pk.b[1], 32 * P);
         cx_layer<128, 2>(xrow, sw, g, w1 + (size_t)P * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(4);
         __syncthreads();
-        cx_store<128, true, WIN>(cx_lds, acc, 32 * P, ct0, j, g);     // pooled: rows 1..75 of the stage-2 layout (64 channels)
+        cx_store<128, true, WIN, TAPS>(cx_lds, acc, 32 * P, ct0, j, g, TAPS ? taps.conv2 + win * 64 * 150 : nullptr, TAPS ? taps.pool1 + win * 64 * 75 : nullptr);     // pooled: rows 1..75 of the stage-2 layout (64 channels)
         if (tid < 24) reinterpret_cast<uint4*>(cx_lds + (tid >> 3) * CX_PLANE + 76 * 128)[tid & 7] = make_uint4(0, 0, 0, 0);   // row 76 = right pad
         __syncthreads();
         TRACE_MARK(5);
@@ -276,7 +288,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         cx_layer<128, 2>(cx_lds + j * 128, sw, g, w2 + (size_t)wv * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(6);
         __syncthreads();
-        cx_store<256, false, 75>(cx_lds, acc, 32 * wv, 0, j, g);      // 128 channels: 256-byte rows, rows 1..75
+        cx_store<256, false, 75, TAPS>(cx_lds, acc, 32 * wv, 0, j, g, TAPS ? taps.conv3 + win * 128 * 75 : nullptr);      // 128 channels: 256-byte rows, rows 1..75
         if (tid < 96) {                                                        // rows 0 and 76 of the new layout = the zero padding
             const int p = tid >> 5, r = (tid >> 4) & 1, s = tid & 15;
             reinterpret_cast<uint4*>(cx_lds + p * CX_PLANE + (r ? 76 : 0) * 256)[s] = make_uint4(0, 0, 0, 0);
@@ -299,10 +311,20 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
             for (int ct = 0; ct < CX_NT; ++ct) {
                 const int t = 16 * ct + j;
                 float v[4] = {acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};
+                if constexpr (TAPS) {
+                    if (t < 75)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) taps.conv4[((size_t)win * 128 + co + r) * 75 + t] = fmaxf(v[r], 0.f);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = fmaxf(fmaxf(v[r], cx_neighbour(v[r])), 0.f);
                     if (window_bad) v[r] = nanv;
+                }
+                if constexpr (TAPS) {
+                    if ((j & 1) == 0 && (t >> 1) < 37)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) feat32[(size_t)win * FEAT + (co + r) * 37 + (t >> 1)] = v[r];
                 }
                 unsigned lo[3], hi[3];
                 cx_split2(v[0], v[1], lo);
@@ -333,7 +355,20 @@ hipError_t init_conv_x3()
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+}
+
+// dce_conv_layer_taps, kernel 7: pre-normalised windows through conv_x3_kernel with every layer's output (and the fp32
+// features) written out
+hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3& pk, unsigned short* feat3, float* feat32,
+                               const LayerTaps& taps, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t plane_elems = (size_t)((n + 1) & ~(int64_t)1) * FEAT;
+    hipLaunchKernelGGL((conv_x3_kernel<false, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, windows, n, pk, feat3, plane_elems, taps, feat32);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st)
@@ -341,8 +376,8 @@ hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPac
     if (n <= 0) return hipSuccess;
     const size_t plane_elems = (size_t)((n + 1) & ~(int64_t)1) * FEAT;
     plan_note("conv_x3");
-    if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems);
-    else        hipLaunchKernelGGL((conv_x3_kernel<false>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems);
+    if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
+    else        hipLaunchKernelGGL((conv_x3_kernel<false>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
     return hipGetLastError();
 }
 

@@ -644,7 +644,10 @@ int dce_conv_layer_taps(dce_ctx* c, const float* windows, int64_t n, int kernel,
                    d + in_f + sz[0] + sz[1] + sz[2] + sz[3]};
     HIP_TRY(c, hipMemcpyAsync(d, windows, in_f * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(d + in_f, 0xff, (total - in_f) * sizeof(float), c->stream));      // untouched taps read back as NaN
-    const hipError_t e = launch_conv_taps(kernel, d, n, c->pk, c->feat, taps, c->stream);
+    if (kernel == 7 && c->precision != DCE_FP32_SPLIT)
+        return fail(c, DCE_ERR_STATE, "dce_conv_layer_taps: kernel 7 (conv_x3) needs a context finalised with DCE_FP32_SPLIT");
+    const hipError_t e = kernel == 7 ? launch_conv_x3_taps(d, n, c->pkx3, c->feat3, c->feat, taps, c->stream)
+                                     : launch_conv_taps(kernel, d, n, c->pk, c->feat, taps, c->stream);
     if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? DCE_ERR_ARG : DCE_ERR_HIP, "dce_conv_layer_taps: kernel %d: %s", kernel, hipGetErrorString(e));
     float* outs[5] = {conv1, conv2, pool1, conv3, conv4};
     float* srcs[5] = {taps.conv1, taps.conv2, taps.pool1, taps.conv3, taps.conv4};

@@ -76,7 +76,8 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
 // their LDS / feature stores; the product instantiations carry no trace of it.
 struct LayerTaps { float *conv1, *conv2, *pool1, *conv3, *conv4; };
 // kernel: 0 two-window Winograd, 1 one-window x 8 waves, 2 half-window segments, 3 quarter-window segments,
-//         4 direct form, 5 one-window x 4 waves, 6 two-window Winograd with four row tiles per wave (DCE_CONV4=1)
+//         4 direct form, 5 one-window x 4 waves, 6 two-window Winograd with four row tiles per wave (DCE_CONV4=1),
+//         7 (dce_api.hip; DCE_FP32_SPLIT contexts only) conv_x3.hip: three-term bf16 operands
 hipError_t launch_conv_taps(int kernel, const float* windows, int64_t n, const ConvPack& pk, float* feat,
                             const LayerTaps& taps, hipStream_t st);
 
@@ -143,6 +144,8 @@ size_t     conv_x3_pack_halfs(int layer);
 void       conv_x3_pack_host(int layer, const float* w, unsigned short* out);
 hipError_t init_conv_x3();
 hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st);
+hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3& pk, unsigned short* feat3, float* feat32,
+                               const LayerTaps& taps, hipStream_t st);
 
 // The same GEMMs at chip-filling sizes (fc_gemm_phased.hip): one workgroup per CU, 256x128 or 128x64 tiles,
 // LDS-DMA staging, two wave groups one phase apart; fp32 (bit-identical to the tile kernels: same K order) and

@@ -146,8 +146,10 @@ int  dce_forward_taps(dce_ctx* ctx, const float* windows, int64_t n, int on_devi
  *   conv4 (n,128,75, before the pool)  feat (n,4736) = pool2 flattened.
  * kernel: 0 two-window Winograd workgroup (the chip-filling kernel), 1 one window on eight waves, 2 half-window
  * segments, 3 quarter-window segments, 4 direct form (DCE_CONV=direct), 5 one window on four waves, 6 the two-window
- * workgroup with four row tiles per wave (DCE_CONV4=1, an A/B variant of 0).  The segment kernels (2, 3) never compute conv4's t = 74 (MaxPool drops it): that column reads NaN.
- * The tapped kernels are the product kernels instantiated with the extra stores; fp32 mode only. */
+ * workgroup with four row tiles per wave (DCE_CONV4=1, an A/B variant of 0), 7 the three-term bf16 conv stack of the
+ * DCE_FP32_SPLIT precision (conv_x3.hip; contexts finalised with that precision only).  The segment kernels (2, 3) never
+ * compute conv4's t = 74 (MaxPool drops it): that column reads NaN.
+ * The tapped kernels are the product kernels instantiated with the extra stores; not in the DCE_BF16_FC precision. */
 int  dce_conv_layer_taps(dce_ctx* ctx, const float* windows, int64_t n, int kernel,
                          float* conv1, float* conv2, float* pool1, float* conv3, float* conv4, float* feat);
 

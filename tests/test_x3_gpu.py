@@ -187,3 +187,32 @@ def test_conv_stack_on_three_term_operands(n, zs, pair, orc, monkeypatch):
     err = np.abs(out["logits"].astype(np.float64) - ref["logits"])
     bound = 1e-5 * np.abs(ref["logits"]).max() + 1e-4 * np.abs(ref["logits"])
     print(f"conv_x3 n={n} zs={zs}: max err/bound {(err / bound).max():.3f}, max |err| {err.max():.2e}, flips {flips}")
+
+
+@pytest.mark.parametrize("name", ["seq_normal", "seq_ar1"])
+def test_conv_x3_layer_taps_vs_reference_hooks(name, golden, case_inputs, orc):
+    """The layers INSIDE conv_x3_kernel -- conv1, conv2, pool1, conv3, conv4, pool2 -- against the reference's forward hooks
+    (window 0 of the fixture; tests/golden/make_golden.py:96-106, reference src/contact_cnn.py:10-26,28-44) and the oracle's
+    taps for two more windows, as tests/test_round3_gpu.py does for the seven fp32 conv kernel families."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    g = golden(name)
+    sd, _ = case_inputs(g)
+    m = contact_cnn(device=0, max_batch=64, precision="fp32_split"); m.load_state_dict(sd).eval()
+    x = np.concatenate([g["zwin"], g["zwin"][::-1]])[:3]
+    taps = m.conv_layer_taps(x, "x3")
+    layers = ("conv1", "conv2", "pool1", "conv3", "conv4")
+    for k in layers:
+        assert not np.isnan(taps[k]).any(), (k, "positions the kernel never wrote")
+        tol_ok(taps[k][0], g["tap_" + k], f"conv_x3: {k} vs the reference's forward hook")
+    tol_ok(taps["feat"][0], g["tap_pool2"].reshape(-1), "conv_x3: pool2")
+    o = orc.Oracle(sd)
+    for i in (1, 2):
+        ref = o.layer_taps(x[i])
+        for k in layers:
+            tol_ok(taps[k][i], ref[k], f"conv_x3: window {i} {k} vs oracle")
+        tol_ok(taps["feat"][i], ref["pool2"].reshape(-1), f"conv_x3: window {i} pool2")
+    # the fp32 contexts refuse the kernel (its weights exist in the split precision only)
+    f = contact_cnn(device=0, max_batch=64); f.load_state_dict(sd).eval()
+    with pytest.raises(RuntimeError):
+        f.conv_layer_taps(x, "x3")
+    f.close(); m.close()
