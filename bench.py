@@ -620,7 +620,7 @@ def main():
             kd = kernels[dom]
             traffic, traffic_src, traffic_stale = None, None, None
             pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc_path):
+            if os.path.exists(pmc_path) and args.precision == "fp32":      # the counters were collected on the fp32 kernels
                 try:
                     from deep_contact_estimator_amd import build as dce_build
                     pmc = json.load(open(pmc_path))
@@ -636,7 +636,7 @@ def main():
             res["roofline"] = {
                 "kernel": dom, "bound": "mfma", "achieved": kd["executed_tflops"], "peak": kd["peak_tflops"],
                 "unit": "TFLOP/s", "frac": kd["frac"], "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
-                "flops_per_launch": EXEC_FLOP[dom] * B, "avg_launch_ms": kd["avg_ms"], "launches_timed": kd["launches"],
+                "flops_per_launch": exec_flop(dom, args.precision) * B, "avg_launch_ms": kd["avg_ms"], "launches_timed": kd["launches"],
                 "algorithmic_flops_per_launch": ALGO_FLOP[dom] * B,
                 "hbm_informational": {"note": "the step's inputs (133 MB) fit the 256 MB Infinity Cache and are re-read every step: these are "
                                               "cache-resident bytes moved per second, not HBM traffic",
@@ -644,7 +644,9 @@ def main():
                                       "algorithmic_GBs": kd["algorithmic_GBs"],
                                       "frac_of_8TBs": kd["algorithmic_GBs"] / PEAK_HBM_GBS},
                 "note": "achieved = matrix-pipe FLOPs issued per launch / average launch duration (HIP events on the launch "
-                        "stream, profiled pass); for this GEMM issued == algorithmic 2*M*N*K",
+                        "stream, profiled pass); " + ("for this GEMM issued == algorithmic 2*M*N*K" if args.precision != "fp32_split" else
+                        "fp32_split: six bf16 x bf16 MFMA terms per fp32 product are issued, so issued = 6 x (the direct form's) 2*MAC; "
+                        "the fp32-grade rate is algorithmic_flops_per_launch / avg_launch_ms"),
             }
             res["kernels"] = kernels
             res["profiled_pass"] = {"steps": psteps, "ms_per_step": prof_ms_per_step,
