@@ -216,3 +216,18 @@ def test_conv_x3_layer_taps_vs_reference_hooks(name, golden, case_inputs, orc):
     with pytest.raises(RuntimeError):
         f.conv_layer_taps(x, "x3")
     f.close(); m.close()
+
+
+def test_split_mode_is_deterministic_run_to_run(pair):
+    """The mode's kernels order LDS-DMA, in-place LDS write-backs and fragment reads with counted waits and barriers only: a
+    race would show as run-to-run differences.  40 repeats of a ragged batch, alternating two contexts (tools/race_screen_x3.py
+    runs 755 over five sizes with a competing copy stream: profiles/r3d_race_screen_x3.txt)."""
+    from deep_contact_estimator_amd import contact_cnn
+    sd, a, b = pair
+    c = contact_cnn(device=0, max_batch=8192, precision="fp32_split"); c.load_state_dict(sd).eval()
+    x = np.random.default_rng(41).standard_normal((4100, 150, 54), dtype=np.float32)
+    ref = b.predict(x)["logits"].copy()
+    for r in range(40):
+        got = (c if r % 2 else b).predict(x)["logits"]
+        assert np.array_equal(got, ref), r
+    c.close()
