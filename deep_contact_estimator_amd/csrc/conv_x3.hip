@@ -225,11 +225,18 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         int t = tid / 27, c2 = tid % 27;                               // pair i = tid + 256 q: row i / 27, channels 2 (i % 27), + 1
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = wsrc[tid + 256 * q < WIN * CH / 2 ? tid + 256 * q : 0];
-        for (int i = tid; i < CX_LDS / 16; i += 256) reinterpret_cast<uint4*>(cx_lds)[i] = make_uint4(0, 0, 0, 0);
-        bool bad = false;
+        {   // zero fill: 3936 x 16 bytes = 15 full rounds of the workgroup + 96 (constant offsets: no loop bookkeeping)
+            uint4* z = reinterpret_cast<uint4*>(cx_lds) + tid;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) bad |= !(fabsf(v[q].x) <= FLT_MAX) || !(fabsf(v[q].y) <= FLT_MAX);
-        window_bad = __syncthreads_or(bad);                            // (also: the zero fill is complete)
+            for (int r = 0; r < CX_LDS / 16 / 256; ++r) z[256 * r] = make_uint4(0, 0, 0, 0);
+            if (tid < CX_LDS / 16 % 256) z[256 * (CX_LDS / 16 / 256)] = make_uint4(0, 0, 0, 0);
+        }
+        // non-finite scan: x * 0 is 0 for a finite x and NaN for Inf / NaN (16 packed FMAs; a chain of compares compiles
+        // to five instructions per value)
+        cc_f32x2 nz = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) nz = __builtin_elementwise_fma(cc_f32x2{v[q].x, v[q].y}, cc_f32x2{0.f, 0.f}, nz);
+        window_bad = __syncthreads_or(!(nz.x == 0.f) || !(nz.y == 0.f));      // (also: the zero fill is complete)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             unsigned p[3];
@@ -317,14 +324,11 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
                         for (int r = 0; r < 4; ++r) taps.conv4[((size_t)win * 128 + co + r) * 75 + t] = fmaxf(v[r], 0.f);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = fmaxf(fmaxf(v[r], cx_neighbour(v[r])), 0.f);
-                    if (window_bad) v[r] = nanv;
-                }
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(v[r], cx_neighbour(v[r])), 0.f);
                 if constexpr (TAPS) {
                     if ((j & 1) == 0 && (t >> 1) < 37)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) feat32[(size_t)win * FEAT + (co + r) * 37 + (t >> 1)] = v[r];
+                        for (int r = 0; r < 4; ++r) feat32[(size_t)win * FEAT + (co + r) * 37 + (t >> 1)] = window_bad ? nanv : v[r];
                 }
                 unsigned lo[3], hi[3];
                 cx_split2(v[0], v[1], lo);
@@ -344,8 +348,9 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         unsigned short* out = feat3 + (size_t)(win >> 1) * (2 * FEAT) + (int)(win & 1) * 32;
         for (int q = tid; q < 3 * (FEAT / 8); q += 256) {
             const int p = q / (FEAT / 8), k8 = (q % (FEAT / 8)) * 8;
-            *reinterpret_cast<uint4*>(out + p * plane_elems + (k8 >> 5) * 64 + (k8 & 31)) =
-                *reinterpret_cast<const uint4*>(cx_lds + ((size_t)p * FEAT + k8) * 2);
+            uint4 val = *reinterpret_cast<const uint4*>(cx_lds + ((size_t)p * FEAT + k8) * 2);
+            if (window_bad) val = make_uint4(0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u);      // a non-finite window: NaN in every term
+            *reinterpret_cast<uint4*>(out + p * plane_elems + (k8 >> 5) * 64 + (k8 & 31)) = val;
         }
     }
     TRACE_MARK(9);
