@@ -180,11 +180,13 @@ void conv_x3_pack_host(int l, const float* w, unsigned short* out)
                         }
 }
 
-template <bool ZS, bool TAPS = false>
+template <bool ZS, bool TAPS = false, bool F32OUT = false>
 __global__ __launch_bounds__(256, 2)
 void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems,
                     LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr)
-{   // TAPS (dce_conv_layer_taps, parity tests): every layer's output also goes to HBM in fp32, and so do the features
+{   // TAPS (dce_conv_layer_taps, parity tests): every layer's output also goes to HBM in fp32, and so do the features.
+    // F32OUT: the features leave as (n, 4736) fp32 in feat32 instead of three planes (batches below the split-bf16 fc.0
+    // kernel's threshold, whose fc.0 runs on the fp32 kernels)
     extern __shared__ __attribute__((aligned(16))) char cx_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -330,20 +332,37 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
 #pragma unroll
                         for (int r = 0; r < 4; ++r) feat32[(size_t)win * FEAT + (co + r) * 37 + (t >> 1)] = window_bad ? nanv : v[r];
                 }
-                unsigned lo[3], hi[3];
-                cx_split2(v[0], v[1], lo);
-                cx_split2(v[2], v[3], hi);
-                if ((j & 1) == 0 && (t >> 1) < 37) {
-                    unsigned short* d = reinterpret_cast<unsigned short*>(cx_lds) + co * 37 + (t >> 1);
+                if constexpr (F32OUT) {
+                    if ((j & 1) == 0 && (t >> 1) < 37) {
+                        float* d = reinterpret_cast<float*>(cx_lds) + co * 37 + (t >> 1);
+                        d[0] = v[0]; d[37] = v[1]; d[74] = v[2]; d[111] = v[3];
+                    }
+                } else {
+                    unsigned lo[3], hi[3];
+                    cx_split2(v[0], v[1], lo);
+                    cx_split2(v[2], v[3], hi);
+                    if ((j & 1) == 0 && (t >> 1) < 37) {
+                        unsigned short* d = reinterpret_cast<unsigned short*>(cx_lds) + co * 37 + (t >> 1);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        d[p * FEAT] = (unsigned short)lo[p];       d[p * FEAT + 37] = (unsigned short)(lo[p] >> 16);
-                        d[p * FEAT + 74] = (unsigned short)hi[p];  d[p * FEAT + 111] = (unsigned short)(hi[p] >> 16);
+                        for (int p = 0; p < 3; ++p) {
+                            d[p * FEAT] = (unsigned short)lo[p];       d[p * FEAT + 37] = (unsigned short)(lo[p] >> 16);
+                            d[p * FEAT + 74] = (unsigned short)hi[p];  d[p * FEAT + 111] = (unsigned short)(hi[p] >> 16);
+                        }
                     }
                 }
             }
         }
         __syncthreads();
+        if constexpr (F32OUT) {
+            const float nn = __builtin_nanf("");
+            for (int q = tid; q < FEAT / 4; q += 256) {
+                float4 val = reinterpret_cast<const float4*>(cx_lds)[q];
+                if (window_bad) val = make_float4(nn, nn, nn, nn);
+                reinterpret_cast<float4*>(feat32 + (size_t)win * FEAT)[q] = val;
+            }
+            TRACE_MARK(9);
+            return;
+        }
         // row `win` of a pair-interleaved plane: runs of 32 k (64 bytes) at stride 128 bytes
         unsigned short* out = feat3 + (size_t)(win >> 1) * (2 * FEAT) + (int)(win & 1) * 32;
         for (int q = tid; q < 3 * (FEAT / 8); q += 256) {
@@ -362,6 +381,10 @@ hipError_t init_conv_x3()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
 }
 
@@ -373,6 +396,16 @@ hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3
     if (n <= 0) return hipSuccess;
     const size_t plane_elems = (size_t)((n + 1) & ~(int64_t)1) * FEAT;
     hipLaunchKernelGGL((conv_x3_kernel<false, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, windows, n, pk, feat3, plane_elems, taps, feat32);
+    return hipGetLastError();
+}
+
+// the same stack with (n, 4736) fp32 features out: DCE_FP32_SPLIT at batches below the split-bf16 fc.0 kernel's threshold
+hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    plan_note("conv_x3_f32");
+    if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat);
+    else        hipLaunchKernelGGL((conv_x3_kernel<false, false, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat);
     return hipGetLastError();
 }
 

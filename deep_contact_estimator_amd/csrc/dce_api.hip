@@ -67,6 +67,7 @@ Tuning tuning_from_env()
     t.x3_min_tiles = (int)num("DCE_X3_MIN_TILES", t.x3_min_tiles);
     t.x3_unfused = getenv("DCE_X3_UNFUSED") != nullptr;
     t.x3_conv = num("DCE_X3_CONV", t.x3_conv ? 1 : 0) != 0;
+    t.x3_conv_min = num("DCE_X3_CONV_MIN", t.x3_conv_min);
     return t;
 }
 
@@ -145,6 +146,8 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         { Timer t(c, 0);
           if (x3_fused && c->tuning.x3_conv && !c->src_row_dev) HIP_TRY(c, launch_conv_x3(src, zscore, n, c->pkx3, c->feat3, c->stream));
           else if (x3_fused) HIP_TRY(c, launch_conv_wino(src, zscore, n, c->pk, c->feat3, 2, c->stream, c->src_row_dev));
+          else if (c->precision == DCE_FP32_SPLIT && !x3 && c->tuning.x3_conv && c->winograd && !c->src_row_dev && !c->want_feat && n >= c->tuning.x3_conv_min)
+              HIP_TRY(c, launch_conv_x3_f32(src, zscore, n, c->pkx3, c->feat, c->stream));      // mid-size batch: three-term conv stack, fp32 FC kernels
           else HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream, c->src_row_dev)); }
         // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
         // (from 9 windows up launch_fc_gemm picks the MFMA chain kernel of fc_gemm_chain.hip instead)

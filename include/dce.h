@@ -63,8 +63,8 @@ typedef enum dce_precision {
     DCE_BF16_FC         = 1,   /* bf16 MFMA (fp32 accumulate) on the FC layers; conv stays fp32 */
     DCE_FP32_SPLIT      = 2    /* fp32 results with the conv stack and fc.0 of chip-filling batches on the bf16 matrix pipe: every fp32
                                   operand enters as three bf16 terms (a = a1 + a2 + a3 exactly), six bf16 MFMAs per product, fp32
-                                  accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; smaller batches run
-                                  the DCE_FP32 kernels.  Opt-in (csrc/conv_x3.hip, csrc/fc_gemm_x3.hip) */
+                                  accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; the conv stack from 128
+                                  windows per call, fc.0 from 2817; below that the DCE_FP32 kernels.  Opt-in (csrc/conv_x3.hip, csrc/fc_gemm_x3.hip) */
 } dce_precision;
 
 typedef struct dce_ctx dce_ctx;   /* opaque; owns device weights, scratch and (by default) a stream */
