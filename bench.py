@@ -84,7 +84,7 @@ def kernel_peak(kernel, precision):
         return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA"
     if precision == "fp32_split" and kernel == "fc1_gemm":
         return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA, six bf16 x bf16 terms per fp32 product (fc_gemm_x3.hip)"
-    if precision == "fp32_split" and kernel == "conv_stack":
+    if precision in ("fp32_split", "bf16_fc") and kernel == "conv_stack":
         return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA, six terms per product, direct-form conv with its tile padding (conv_x3.hip)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA" if kernel != "fc3_tail" else "fp32 VALU (= fp32 MFMA rate)"
 
@@ -93,7 +93,7 @@ def exec_flop(kernel, precision):
     """Matrix-pipe FLOPs issued per window by the kernel in this precision mode."""
     if precision == "fp32_split" and kernel == "fc1_gemm":
         return 6 * EXEC_FLOP[kernel]
-    if precision == "fp32_split" and kernel == "conv_stack":       # direct form on 16x16 tiles: (64*160 + 64*160 + 128*80) * 192 + 128*80*384 MACs
+    if precision in ("fp32_split", "bf16_fc") and kernel == "conv_stack":       # direct form on 16x16 tiles: (64*160 + 64*160 + 128*80) * 192 + 128*80*384 MACs
         return 6 * 2 * ((64 * 160 + 64 * 160 + 128 * 80) * 192 + 128 * 80 * 384)
     return EXEC_FLOP[kernel]
 
@@ -352,7 +352,8 @@ def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000):
 
 
 MODE_TEXT = {
-    "bf16_fc": "BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; conv stack and fc.6 fp32",
+    "bf16_fc": "BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; conv stack fp32-grade "
+               "(three-term bf16 operands on the bf16 matrix pipe, conv_x3.hip; DCE_X3_CONV=0: the fp32 Winograd kernel), fc.6 fp32",
     "fp32_split": "the bench step ({B} windows) with the conv stack and fc.0 on the bf16 matrix pipe, every fp32 operand as three bf16 terms "
                   "(six MFMAs per product, fp32 accumulate: fp32 results, not the fp32 path's bits -- opt-in, include/dce.h DCE_FP32_SPLIT); "
                   "fc.3 and fc.6 fp32 MFMA",
@@ -598,7 +599,7 @@ def main():
             "metric": METRIC, "value": wps, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16_fc": "f32 conv + bf16 FC (f32 accumulate)",
+            "dtype": {"fp32": "f32", "bf16_fc": "f32 conv (three-term bf16 operands, f32 accumulate) + bf16 FC (f32 accumulate)",
                       "fp32_split": "f32 (conv stack and fc.0: f32 operands as three bf16 terms on bf16 MFMA, f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: {B} pre-normalised windows (B,150,54) fp32 per GPU per step, "

@@ -180,13 +180,14 @@ void conv_x3_pack_host(int l, const float* w, unsigned short* out)
                         }
 }
 
-template <bool ZS, bool TAPS = false, bool F32OUT = false>
+template <bool ZS, bool TAPS = false, int OUT = 0>
 __global__ __launch_bounds__(256, 2)
 void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems,
                     LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr)
 {   // TAPS (dce_conv_layer_taps, parity tests): every layer's output also goes to HBM in fp32, and so do the features.
-    // F32OUT: the features leave as (n, 4736) fp32 in feat32 instead of three planes (batches below the split-bf16 fc.0
-    // kernel's threshold, whose fc.0 runs on the fp32 kernels)
+    // OUT: 0 the features leave as three bf16 planes (fc_gemm_x3.hip's layout); 1 as (n, 4736) fp32 in feat32 (batches below
+    // the split-bf16 fc.0 kernel's threshold, whose fc.0 runs on the fp32 kernels); 2 as (n, 4736) bf16, round-to-nearest-even,
+    // in feat3 (the DCE_BF16_FC precision, whose FC layers take bf16 operands)
     extern __shared__ __attribute__((aligned(16))) char cx_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -332,10 +333,19 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
 #pragma unroll
                         for (int r = 0; r < 4; ++r) feat32[(size_t)win * FEAT + (co + r) * 37 + (t >> 1)] = window_bad ? nanv : v[r];
                 }
-                if constexpr (F32OUT) {
+                if constexpr (OUT == 1) {
                     if ((j & 1) == 0 && (t >> 1) < 37) {
                         float* d = reinterpret_cast<float*>(cx_lds) + co * 37 + (t >> 1);
                         d[0] = v[0]; d[37] = v[1]; d[74] = v[2]; d[111] = v[3];
+                    }
+                } else if constexpr (OUT == 2) {
+                    unsigned lo[3], hi[3];                             // term 1 = the value rounded to bf16 (nearest-even)
+                    cx_split2(v[0], v[1], lo);
+                    cx_split2(v[2], v[3], hi);
+                    if ((j & 1) == 0 && (t >> 1) < 37) {
+                        unsigned short* d = reinterpret_cast<unsigned short*>(cx_lds) + co * 37 + (t >> 1);
+                        d[0] = (unsigned short)lo[0];  d[37] = (unsigned short)(lo[0] >> 16);
+                        d[74] = (unsigned short)hi[0]; d[111] = (unsigned short)(hi[0] >> 16);
                     }
                 } else {
                     unsigned lo[3], hi[3];
@@ -353,7 +363,16 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
             }
         }
         __syncthreads();
-        if constexpr (F32OUT) {
+        if constexpr (OUT == 2) {
+            for (int q = tid; q < FEAT / 8; q += 256) {
+                uint4 val = reinterpret_cast<const uint4*>(cx_lds)[q];
+                if (window_bad) val = make_uint4(0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u);
+                reinterpret_cast<uint4*>(feat3 + (size_t)win * FEAT)[q] = val;
+            }
+            TRACE_MARK(9);
+            return;
+        }
+        if constexpr (OUT == 1) {
             const float nn = __builtin_nanf("");
             for (int q = tid; q < FEAT / 4; q += 256) {
                 float4 val = reinterpret_cast<const float4*>(cx_lds)[q];
@@ -381,9 +400,13 @@ hipError_t init_conv_x3()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
 }
@@ -404,8 +427,18 @@ hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const Con
 {
     if (n <= 0) return hipSuccess;
     plan_note("conv_x3_f32");
-    if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat);
-    else        hipLaunchKernelGGL((conv_x3_kernel<false, false, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat);
+    if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 1>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat);
+    else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 1>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat);
+    return hipGetLastError();
+}
+
+// ... with (n, 4736) bf16 features out: the DCE_BF16_FC precision
+hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    plan_note("conv_x3_bf16");
+    if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+    else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
     return hipGetLastError();
 }
 

@@ -128,7 +128,12 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
     if (c->precision == DCE_BF16_FC) {
         // conv stack in fp32 -> bf16 features; fc.0 / fc.3 on bf16 MFMA with fp32 accumulate
         // (feat and h1 scratch hold bf16 here); fc.6 + argmax stay fp32
-        { Timer t(c, 0); HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream, c->src_row_dev)); }
+        { Timer t(c, 0);
+          // from 128 windows the conv stack runs on three-term bf16 operands (conv_x3.hip: fp32-grade results at 1.27x the
+          // fp32 Winograd kernel's rate), its features rounded to bf16 as the Winograd kernel's are; DCE_X3_CONV=0 switches back
+          if (c->tuning.x3_conv && c->winograd && !c->src_row_dev && n >= c->tuning.x3_conv_min)
+              HIP_TRY(c, launch_conv_x3_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream));
+          else HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream, c->src_row_dev)); }
         { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
         if (fc23_fused_ok(n, 1)) {
             { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch,
@@ -466,7 +471,8 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         }
     }
     size_t off_x3 = 0, off_cx[4] = {0, 0, 0, 0};
-    if (precision == DCE_FP32_SPLIT)
+    const bool want_cx = precision == DCE_FP32_SPLIT || (precision == DCE_BF16_FC && c->tuning.x3_conv);
+    if (want_cx)
         for (int l = 0; l < 4; ++l) {                     // conv weights as three-term planes, packed per lane (conv_x3.hip)
             off_cx[l] = reserve((conv_x3_pack_halfs(l) + 1) / 2);
             conv_x3_pack_host(l, c->host_w[2 * l].data(), reinterpret_cast<unsigned short*>(img.data() + off_cx[l]));
@@ -491,7 +497,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     c->fc1w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[0] : nullptr;
     c->fc2w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[1] : nullptr;
     for (int l = 0; l < 4; ++l) {
-        c->pkx3.w[l] = precision == DCE_FP32_SPLIT ? reinterpret_cast<const unsigned short*>(c->d_weights + off_cx[l]) : nullptr;
+        c->pkx3.w[l] = want_cx ? reinterpret_cast<const unsigned short*>(c->d_weights + off_cx[l]) : nullptr;
         c->pkx3.b[l] = c->pk.b[l];
     }
     c->fc1w_x3 = precision == DCE_FP32_SPLIT ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3) : nullptr;

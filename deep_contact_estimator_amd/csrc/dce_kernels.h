@@ -145,6 +145,7 @@ size_t     conv_x3_pack_halfs(int layer);
 void       conv_x3_pack_host(int layer, const float* w, unsigned short* out);
 hipError_t init_conv_x3();
 hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st);
+hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st);
 hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st);
 hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3& pk, unsigned short* feat3, float* feat32,
                                const LayerTaps& taps, hipStream_t st);

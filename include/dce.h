@@ -60,7 +60,8 @@ typedef enum dce_status {
 
 typedef enum dce_precision {
     DCE_FP32            = 0,   /* fp32 MFMA everywhere (exact fp32 fmaf chains) -- the headline path */
-    DCE_BF16_FC         = 1,   /* bf16 MFMA (fp32 accumulate) on the FC layers; conv stays fp32 */
+    DCE_BF16_FC         = 1,   /* bf16 operands (fp32 accumulate) on fc.0 / fc.3; the conv stack keeps fp32 results (from 128 windows per
+                                  call on three-term bf16 operands, csrc/conv_x3.hip, as in DCE_FP32_SPLIT; below that the fp32 kernels) */
     DCE_FP32_SPLIT      = 2    /* fp32 results with the conv stack and fc.0 of chip-filling batches on the bf16 matrix pipe: every fp32
                                   operand enters as three bf16 terms (a = a1 + a2 + a3 exactly), six bf16 MFMAs per product, fp32
                                   accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; the conv stack from 128

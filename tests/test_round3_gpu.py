@@ -128,8 +128,20 @@ def test_bf16_fc_vs_independent_restatement(n, model_of, orc):
     t16 = m16.forward_taps(x)
     feat32 = m32.forward_taps(x)["feat"]
     assert t16["feat"].dtype == np.uint16 and t16["h1"].dtype == np.uint16
-    # (1) features: exact
-    assert np.array_equal(t16["feat"], orc.bf16_bits(orc.bf16_round(feat32)))
+    # (1) features.  Below 128 windows the conv kernel is the fp32 context's and only the store differs: exact.  From 128 windows
+    # the mode's conv stack runs on three-term bf16 operands (csrc/conv_x3.hip): fp32-grade values in another association, so
+    # a value within fp32 noise of a bf16 rounding boundary may round the other way -- rare, and never by more than that.
+    want16 = orc.bf16_round(feat32)
+    got16 = orc.bf16_from_bits(t16["feat"])
+    if n < 128:
+        assert np.array_equal(t16["feat"], orc.bf16_bits(want16))
+    else:
+        assert m16.last_plan()[0] == "conv_x3_bf16", m16.last_plan()
+        fd = got16 != want16
+        assert fd.mean() < 2e-3, f"{fd.sum()} of {fd.size} features round differently"
+        _, fe = np.frexp(np.maximum(np.abs(want16), np.abs(got16)))
+        fbad = fd & (np.abs(got16 - feat32) > np.ldexp(0.5, fe - 8) + 1e-5 * np.abs(feat32).max() + 1e-4 * np.abs(feat32))
+        assert not fbad.any(), f"{fbad.sum()} features differ by more than a rounding-boundary flip"
     # (2) fc.0 on the device's own bf16 features
     w1, w2 = orc.bf16_round(sd["fc.0.weight"]), orc.bf16_round(sd["fc.3.weight"])
     feat16 = orc.bf16_from_bits(t16["feat"][sl])
