@@ -270,6 +270,7 @@ def test_conv_rt4_equals_its_predecessor_bitwise(monkeypatch):
     x = rng.standard_normal((2049, 150, 54), dtype=np.float32)
     x[7, 3, 5] = np.nan; x[1000, 100, 0] = np.inf
     seq = rng.standard_normal((1500 + 149, 54)).astype(np.float32) * 3 + 1
+    monkeypatch.setenv("DCE_X3_CONV", "0")                   # bf16_fc: the Winograd conv stack (its default is conv_x3.hip from 128 windows)
     for precision in ("fp32", "bf16_fc"):
         old = contact_cnn(device=0, max_batch=4096, precision=precision); old.load_state_dict(sd)
         ref_t = old.forward_taps(x); assert old.last_plan()[0] == "conv_wino2"

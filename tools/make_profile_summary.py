@@ -83,7 +83,7 @@ def main(tag):
         lines += ["", "bf16-FC mode (`--precision bf16_fc`), same step:", "",
                   "| kernel | MFMA busy | LDS busy: SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE/8) | bank-conflict cycles / LDS active | LDS instructions per launch | L2 hit rate | TCC_REQ |",
                   "|---|---|---|---|---|---|---|"]
-        for k in ("conv_stack", "fc1_gemm_bf16", "fc2_gemm_bf16"):
+        for k in ("conv_stack", "conv_x3", "fc1_gemm_bf16", "fc2_gemm_bf16"):
             c = b16.get(k)
             if not c or "GRBM_GUI_ACTIVE" not in c:
                 continue
