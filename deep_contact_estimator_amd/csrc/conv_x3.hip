@@ -12,9 +12,9 @@
 // One workgroup = 4 waves = ONE window; 63 KB of LDS -> two workgroups per CU.  Activations live in LDS as three bf16
 // planes, [position][channel] (position p = t + 1; rows 0 and T + 1 are the zero padding): the B operand of
 // v_mfma_f32_16x16x32_bf16 -- lane (j = column = position, g): 8 consecutive channels -- is then ONE ds_read_b128 per plane,
-// for every tap (tap k reads row t + k).  16-byte slot s of row r is stored at s ^ swz(r) (128-byte rows: (r >> 1) & 7,
-// 256-byte rows: r & 15) so that the 16 rows a read touches spread over all banks; the swizzle of row t + k + 16 ct does
-// not depend on the column tile ct, so a K-step needs one address register and 15 immediates.
+// for every tap (tap k reads row t + k).  16-byte slot s of row r is stored at s ^ swz(r) (cx_swz below) so that the rows a
+// read touches spread over all banks for every tap; the swizzle of row t + k + 16 ct does not depend on the column tile ct,
+// so a K-step needs one address register and 15 immediates.
 // GEMM per layer: M = Cout (16-row tiles), N = positions (16-column tiles: 150 -> 10, 75 -> 5), K = 3 taps x Cin in steps
 // of 32 channels.  A wave holds 2 row tiles x 5 column tiles (40 accumulator registers); per K-step it reads 6 weight
 // fragments (packed per lane on the host, three planes, streamed from L2) and 15 activation fragments and issues 60 MFMAs;
@@ -31,6 +31,10 @@ namespace dce {
 typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float cx_f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CX_EXP
+#define CX_EXP 0     // timing / counter probes (WRONG results): 1 no LDS stores in the write-backs, 2 none in the feature staging, 4 none in the prologue, 8 no activation reads in the K loop
+#endif
+
 namespace {
 
 constexpr int CX_ROWS1 = 16 * 10 + 2, CX_ROWS2 = 16 * 5 + 2;      // LDS rows a stage reads: every column tile x every tap
@@ -43,7 +47,13 @@ static const int cxCin[4]  = {54, 64, 64, 128};
 static const int cxCinP[4] = {64, 64, 64, 128};
 static const int cxCout[4] = {64, 64, 128, 128};
 
-template <int ROWB> __device__ __forceinline__ int cx_swz(int row) { return ROWB == 128 ? (row >> 1) & 7 : row & 15; }
+// Swizzle of the 16-byte slots of a row.  ds_read_b128 serves 16 lanes a cycle -- lanes {0-3, 12-15, 20-27} and {4-11, 16-19,
+// 28-31} of each half wave -- over 64 banks = sixteen 16-byte positions; here lane = (row offset j = lane & 15, slot offset
+// g = lane >> 4), and the three taps start at rows = 0, 1, 2 (mod 16).  These two functions make all sixteen positions of every
+// cycle distinct for all three alignments (exhaustive check of the lane grouping above; with (row >> 1) & 7 / row & 15 -- the
+// swizzles of the GEMM kernels, whose reads start at multiples of 32 rows -- taps 1 and 2 ran into two-way conflicts:
+// SQ_LDS_BANK_CONFLICT 2.3e7 of 6.7e7 LDS cycles per launch).  Both repeat every 8 rows, so they do not depend on the column tile.
+template <int ROWB> __device__ __forceinline__ int cx_swz(int row) { return ROWB == 128 ? row & 7 : (row & 7) << 1; }
 
 // byte offset of channel ch (bf16) of row `row` inside a plane
 template <int ROWB> __device__ __forceinline__ int cx_addr(int row, int ch)
@@ -85,7 +95,7 @@ __device__ __forceinline__ void cx_layer(const char* __restrict__ xrow, const in
 #pragma unroll
         for (int ct = 0; ct < CX_NT; ++ct)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[b][ct][p] = *reinterpret_cast<const uint4*>(x + ct * 16 * ROWB + p * CX_PLANE);
+            for (int p = 0; p < 3; ++p) if (!(CX_EXP & 8) || s == 0) bf[b][ct][p] = *reinterpret_cast<const uint4*>(x + ct * 16 * ROWB + p * CX_PLANE);
     };
     // (Requesting the NEXT layer's first weight fragments before the write-back, so that its barriers do not stand in front
     //  of an L2 round trip, was tried: 24 more live registers, 84-100 B of scratch, 394 us instead of 350.)
@@ -147,7 +157,7 @@ __device__ __forceinline__ void cx_store(char* __restrict__ lds, const cx_f32x4 
             unsigned lo[3], hi[3];
             cx_split2(v[0], v[1], lo);
             cx_split2(v[2], v[3], hi);
-            if (ok) {
+            if (ok && !(CX_EXP & 1)) {
                 char* d = lds + cx_addr<ROWB_OUT>(row, co);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * CX_PLANE) = make_uint2(lo[p], hi[p]);
@@ -244,7 +254,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         for (int q = 0; q < 16; ++q) {
             unsigned p[3];
             cx_split2(v[q].x, v[q].y, p);
-            if (tid + 256 * q < WIN * CH / 2) {
+            if (tid + 256 * q < WIN * CH / 2 && !(CX_EXP & 4)) {
                 char* d = cx_lds + cx_addr<128>(t + 1, 2 * c2);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(d + k * CX_PLANE) = p[k];
@@ -351,7 +361,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
                     unsigned lo[3], hi[3];
                     cx_split2(v[0], v[1], lo);
                     cx_split2(v[2], v[3], hi);
-                    if ((j & 1) == 0 && (t >> 1) < 37) {
+                    if ((j & 1) == 0 && (t >> 1) < 37 && !(CX_EXP & 2)) {
                         unsigned short* d = reinterpret_cast<unsigned short*>(cx_lds) + co * 37 + (t >> 1);
 #pragma unroll
                         for (int p = 0; p < 3; ++p) {
