@@ -41,6 +41,9 @@ def main(argv=None):
                         default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "config",
                                              "inference_one_seq_params.yaml"))
     parser.add_argument("--fused", action="store_true", help="one fused pass instead of the batch loop")
+    parser.add_argument("--precision", default=None, choices=["fp32", "bf16_fc", "fp32_split"],
+                        help="arithmetic of the library (default fp32 = the reference's; the YAML may carry a `precision` key too): "
+                             "bf16_fc = bf16 operands on fc.0 / fc.3; fp32_split = fp32 results on the bf16 matrix pipe (DESIGN.md 4.1x / 4.2x)")
     args = parser.parse_args(argv)
     config = yaml.safe_load(open(args.config_name))
 
@@ -48,7 +51,8 @@ def main(argv=None):
                               window_size=config["window_size"], device=device)
     dataloader = WindowLoader(dataset, batch_size=config["batch_size"])
 
-    model = contact_cnn(device=local, max_batch=max(int(config["batch_size"]), 32768))
+    model = contact_cnn(device=local, max_batch=max(int(config["batch_size"]), 32768),
+                        precision=args.precision or config.get("precision", "fp32"))
     model.load_state_dict(load_checkpoint(config["model_load_path"]))
     model = model.eval().to(device)
 
