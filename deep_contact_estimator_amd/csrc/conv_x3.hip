@@ -1,7 +1,9 @@
 // conv_x3.hip -- the conv stack (z-score + 4 x [Conv1d k3 p1 + ReLU] + 2 x MaxPool1d(2) + flatten; reference
 // src/contact_cnn.py:10-44,61,64 and utils/data_handler.py:55-56) with fp32 results on the bf16 matrix pipe: every fp32
 // operand -- activations and weights -- enters the MFMAs as THREE bf16 terms (a = a1 + a2 + a3 exactly), six bf16 x bf16
-// MFMAs per product, fp32 accumulate.  Precision DCE_FP32_SPLIT (opt-in), see fc_gemm_x3.hip for the arithmetic.
+// MFMAs per product, fp32 accumulate (fc_gemm_x3.hip has the arithmetic).  Used by the DCE_FP32_SPLIT precision from 128 windows per
+// call (features out as three bf16 planes for fc_gemm_x3.hip, or as fp32 below that kernel's threshold) and by DCE_BF16_FC (features
+// out rounded to bf16: the first term of the last split); never by the default DCE_FP32 precision.
 //
 // Why not Winograd here: its input transform would have to produce three-term operands on the fly (six more VALU
 // operations per transformed value, on a kernel that is already bound by what it issues between MFMAs).  In the direct form
@@ -19,8 +21,8 @@
 // of 32 channels.  A wave holds 2 row tiles x 5 column tiles (40 accumulator registers); per K-step it reads 6 weight
 // fragments (packed per lane on the host, three planes, streamed from L2) and 15 activation fragments and issues 60 MFMAs;
 // the fragments of step s+1 are requested before the MFMAs of step s.  Write-back (in place, between two barriers; the bias
-// is the accumulators' initial value): ReLU, MaxPool (neighbouring columns sit in neighbouring lanes: one DPP quad_perm), split into the three terms
-// (v_cvt_pk_bf16_f32), 8-byte stores.  conv4 + pool leave the workgroup as three planes in the layout fc_gemm_x3.hip reads.
+// is the accumulators' initial value): ReLU, MaxPool (neighbouring columns sit in neighbouring lanes: one DPP quad_perm), split
+// into the three terms (v_cvt_pk_bf16_f32), 8-byte stores.  conv4 + pool go through LDS once more and leave as 16-byte stores.
 #include "conv_common.h"
 #include <cfloat>
 #include <cstring>
