@@ -294,5 +294,9 @@ def test_bench_default_line_contract():
     ex = j["extra"]
     assert ex["streaming_1e6"]["hbm_resident_windows_per_s"] > 1e6 and ex["bf16_fc"]["windows_per_s"] > 1e6
     assert 10 < ex["online_push"]["us_per_push"] < 500 and ex["online_push"]["pushes"] >= 1000
+    fs = ex["fp32_split"]                                    # the opt-in precision: fp32-grade results, so (almost) no argmax change
+    assert fs["windows_per_s"] > 1e6 and fs["vs_fp32_same_input"]["argmax_flips"] <= 2
+    assert fs["vs_fp32_same_input"]["max_abs_dlogit"] < 1e-4 * fs["vs_fp32_same_input"]["max_abs_logit"]
+    assert "bf16 MFMA" in fs["kernels"]["fc1_gemm"]["pipe"] and "bf16 MFMA" in fs["kernels"]["conv_stack"]["pipe"]
     sb = ex["small_batches"]["batches"]
     assert set(sb) >= {"1", "30"} and 0 < sb["1"]["us_per_call"] < sb["30"]["us_per_call"] < 500
