@@ -68,6 +68,8 @@ Tuning tuning_from_env()
     t.x3_unfused = getenv("DCE_X3_UNFUSED") != nullptr;
     t.x3_conv = num("DCE_X3_CONV", t.x3_conv ? 1 : 0) != 0;
     t.x3_conv_min = num("DCE_X3_CONV_MIN", t.x3_conv_min);
+    t.x3_pair = num("DCE_X3_PAIR", t.x3_pair ? 1 : 0) != 0;
+    t.x3_pair_min = num("DCE_X3_PAIR_MIN", t.x3_pair_min);
     return t;
 }
 
@@ -128,13 +130,17 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
     if (c->precision == DCE_BF16_FC) {
         // conv stack in fp32 -> bf16 features; fc.0 / fc.3 on bf16 MFMA with fp32 accumulate
         // (feat and h1 scratch hold bf16 here); fc.6 + argmax stay fp32
+        // chip-filling batch: two windows per workgroup, a phase apart (conv_x3p.hip); its features -- and the fc.0 weights used
+        // behind it -- are in the K order t' * 128 + c.  A tap of the features keeps the reference's flatten order (conv_x3.hip).
+        const bool pair = c->tuning.x3_conv && c->tuning.x3_pair && c->winograd && !c->src_row_dev && !c->want_feat && n >= c->tuning.x3_pair_min;
         { Timer t(c, 0);
           // from 128 windows the conv stack runs on three-term bf16 operands (conv_x3.hip: fp32-grade results at 1.27x the
           // fp32 Winograd kernel's rate), its features rounded to bf16 as the Winograd kernel's are; DCE_X3_CONV=0 switches back
-          if (c->tuning.x3_conv && c->winograd && !c->src_row_dev && n >= c->tuning.x3_conv_min)
+          if (pair) HIP_TRY(c, launch_conv_x3p_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream));
+          else if (c->tuning.x3_conv && c->winograd && !c->src_row_dev && n >= c->tuning.x3_conv_min)
               HIP_TRY(c, launch_conv_x3_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream));
           else HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream, c->src_row_dev)); }
-        { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
+        { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, pair ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
         if (fc23_fused_ok(n, 1)) {
             { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch,
                                                           c->want_h2 ? c->h2 : nullptr, n, c->stream)); }
@@ -148,8 +154,10 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         // (unless a tap wants them in fp32, or the direct-form conv kernel is selected: then a kernel of its own splits them)
         const bool x3 = c->precision == DCE_FP32_SPLIT && fc_gemm_x3_ok(n, FC1, FEAT);
         const bool x3_fused = x3 && c->winograd && !c->want_feat && !c->tuning.x3_unfused;
+        const bool pair = x3_fused && c->tuning.x3_conv && c->tuning.x3_pair && !c->src_row_dev && n >= c->tuning.x3_pair_min;     // conv_x3p.hip (K order t' * 128 + c)
         { Timer t(c, 0);
-          if (x3_fused && c->tuning.x3_conv && !c->src_row_dev) HIP_TRY(c, launch_conv_x3(src, zscore, n, c->pkx3, c->feat3, c->stream));
+          if (pair) HIP_TRY(c, launch_conv_x3p(src, zscore, n, c->pkx3, c->feat3, c->stream));
+          else if (x3_fused && c->tuning.x3_conv && !c->src_row_dev) HIP_TRY(c, launch_conv_x3(src, zscore, n, c->pkx3, c->feat3, c->stream));
           else if (x3_fused) HIP_TRY(c, launch_conv_wino(src, zscore, n, c->pk, c->feat3, 2, c->stream, c->src_row_dev));
           else if (c->precision == DCE_FP32_SPLIT && !x3 && c->tuning.x3_conv && c->winograd && !c->src_row_dev && !c->want_feat && n >= c->tuning.x3_conv_min)
               HIP_TRY(c, launch_conv_x3_f32(src, zscore, n, c->pkx3, c->feat, c->stream));      // mid-size batch: three-term conv stack, fp32 FC kernels
@@ -161,7 +169,7 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
             // fc.0 on the bf16 matrix pipe with three-term operands (fc_gemm_x3.hip); everything else as in DCE_FP32
             Timer t(c, 1);
             if (!x3_fused) HIP_TRY(c, launch_split3(c->feat, c->feat3, n, FEAT, c->stream));
-            HIP_TRY(c, launch_fc_gemm_x3(c->feat3, c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream));
+            HIP_TRY(c, launch_fc_gemm_x3(c->feat3, pair ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream));
         } else
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
         if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1) && !fc_split_ok(n, FC2, FC1)) {
@@ -355,6 +363,7 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     CREATE_TRY(init_fc_gemm());
     CREATE_TRY(init_fc_gemm_x3());
     CREATE_TRY(init_conv_x3());
+    CREATE_TRY(init_conv_x3p());
     CREATE_TRY(hipMalloc(&c->feat, (size_t)max_batch * FEAT * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h1, (size_t)max_batch * FC1 * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h2, (size_t)max_batch * FC2 * sizeof(float)));
@@ -456,22 +465,31 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         off_fc[k] = reserve(v.size());
         memcpy(img.data() + off_fc[k], v.data(), v.size() * sizeof(float));
     }
-    size_t off_bf[2] = {0, 0};
+    auto to_bf16 = [](const float* v, size_t count, unsigned short* d) {     // round-to-nearest-even; NaN stays NaN
+        for (size_t i = 0; i < count; ++i) {
+            unsigned u; memcpy(&u, &v[i], 4);
+            d[i] = ((u & 0x7fffffffu) > 0x7f800000u) ? (unsigned short)((u >> 16) | 0x40)
+                                                     : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+    };
+    const bool want_cx = precision == DCE_FP32_SPLIT || (precision == DCE_BF16_FC && c->tuning.x3_conv);
+    const bool want_pair = want_cx && c->tuning.x3_pair;              // conv_x3p.hip: fc.0's weights once more, K axis in its feature order
+    std::vector<float> w1p;
+    if (want_pair) { w1p.resize(c->host_w[8].size()); fc_perm_k_host(c->host_w[8].data(), FC1, w1p.data()); }
+    size_t off_bf[2] = {0, 0}, off_bfp = 0;
     if (precision == DCE_BF16_FC) {
         // bf16 copies of fc.0 / fc.3 weights (round-to-nearest-even), same [out][in] layout
         for (int k = 0; k < 2; ++k) {
             const auto& v = c->host_w[8 + 2 * k];
             off_bf[k] = reserve((v.size() + 1) / 2);
-            unsigned short* d = reinterpret_cast<unsigned short*>(img.data() + off_bf[k]);
-            for (size_t i = 0; i < v.size(); ++i) {
-                unsigned u; memcpy(&u, &v[i], 4);
-                d[i] = ((u & 0x7fffffffu) > 0x7f800000u) ? (unsigned short)((u >> 16) | 0x40)
-                                                         : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-            }
+            to_bf16(v.data(), v.size(), reinterpret_cast<unsigned short*>(img.data() + off_bf[k]));
+        }
+        if (want_pair) {
+            off_bfp = reserve((w1p.size() + 1) / 2);
+            to_bf16(w1p.data(), w1p.size(), reinterpret_cast<unsigned short*>(img.data() + off_bfp));
         }
     }
-    size_t off_x3 = 0, off_cx[4] = {0, 0, 0, 0};
-    const bool want_cx = precision == DCE_FP32_SPLIT || (precision == DCE_BF16_FC && c->tuning.x3_conv);
+    size_t off_x3 = 0, off_x3p = 0, off_cx[4] = {0, 0, 0, 0};
     if (want_cx)
         for (int l = 0; l < 4; ++l) {                     // conv weights as three-term planes, packed per lane (conv_x3.hip)
             off_cx[l] = reserve((conv_x3_pack_halfs(l) + 1) / 2);
@@ -482,6 +500,10 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         const auto& v = c->host_w[8];
         off_x3 = reserve((3 * v.size() + 1) / 2);
         split3_host(v.data(), FC1, FEAT, reinterpret_cast<unsigned short*>(img.data() + off_x3));
+        if (want_pair) {
+            off_x3p = reserve((3 * v.size() + 1) / 2);
+            split3_host(w1p.data(), FC1, FEAT, reinterpret_cast<unsigned short*>(img.data() + off_x3p));
+        }
         if (!c->feat3) HIP_TRY(c, hipMalloc(&c->feat3, (size_t)(c->max_batch + 1) * FEAT * 3 * sizeof(unsigned short)));
     }
     if (c->d_weights) { HIP_TRY(c, hipFree(c->d_weights)); c->d_weights = nullptr; }
@@ -496,11 +518,13 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     c->fc3w = c->d_weights + off_fc[4]; c->fc3b = c->d_weights + off_fc[5];
     c->fc1w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[0] : nullptr;
     c->fc2w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[1] : nullptr;
+    c->fc1w_bf16p = precision == DCE_BF16_FC && want_pair ? c->d_weights + off_bfp : nullptr;
     for (int l = 0; l < 4; ++l) {
         c->pkx3.w[l] = want_cx ? reinterpret_cast<const unsigned short*>(c->d_weights + off_cx[l]) : nullptr;
         c->pkx3.b[l] = c->pk.b[l];
     }
     c->fc1w_x3 = precision == DCE_FP32_SPLIT ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3) : nullptr;
+    c->fc1w_x3p = precision == DCE_FP32_SPLIT && want_pair ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3p) : nullptr;
     c->precision = precision;
     c->finalized = true;
     return DCE_OK;

@@ -35,11 +35,13 @@ struct dce_ctx {
     const float *fc1w = nullptr, *fc1b = nullptr, *fc2w = nullptr, *fc2b = nullptr,
                 *fc3w = nullptr, *fc3b = nullptr;
     const void *fc1w_bf16 = nullptr, *fc2w_bf16 = nullptr;   // DCE_BF16_FC only
+    const void* fc1w_bf16p = nullptr;                        // ... fc.0 with its K axis in conv_x3p.hip's feature order (t' * 128 + c)
 
     float *feat = nullptr, *h1 = nullptr, *h2 = nullptr;   // scratch, max_batch rows each
     unsigned short* feat3 = nullptr;                        // DCE_FP32_SPLIT: the features as three bf16 planes [3][n][4736]
     dce::ConvPackX3 pkx3{};                                      // ... and the conv weights, packed per lane (conv_x3.hip)
     const unsigned short* fc1w_x3 = nullptr;                // ... and fc.0's weights, [3][2048][4736] (inside d_weights)
+    const unsigned short* fc1w_x3p = nullptr;               // ... and the same with the K axis in conv_x3p.hip's feature order
     float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
     bool want_feat = false;                                // dce_forward_taps: DCE_FP32_SPLIT keeps the fp32 features (split by a kernel of its own)
     bool want_h2 = false;                                  // dce_forward_taps: the fused epilogue also writes h2

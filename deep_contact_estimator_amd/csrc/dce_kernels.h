@@ -30,6 +30,8 @@ struct Tuning {
     bool x3_conv = true;                                    // DCE_X3_CONV=0: DCE_FP32_SPLIT keeps the fp32 Winograd conv stack (three-plane feature output) instead of conv_x3.hip (A/B)
     long long x3_conv_min = 128;                            // DCE_X3_CONV_MIN: from this many windows the mode's conv stack runs on conv_x3.hip also BELOW the fc.0 threshold (fp32 features out)
     bool x3_unfused = false;                                // DCE_X3_UNFUSED: fp32 features + split3 kernel instead of the conv kernel's three-plane output (A/B)
+    bool x3_pair = true;                                    // DCE_X3_PAIR=0: chip-filling batches stay on conv_x3.hip (one window per workgroup) instead of conv_x3p.hip (A/B)
+    long long x3_pair_min = 1024;                           // DCE_X3_PAIR_MIN: windows per launch from which conv_x3p.hip runs
     int x3_min_tiles = 192;                                 // DCE_X3_MIN_TILES: 256x128 tiles a launch needs for the split-bf16 fc.0 kernel
     int conv4 = 0;                                          // DCE_CONV4=1: four row tiles per wave in the two-window conv kernel (A/B; slower)
 };
@@ -149,6 +151,15 @@ hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const Co
 hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st);
 hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3& pk, unsigned short* feat3, float* feat32,
                                const LayerTaps& taps, hipStream_t st);
+// The same stack for chip-filling batches (conv_x3p.hip): one persistent workgroup per CU, two windows a fixed three phases
+// apart (one's write-back beside the other's MFMAs), next window by LDS-DMA.  The features leave in the K order
+// k' = t' * 128 + c (not the reference's flatten order c * 37 + t'): fc.0 behind it takes weights whose K axis is permuted
+// the same way (fc_perm_k_host).
+hipError_t init_conv_x3p();
+hipError_t launch_conv_x3p(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st);
+hipError_t launch_conv_x3p_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st);
+// out[o][t' * 128 + c] = w[o][c * 37 + t'] for the (rows, 4736) fc.0 weight
+void       fc_perm_k_host(const float* w, size_t rows, float* out);
 
 // The same GEMMs at chip-filling sizes (fc_gemm_phased.hip): one workgroup per CU, 256x128 or 128x64 tiles,
 // LDS-DMA staging, two wave groups one phase apart; fp32 (bit-identical to the tile kernels: same K order) and
