@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Debug: per-workgroup phase timeline of conv_x3p_kernel -- for both groups of every workgroup, the start of each phase and the
-end of its work (in front of the barrier), last window pair (needs build_variant('trace', ['-DDCE_TRACE=1']) and
-DCE_LIB=deep_contact_estimator_amd/libdce_trace.so)."""
+"""Debug: per-workgroup layer timeline of conv_x3p_kernel -- wave 0's clock at the start of every layer of its last window and in
+front of the barrier behind it (needs build_variant('trace', ['-DDCE_TRACE=1']) and DCE_LIB=deep_contact_estimator_amd/libdce_trace.so)."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,18 +14,15 @@ for _ in range(3): m.predict(x)
 torch.cuda.synchronize()
 print(m.last_plan())
 lib = _lib.load()
-nb = min(256, (B + 1) // 2)
-buf = np.zeros((nb, 64), np.uint64)
+nb = min(256, B)
+buf = np.zeros((nb, 16), np.uint64)
 assert lib.dce_debug_trace_read_x3p(buf.ctypes.data_as(C.c_void_p), nb) == 0
-t = buf.astype(np.int64).reshape(nb, 2, 32)[:, :, :16]
-names = ["0 out+in", "1 conv1", "2 store", "3 conv2", "4 store+pool", "5 conv3", "6 store", "7 conv4"]
-print("cycles, mean over workgroups (wave 0 of each group, its last window): work = phase start -> in front of the barrier; wait = barrier")
-for g in range(2):
-    print(f" group {g}")
-    for ph in range(8):
-        work = t[:, g, 2 * ph + 1] - t[:, g, 2 * ph]
-        nxt = t[:, g, 2 * ph + 2] if ph < 7 else None
-        wait = (nxt - t[:, g, 2 * ph + 1]).mean() if nxt is not None else float("nan")
-        print(f"  {names[ph]:13s} work {work.mean():8.0f} (p10 {np.percentile(work, 10):7.0f} p90 {np.percentile(work, 90):7.0f})   wait {wait:8.0f}")
-    print(f"  phases 0..7 of one window: {(t[:, g, 15] - t[:, g, 0]).mean():.0f} cycles to the end of conv4's work")
-print("MFMAs of two windows on a SIMD: 57,600 cycles; per wave: conv1/2/3 5,760 each, conv4 11,520")
+t = buf.astype(np.int64)
+names = ["conv1", "conv2+pool", "conv3", "conv4+prologue"]
+pure = [2880, 2880, 2880, 5760]
+print("cycles, mean over workgroups (wave 0, last window): work = layer start -> in front of its barrier; wait = barrier; MFMAs alone")
+for l in range(4):
+    work = t[:, 2 * l + 1] - t[:, 2 * l]
+    wait = (t[:, 2 * l + 2] - t[:, 2 * l + 1]).mean() if l < 3 else float("nan")
+    print(f"  {names[l]:15s} work {work.mean():8.0f} (p10 {np.percentile(work, 10):7.0f} p90 {np.percentile(work, 90):7.0f})  wait {wait:7.0f}   2 waves x {pure[l]} = {2 * pure[l]}")
+print(f"  one window, conv1 start -> conv4 end: {(t[:, 7] - t[:, 0]).mean():.0f} cycles; MFMAs of one window on a SIMD: 28,800")
