@@ -23,10 +23,18 @@
 // the fragments of step s+1 are requested before the MFMAs of step s.  Write-back (in place, between two barriers; the bias
 // is the accumulators' initial value): ReLU, MaxPool (neighbouring columns sit in neighbouring lanes: one DPP quad_perm), split
 // into the three terms (v_cvt_pk_bf16_f32), 8-byte stores.  conv4 + pool go through LDS once more and leave as 16-byte stores.
-#include "conv_x3_common.h"
 #include <cfloat>
 #include <cstring>
 #include <type_traits>
+
+#ifndef CX_ILV
+#define CX_ILV 1        // the fragment requests of K-step s + 1 dealt out between the MFMAs of step s instead of going out in a bunch ahead of them (A/B: -DCX_ILV=0; 319.5 -> 312.4 us per 4096 windows)
+#endif
+#ifndef CX_SCALAR_SPLIT
+#define CX_SCALAR_SPLIT 1   // the split's exact remainders on v_sub_f32 instead of v_pk_add_f32 (A/B: -DCX_SCALAR_SPLIT=0; 319.5 -> 311.7 us, both: 308.4; same bits)
+#endif
+
+#include "conv_x3_common.h"
 
 namespace dce {
 
@@ -148,14 +156,14 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         const int sw[3] = {cx_swz<128>(base), cx_swz<128>(base + 1), cx_swz<128>(base + 2)};
         const char* xrow = cx_lds + base * 128;
         bias_acc(pk.b[0], 32 * P);
-        cx_layer<128, 2>(xrow, sw, g, w0 + (size_t)P * (6 * 2 * 3 * 64), acc);
+        cx_layer<128, 2, false, CX_ILV != 0>(xrow, sw, g, w0 + (size_t)P * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(2);
         __syncthreads();                                               // every wave has read conv1's input
         cx_store<128, false, WIN, TAPS>(cx_lds, acc, 32 * P, ct0, j, g, TAPS ? taps.conv1 + win * 64 * 150 : nullptr);
         __syncthreads();
         TRACE_MARK(3);
         bias_acc(pk.b[1], 32 * P);
-        cx_layer<128, 2>(xrow, sw, g, w1 + (size_t)P * (6 * 2 * 3 * 64), acc);
+        cx_layer<128, 2, false, CX_ILV != 0>(xrow, sw, g, w1 + (size_t)P * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(4);
         __syncthreads();
         cx_store<128, true, WIN, TAPS>(cx_lds, acc, 32 * P, ct0, j, g, TAPS ? taps.conv2 + win * 64 * 150 : nullptr, TAPS ? taps.pool1 + win * 64 * 75 : nullptr);     // pooled: rows 1..75 of the stage-2 layout (64 channels)
@@ -167,7 +175,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
     {
         const int sw[3] = {cx_swz<128>(j), cx_swz<128>(j + 1), cx_swz<128>(j + 2)};
         bias_acc(pk.b[2], 32 * wv);
-        cx_layer<128, 2>(cx_lds + j * 128, sw, g, w2 + (size_t)wv * (6 * 2 * 3 * 64), acc);
+        cx_layer<128, 2, false, CX_ILV != 0>(cx_lds + j * 128, sw, g, w2 + (size_t)wv * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(6);
         __syncthreads();
         cx_store<256, false, 75, TAPS>(cx_lds, acc, 32 * wv, 0, j, g, TAPS ? taps.conv3 + win * 128 * 75 : nullptr);      // 128 channels: 256-byte rows, rows 1..75
@@ -179,7 +187,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         TRACE_MARK(7);
         const int sw4[3] = {cx_swz<256>(j), cx_swz<256>(j + 1), cx_swz<256>(j + 2)};
         bias_acc(pk.b[3], 32 * wv);
-        cx_layer<256, 4>(cx_lds + j * 256, sw4, g, w3 + (size_t)wv * (12 * 2 * 3 * 64), acc);
+        cx_layer<256, 4, false, CX_ILV != 0>(cx_lds + j * 256, sw4, g, w3 + (size_t)wv * (12 * 2 * 3 * 64), acc);
         TRACE_MARK(8);
         // ---- conv4 + bias + ReLU + MaxPool (t = 74 dropped) + flatten k = c * 37 + t' -> three planes [k] in LDS (the layer's
         //      input is dead once every wave is through its MFMAs), then 16-byte stores into fc_gemm_x3.hip's layout: 7 per

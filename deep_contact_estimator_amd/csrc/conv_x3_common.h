@@ -38,6 +38,17 @@ __device__ __forceinline__ void cx_split2(float v0, float v1, unsigned (&p)[3])
 {
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
+#if defined(CX_SCALAR_SPLIT) && CX_SCALAR_SPLIT
+    {   // plain v_sub_f32 for the exact remainders (written as instructions: the optimiser re-packs neighbouring subtractions into v_pk_add_f32)
+        auto sub = [](float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{v0, v1}, b2));
+            if (k < 2) { v0 = sub(v0, __builtin_bit_cast(float, p[k] << 16)); v1 = sub(v1, __builtin_bit_cast(float, p[k] & 0xffff0000u)); }
+        }
+        return;
+    }
+#endif
     const f2 v = {v0, v1};
     const b2 t1 = __builtin_convertvector(v, b2);
     const f2 r1 = v - __builtin_convertvector(t1, f2);

@@ -30,7 +30,7 @@ struct Tuning {
     bool x3_conv = true;                                    // DCE_X3_CONV=0: DCE_FP32_SPLIT keeps the fp32 Winograd conv stack (three-plane feature output) instead of conv_x3.hip (A/B)
     long long x3_conv_min = 128;                            // DCE_X3_CONV_MIN: from this many windows the mode's conv stack runs on conv_x3.hip also BELOW the fc.0 threshold (fp32 features out)
     bool x3_unfused = false;                                // DCE_X3_UNFUSED: fp32 features + split3 kernel instead of the conv kernel's three-plane output (A/B)
-    bool x3_pair = true;                                    // DCE_X3_PAIR=0: chip-filling batches stay on conv_x3.hip (one window per workgroup) instead of conv_x3p.hip (A/B)
+    bool x3_pair = false;                                   // DCE_X3_PAIR=1: chip-filling batches on conv_x3p.hip (two windows per 8-wave workgroup; measured 5-9 % SLOWER than conv_x3.hip, kept for the record and the A/B) instead of conv_x3.hip
     long long x3_pair_min = 1024;                           // DCE_X3_PAIR_MIN: windows per launch from which conv_x3p.hip runs
     int x3_min_tiles = 192;                                 // DCE_X3_MIN_TILES: 256x128 tiles a launch needs for the split-bf16 fc.0 kernel
     int conv4 = 0;                                          // DCE_CONV4=1: four row tiles per wave in the two-window conv kernel (A/B; slower)

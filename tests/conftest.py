@@ -14,13 +14,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def tol_ok(got, ref, what=""):
+def tol_ok(got, ref, what="", factor=1.0):
     """The stated fp32 contract:
-    |got-ref| <= 1e-5*max|ref| + 1e-4*|ref| elementwise."""
+    |got-ref| <= 1e-5*max|ref| + 1e-4*|ref| elementwise (times `factor` where a test says why)."""
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    bound = 1e-5 * np.abs(ref).max() + 1e-4 * np.abs(ref)
+    bound = factor * (1e-5 * np.abs(ref).max() + 1e-4 * np.abs(ref))
     err = np.abs(got - ref)
     bad = ~(err <= bound)           # also catches NaN
     assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} outside tol; max err {np.nanmax(err):.3e} " \

@@ -326,9 +326,41 @@ def bf16fc_case():
           f"flips {(logits.argmax(1) != fp32_logits.argmax(1)).sum().item()}")
 
 
+def chip_case():
+    """Case C: a CHIP-FILLING launch from the reference itself -- 4096 windows of an AR(1)+offset sequence, biased He weights
+    (the launch size of BASELINE.json configs[1]; src/test.py:72-107 loop shape, batch 512).  Only logits / argmax / margin are
+    kept (~250 KB): the kernels that serve chip-filling batches (256 x 128 phased GEMM, fused fc.3 epilogue, the three-term
+    conv stack) are otherwise compared with the reference's own numbers at <= 256 windows only."""
+    wseed, bias, T, sseed, kind = 3, "uniform", 4096 + 149, 11, "ar1"
+    sd = synth.make_state_dict(wseed, bias)
+    seq = synth.make_sequence(T, sseed, kind)
+    lab = synth.make_labels(T, sseed, two_d=False)
+    model = build_model(sd)
+    with tempfile.TemporaryDirectory() as d:
+        dp, lp = os.path.join(d, "data.npy"), os.path.join(d, "label.npy")
+        np.save(dp, seq); np.save(lp, lab)
+        ds = contact_dataset(data_path=dp, label_path=lp, window_size=150, device="cpu")
+        logits = []
+        with torch.no_grad():
+            for sample in DataLoader(dataset=ds, batch_size=512):
+                logits.append(model(sample["data"]).numpy().copy())
+    logits = np.concatenate(logits)
+    pred = logits.argmax(1).astype(np.int32)
+    srt = np.sort(logits, axis=1)
+    out = dict(wseed=wseed, bias=bias, T=T, sseed=sseed, kind=kind, seq_checksum=checksum(seq.astype(np.float32)),
+               w_checksum=np.stack([checksum(sd[k]) for k, _ in synth.STATE_DICT_SHAPES]),
+               logits=logits, pred=pred, margin=(srt[:, -1] - srt[:, -2]).astype(np.float32))
+    np.savez_compressed(os.path.join(HERE, "chip_ar1.npz"), **out)
+    print(f"chip_ar1: n={logits.shape[0]} classes {len(np.unique(pred))} max|logit| {np.abs(logits).max():.2f} "
+          f"median margin {np.median(out['margin']):.3f} min margin {out['margin'].min():.2e}")
+
+
 if __name__ == "__main__":
     if "--only-bf16fc" in sys.argv:
         bf16fc_case()
+        sys.exit(0)
+    if "--only-chip" in sys.argv:
+        chip_case()
         sys.exit(0)
     # case A: N(0,1) sequence, biased He weights, batch 30 (config/test_params.yaml:9), 1-D labels
     run_case("seq_normal", wseed=1, bias="uniform", T=150 + 255, sseed=0, kind="normal",
@@ -343,3 +375,4 @@ if __name__ == "__main__":
     loop_case()
     ingest_case()
     bf16fc_case()
+    chip_case()

@@ -14,10 +14,7 @@ from deep_contact_estimator_amd import contact_cnn, synth
 
 
 def make(precision, pair, max_batch=8192):
-    if pair:
-        os.environ.pop("DCE_X3_PAIR", None)
-    else:
-        os.environ["DCE_X3_PAIR"] = "0"
+    os.environ["DCE_X3_PAIR"] = "1" if pair else "0"
     m = contact_cnn(device=0, max_batch=max_batch, precision=precision)
     m._ensure_ctx()                                   # (the switches are read when the context is created)
     m.load_state_dict(synth.make_state_dict(1, "uniform")).eval()

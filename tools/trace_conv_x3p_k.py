@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Debug: conv1 of conv_x3p_kernel, every wave of every workgroup: clock at the K-step boundaries, the tail, the barrier
+"""Debug: phase 3 (conv2 X + features Y- + prologue Y) of conv_x3p_kernel, every wave of every workgroup: clock at the K-step boundaries, the tail, the barrier
 (build_variant('trace2', ['-DDCE_TRACE=2']), DCE_LIB=deep_contact_estimator_amd/libdce_trace2.so)."""
 import ctypes as C, os, sys
 import numpy as np
@@ -17,8 +17,8 @@ assert lib.dce_debug_trace_read_x3p_k(buf.ctypes.data_as(C.c_void_p), 256) == 0
 t = buf.astype(np.int64)
 t0 = t[:, :, 0].min(axis=1)[:, None, None]          # first wave into conv1
 r = t - t0
-names = ["enter", "step0", "step1", "step2", "step3", "step4", "last step", "last tile's tail", "tail done", "behind barrier"]
-print("cycles since the workgroup's first wave entered conv1; mean over 256 workgroups, per wave 0..7 (waves w, w+4 share a SIMD)")
+names = ["enter", "step0", "step1", "step2", "step3", "step4", "step5", "steps done", "-", "behind barrier"]
+print("cycles since the workgroup's first wave entered the phase; mean over 256 workgroups, per wave 0..7 (waves w, w+4 share a SIMD)")
 for k, nme in enumerate(names):
     print(f"  {nme:18s} " + " ".join(f"{r[:, w, k].mean():7.0f}" for w in range(8)))
 d = np.diff(r[:, :, :10], axis=2)
