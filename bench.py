@@ -472,6 +472,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DCE_DEVICE_MAP"):                    # "3,2,1,0": LOCAL_RANK -> index among the VISIBLE devices, for launchers whose
+        local_rank = int(os.environ["DCE_DEVICE_MAP"].split(",")[local_rank])      # local ranks are not device indices
     args.gpus = world                                       # the launcher's world is what runs
     backend = os.environ.get("DCE_DIST_BACKEND", "nccl")   # "gloo": functional check of the N>1 flow on
     if backend != "nccl":                                   # fewer GPUs than ranks (ranks share devices)
@@ -571,10 +573,29 @@ def main():
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own clock over the same region (it ends in a barrier: the spread is what each rank spent BEFORE it), so
+        # that a first multi-GPU record explains itself: which rank was the slow one, by how much
+        mine = time.perf_counter() - t0
+        t = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t[rank] = mine
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ms = (t / args.steps * 1e3).tolist()
+        per_rank = {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "rank_of_max": int(max(range(world), key=lambda r: ms[r])),
+                    "ms_per_step": [round(v, 4) for v in ms]}
+        elapsed = max(ms) * args.steps / 1e3
+    gather_us = None
+    if rccl_info is not None:
+        # the exchange alone: synchronous gathers of the last step's rows, host clock around issue + completion
+        last = gatherer.send[(gatherer._i - 1) & 1]
+        model.gather_results(last, None, root=0, out=gatherer.recv[0]); model.comm_sync()
+        dist.barrier()
+        tg = time.perf_counter()
+        for _ in range(20):
+            model.gather_results(last, None, root=0, out=gatherer.recv[0])
+            model.comm_sync()
+        gather_us = (time.perf_counter() - tg) / 20 * 1e6
 
     # 4. profiled pass: HIP events around every kernel of every step (same loop, same stream)
     prof, prof_ms_per_step, psteps = {}, None, max(args.steps, 50)
@@ -611,11 +632,14 @@ def main():
             },
         }
         if rccl_info is not None:
+            rccl_info["gather_alone_us"] = round(gather_us, 1)                 # one blocking dce_gather_results + dce_comm_sync, this rank's host clock
             res["rccl"] = rccl_info
         elif multi and rccl_fallback:
             res["rccl"] = {"backend": "FALLBACK " + rccl_fallback}
         elif multi:
             res["rccl"] = {"backend": f"none: torch.distributed {backend} with ranks sharing GPUs (functional test of the N>1 flow)"}
+        if per_rank is not None:
+            res["per_rank"] = per_rank
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
             kd = kernels[dom]
@@ -672,19 +696,25 @@ def main():
         if multi:
             # the headline above is measured; the sharded pass below must not be able to take it down with it: if a rank
             # fails or the pass hangs, every rank leaves after the deadline and rank 0 prints the line with the error in it
-            deadline = float(os.environ.get("DCE_EXTRA_TIMEOUT", "240"))
+            # (longer than the communicator's own watchdog plus a 1e6-window pass, so that a slow but healthy exchange is not cut off)
+            deadline = float(os.environ.get("DCE_EXTRA_TIMEOUT", str(max(240.0, float(os.environ.get("DCE_COMM_TIMEOUT", "180")) + 120.0))))
 
             def bail():
                 if not finished.wait(deadline):
                     if rank == 0 and not printed.is_set():
                         res.setdefault("extra", {"sharded_1e6": {"error": f"did not finish within {deadline:.0f} s"}})
+                        # the headline above stands (it was measured before this pass); the line says that the job is incomplete, so
+                        # that a reader of exit codes and a reader of the JSON both see a broken multi-GPU exchange
+                        res["partial"], res["status"] = True, f"extra.sharded_1e6 did not finish within {deadline:.0f} s"
                     emit()
-                    os._exit(0)
+                    os._exit(3)
             threading.Thread(target=bail, daemon=True, name="bench-extra-deadline").start()
             try:
                 sh = extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, use_rccl=rccl_fallback is None)
             except Exception as e:                                # noqa: BLE001
                 sh = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
+                if rank == 0:
+                    res["partial"], res["status"] = True, "extra.sharded_1e6 failed: " + sh["error"]
                 print(f"bench.py: extra.sharded_1e6 failed on rank {rank}: {e}", file=sys.stderr, flush=True)
             if rank == 0:
                 res["extra"] = {"sharded_1e6": sh}

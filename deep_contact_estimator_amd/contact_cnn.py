@@ -243,8 +243,8 @@ class contact_cnn:
             n = max(x.shape[0] - (WINDOW - 1) if raw_sequence else x.shape[0], 0)
             if out is None:
                 out = torch.empty((n, PACKED_ROW), dtype=torch.uint8, device=x.device)
-            elif tuple(out.shape) != (n, PACKED_ROW) or out.dtype != torch.uint8 or not out.is_contiguous():
-                raise RuntimeError(f"out must be a contiguous ({n},{PACKED_ROW}) uint8 tensor")
+            elif tuple(out.shape) != (n, PACKED_ROW) or out.dtype != torch.uint8 or not out.is_contiguous() or out.data_ptr() % 4:
+                raise RuntimeError(f"out must be a contiguous, 4-byte aligned ({n},{PACKED_ROW}) uint8 tensor")
             self._torch_stream(x)
             dst = C.c_void_p(out.data_ptr()) if n > 0 else None
             if raw_sequence:

@@ -224,6 +224,10 @@ int ensure_out(dce_ctx* c, size_t rows)
     return DCE_OK;
 }
 
+// packed rows are written (4-byte float / uchar4 stores) and read (unsigned loads) as 32-bit words: a DEVICE pointer to them must
+// be 4-byte aligned (the rows themselves are 68 bytes, so every row of an aligned buffer is)
+bool misaligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
+
 int check_ready(dce_ctx* c)
 {
     if (!c) return DCE_ERR_ARG;
@@ -560,6 +564,7 @@ int dce_forward_windows_packed(dce_ctx* c, const float* windows, int64_t n, int 
     if (rc) return rc;
     DEVICE_GUARD(c);
     if (n < 0 || (n > 0 && (!windows || !packed))) return fail(c, DCE_ERR_ARG, "dce_forward_windows_packed: bad argument");
+    if (on_device && misaligned4(packed)) return fail(c, DCE_ERR_ARG, "dce_forward_windows_packed: device `packed` must be 4-byte aligned");
     if (n == 0) return DCE_OK;
     return run_all(c, windows, 0, n, n * WIN * CH, on_device, nullptr, nullptr, nullptr, packed);
 }
@@ -572,6 +577,7 @@ int dce_infer_sequence_packed(dce_ctx* c, const float* seq, int64_t T, int windo
     if (window != WIN) return fail(c, DCE_ERR_ARG, "window_size must be %d (the model hard-codes 4736 = 128*37), got %d", WIN, window);
     const int64_t n = T - WIN + 1;
     if (T < 0 || (n > 0 && (!seq || !packed))) return fail(c, DCE_ERR_ARG, "dce_infer_sequence_packed: bad argument");
+    if (on_device && misaligned4(packed)) return fail(c, DCE_ERR_ARG, "dce_infer_sequence_packed: device `packed` must be 4-byte aligned");
     if (n <= 0) return DCE_OK;
     return run_all(c, seq, 1, n, T * CH, on_device, nullptr, nullptr, nullptr, packed);
 }
@@ -580,6 +586,7 @@ int dce_unpack_results(dce_ctx* c, const uint8_t* packed, int64_t n, int on_devi
                        float* logits, int32_t* pred, uint8_t* contacts)
 {
     if (n < 0 || (n > 0 && !packed) || (on_device && !c)) return fail(c, DCE_ERR_ARG, "dce_unpack_results: bad argument");
+    if (on_device && misaligned4(packed)) return fail(c, DCE_ERR_ARG, "dce_unpack_results: device `packed` must be 4-byte aligned");
     if (n == 0) return DCE_OK;
     if (on_device) {
         DEVICE_GUARD(c);
@@ -665,6 +672,11 @@ int dce_conv_layer_taps(dce_ctx* c, const float* windows, int64_t n, int kernel,
     DEVICE_GUARD(c);
     if (n <= 0 || n > c->max_batch || n > 64 || !windows || !conv1 || !conv2 || !pool1 || !conv3 || !conv4 || !feat)
         return fail(c, DCE_ERR_ARG, "dce_conv_layer_taps: need 0 < n <= min(64, max_batch) host windows and all six host outputs");
+    if (kernel == 7 && c->precision != DCE_FP32_SPLIT)
+        return fail(c, DCE_ERR_STATE, "dce_conv_layer_taps: kernel 7 (conv_x3) needs a context finalised with DCE_FP32_SPLIT");
+    if (c->precision == DCE_BF16_FC)
+        return fail(c, DCE_ERR_STATE, "dce_conv_layer_taps: not available in DCE_BF16_FC (its conv stack is the fp32 / three-term one: tap a DCE_FP32 or DCE_FP32_SPLIT context)");
+    TuningScope tuning_scope(&c->tuning);                 // the launchers below read this context's switches, not the process defaults
     // host pointers only (a test hook): stage the windows, run ONE named kernel family with its taps on, copy everything out
     const size_t in_f = (size_t)n * WIN * CH;
     const size_t sz[5] = {(size_t)n * 64 * 150, (size_t)n * 64 * 150, (size_t)n * 64 * 75, (size_t)n * 128 * 75, (size_t)n * 128 * 75};
@@ -677,8 +689,6 @@ int dce_conv_layer_taps(dce_ctx* c, const float* windows, int64_t n, int kernel,
                    d + in_f + sz[0] + sz[1] + sz[2] + sz[3]};
     HIP_TRY(c, hipMemcpyAsync(d, windows, in_f * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(d + in_f, 0xff, (total - in_f) * sizeof(float), c->stream));      // untouched taps read back as NaN
-    if (kernel == 7 && c->precision != DCE_FP32_SPLIT)
-        return fail(c, DCE_ERR_STATE, "dce_conv_layer_taps: kernel 7 (conv_x3) needs a context finalised with DCE_FP32_SPLIT");
     const hipError_t e = kernel == 7 ? launch_conv_x3_taps(d, n, c->pkx3, c->feat3, c->feat, taps, c->stream)
                                      : launch_conv_taps(kernel, d, n, c->pk, c->feat, taps, c->stream);
     if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? DCE_ERR_ARG : DCE_ERR_HIP, "dce_conv_layer_taps: kernel %d: %s", kernel, hipGetErrorString(e));

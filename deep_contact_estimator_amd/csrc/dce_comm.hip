@@ -164,6 +164,8 @@ int dce_gather_results(dce_ctx* c, const uint8_t* packed_local, int64_t n_local,
     const int W = c->comm_world, me = c->comm_rank;
     if (root < 0 || root >= W || n_local < 0 || (n_local > 0 && !packed_local))
         return fail(c, DCE_ERR_ARG, "dce_gather_results: bad argument");
+    if (((reinterpret_cast<uintptr_t>(packed_local) | reinterpret_cast<uintptr_t>(packed_all)) & 3u) != 0)
+        return fail(c, DCE_ERR_ARG, "dce_gather_results: the packed row buffers must be 4-byte aligned");
     bool uniform = true;
     int64_t total = 0;
     if (rows_per_rank) {

@@ -99,21 +99,61 @@ def gather_rows(t, sizes=None, group=None, dst: int = 0):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0).to(home)
 
 
+ID_FILE_NONCE = 16      # bytes of job nonce in front of the 128-byte ncclUniqueId (the same file format as tests/c/abi_ranks.c)
+
+
+def id_file_rendezvous(path: str, rank: int, make_id, timeout: float = 120.0) -> bytes:
+    """The ncclUniqueId of rank 0 through a file, safe against a file an earlier job left behind: the payload is
+    <16-byte nonce><128-byte id>, the nonce comes from DCE_COMM_NONCE (the launcher draws one per job; tools/launch_ranks.sh);
+    rank 0 removes a left-over, writes a temporary file and renames it; the others accept only a file with THEIR nonce -- a
+    stale id would otherwise send ncclCommInitRank waiting for peers that will never come -- and give up after `timeout`.
+    Without DCE_COMM_NONCE the nonce is empty and a file older than this process by more than an hour is taken for stale."""
+    import os
+    import time
+    nonce = os.environ.get("DCE_COMM_NONCE", "").encode()[:ID_FILE_NONCE].ljust(ID_FILE_NONCE, b"\0")
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except FileNotFoundError:
+            pass
+        uid = make_id()
+        tmp = f"{path}.tmp.{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(nonce + uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        try:
+            with open(path, "rb") as f:
+                buf = f.read()
+            fresh = any(nonce) or os.path.getmtime(path) > t0 - 3600.0
+            if len(buf) == ID_FILE_NONCE + 128 and buf[:ID_FILE_NONCE] == nonce and fresh:
+                return buf[ID_FILE_NONCE:]
+        except FileNotFoundError:
+            pass
+        time.sleep(0.01)
+    raise RuntimeError(f"no ncclUniqueId of this job (DCE_COMM_NONCE) appeared at {path} within {timeout:.0f} s")
+
+
 _bootstraps = 0
 
 
 def comm_bootstrap(model, rank: int, world: int, key: str = "dce_comm_id"):
     """Give `model` (one per rank) the node's RCCL communicator: rank 0 draws an ncclUniqueId and the 128 bytes travel
     through the store of the initialised torch.distributed group (TCP, no GPU collective), or -- with DCE_COMM_ID_FILE
-    set and no process group -- through that file (written atomically by rank 0, polled by the others)."""
+    set and no process group -- through that file (id_file_rendezvous; removed by rank 0 once every rank has joined).
+    dce_comm_init is collective; without a process group it runs under a deadline (DCE_COMM_TIMEOUT, default 180 s), so that
+    a peer that never arrives ends in an error, not in a hang."""
     import os
-    import time
+    import threading
     global _bootstraps
     _bootstraps += 1                       # every rank calls in the same order: the n-th communicator of a process has its own key / file
     key = f"{key}_{_bootstraps}"
     path = os.environ.get("DCE_COMM_ID_FILE")
     if path:
         path = f"{path}.{_bootstraps}"
+    timeout = float(os.environ.get("DCE_COMM_TIMEOUT", "180"))
     store = None
     try:
         import torch.distributed as dist
@@ -126,23 +166,35 @@ def comm_bootstrap(model, rank: int, world: int, key: str = "dce_comm_id"):
         if rank == 0:
             store.set(key, type(model).comm_unique_id())
         uid = bytes(store.get(key))
-    elif path:
+        model.comm_init(rank, world, uid)
+        return model
+    if path:
+        uid = id_file_rendezvous(path, rank, type(model).comm_unique_id, timeout=min(timeout, 120.0))
+        done, err = threading.Event(), []
+
+        def init():
+            try:
+                model.comm_init(rank, world, uid)
+            except Exception as e:                                # noqa: BLE001
+                err.append(e)
+            done.set()
+
+        th = threading.Thread(target=init, daemon=True, name="dce-comm-init")
+        th.start()
+        if not done.wait(timeout):
+            raise RuntimeError(f"dce_comm_init did not return within {timeout:.0f} s: {world - 1} peer(s) expected through {path}")
+        if err:
+            raise err[0]
         if rank == 0:
-            with open(path + ".tmp", "wb") as f:
-                f.write(type(model).comm_unique_id())
-            os.replace(path + ".tmp", path)
-        t0 = time.time()
-        while not os.path.exists(path):
-            if time.time() - t0 > 120:
-                raise RuntimeError(f"no ncclUniqueId appeared at {path}")
-            time.sleep(0.01)
-        uid = open(path, "rb").read()
-    elif world == 1:
-        uid = type(model).comm_unique_id()
-    else:
-        raise RuntimeError("comm_bootstrap needs an initialised torch.distributed group or DCE_COMM_ID_FILE")
-    model.comm_init(rank, world, uid)
-    return model
+            try:
+                os.unlink(path)            # every rank has joined: nobody reads it any more, the next job starts clean
+            except FileNotFoundError:
+                pass
+        return model
+    if world == 1:
+        model.comm_init(rank, world, type(model).comm_unique_id())
+        return model
+    raise RuntimeError("comm_bootstrap needs an initialised torch.distributed group or DCE_COMM_ID_FILE")
 
 
 def comm_bootstrap_checked(model, rank: int, world: int, device, key: str = "dce_comm_id", timeout: float | None = None):

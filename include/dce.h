@@ -67,6 +67,13 @@ typedef enum dce_precision {
                                   accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; the conv stack from 128
                                   windows per call, fc.0 from 2817; below that the DCE_FP32 kernels.  Opt-in (csrc/conv_x3.hip, csrc/fc_gemm_x3.hip) */
 } dce_precision;
+/* Batch-size regimes.  DCE_FP32 gives a window the same bits whatever the size of the call it arrives in (one fixed summation tree in
+ * every kernel family).  The two other precisions pick kernels by the number of windows in a launch (a call of more than max_batch
+ * windows is several launches: the last one may fall into another regime): below 128 windows the DCE_FP32 kernels, from 128 the
+ * three-term conv stack, DCE_FP32_SPLIT from 2817 the split fc.0 -- so the same window may differ in its last bits between a small and
+ * a large call (fp32_split: both within the fp32 tolerance of the reference, <= 2e-5 of the largest logit apart; bf16_fc: a feature
+ * within fp32 noise of a bf16 rounding boundary may round the other way, <= 2e-2 of the largest logit).  Tested:
+ * tests/test_round4_gpu.py::test_batch_size_regimes_stay_within_the_mode_tolerance.  A caller that needs call-size invariance uses DCE_FP32. */
 
 typedef struct dce_ctx dce_ctx;   /* opaque; owns device weights, scratch and (by default) a stream */
 
@@ -119,6 +126,8 @@ int  dce_infer_sequence(dce_ctx* ctx, const float* seq, int64_t T, int window, i
  * bijection on 0..15) -- written in that form by the last kernel of the path.  This is the row format of the
  * multi-GPU gather below: what a rank computes is what travels, no repacking pass. */
 #define DCE_PACKED_ROW  68
+/* A DEVICE `packed` pointer must be 4-byte aligned (the kernels write and read the rows as 32-bit words; rows are 68 bytes, so
+ * an aligned buffer keeps every row aligned): DCE_ERR_ARG otherwise.  Host pointers need no alignment. */
 int  dce_forward_windows_packed(dce_ctx* ctx, const float* windows, int64_t n, int on_device, uint8_t* packed);
 int  dce_infer_sequence_packed(dce_ctx* ctx, const float* seq, int64_t T, int window, int on_device, uint8_t* packed);
 /* (n,68) packed rows -> logits (n,16) f32, pred (n) i32, contacts (n,4) u8 (any may be NULL); device pointers run
@@ -150,7 +159,7 @@ int  dce_forward_taps(dce_ctx* ctx, const float* windows, int64_t n, int on_devi
  * workgroup with four row tiles per wave (DCE_CONV4=1, an A/B variant of 0), 7 the three-term bf16 conv stack of the
  * DCE_FP32_SPLIT precision (conv_x3.hip; contexts finalised with that precision only).  The segment kernels (2, 3) never
  * compute conv4's t = 74 (MaxPool drops it): that column reads NaN.
- * The tapped kernels are the product kernels instantiated with the extra stores; not in the DCE_BF16_FC precision. */
+ * The tapped kernels are the product kernels instantiated with the extra stores; a DCE_BF16_FC context is refused (DCE_ERR_STATE). */
 int  dce_conv_layer_taps(dce_ctx* ctx, const float* windows, int64_t n, int kernel,
                          float* conv1, float* conv2, float* pool1, float* conv3, float* conv4, float* feat);
 

@@ -39,3 +39,66 @@ def test_c_client_runs(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi_client: OK" in r.stdout
     print(r.stdout.strip())
+
+
+def _build_ranks(out):
+    if not os.path.exists(os.path.join(PKG, "libdce.so")):
+        from deep_contact_estimator_amd import build
+        build.build()
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_ranks.c"), "-L" + PKG, "-ldce", "-L" + ROCM_LIB, "-lamdhip64", "-lm",
+           "-Wl,-rpath," + PKG, "-Wl,-rpath," + ROCM_LIB, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+def test_n_rank_client_rendezvous_without_a_gpu(tmp_path):
+    """SURVEY.md 8(e)'s torch-free bootstrap in its N-rank form (tests/c/abi_ranks.c + tools/launch_ranks.sh): three processes
+    meet through the id file although a stale file of another job sits at the same path; a rank with another job's nonce is
+    NOT fooled by the file and gives up with an error instead of taking a wrong id (--dry-run: no GPU, no RCCL)."""
+    exe = _build_ranks(str(tmp_path / "abi_ranks"))
+    idf = tmp_path / "id"
+    idf.write_bytes(b"s" * 144)                                  # left behind by an earlier job
+    env = dict(os.environ, DCE_COMM_ID_FILE=str(idf), DCE_COMM_TIMEOUT="20")
+    r = subprocess.run([os.path.join(ROOT, "tools", "launch_ranks.sh"), "3", exe, "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("OK (dry run") == 3 and "all 3 ranks OK" in r.stdout
+    env = dict(os.environ, DCE_COMM_TIMEOUT="1")
+    r = subprocess.run([exe, "--rank", "1", "--world", "2", "--id-file", str(idf), "--nonce", "another-job", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no id with this job's nonce" in r.stderr
+
+
+def test_python_id_file_rendezvous_rejects_a_stale_id(tmp_path, monkeypatch):
+    """distributed.id_file_rendezvous (DCE_COMM_ID_FILE without a torch.distributed group): same file format, same rules."""
+    import threading
+    import time
+    from deep_contact_estimator_amd import distributed as d
+    p = str(tmp_path / "id")
+    open(p, "wb").write(b"x" * 144)
+    monkeypatch.setenv("DCE_COMM_NONCE", "job-a")
+    got = {}
+    ts = [threading.Thread(target=lambda r=r: got.__setitem__(r, d.id_file_rendezvous(p, r, None, timeout=20))) for r in (1, 2)]
+    [t.start() for t in ts]
+    time.sleep(0.2)
+    got[0] = d.id_file_rendezvous(p, 0, lambda: bytes(range(128)))
+    [t.join() for t in ts]
+    assert got[0] == got[1] == got[2] == bytes(range(128))
+    monkeypatch.setenv("DCE_COMM_NONCE", "job-b")
+    with pytest.raises(RuntimeError, match="DCE_COMM_NONCE"):
+        d.id_file_rendezvous(p, 1, None, timeout=0.3)
+
+
+@pytest.mark.gpu
+def test_n_rank_client_runs_in_a_world_of_one(tmp_path):
+    """The whole torch-free flow on the one GPU of this box: launcher -> id file -> dce_comm_init -> shard ->
+    dce_gather_results -> byte comparison on the root -> dce_allreduce_counts."""
+    exe = _build_ranks(str(tmp_path / "abi_ranks"))
+    env = dict(os.environ, DCE_COMM_ID_FILE=str(tmp_path / "id"))
+    r = subprocess.run([os.path.join(ROOT, "tools", "launch_ranks.sh"), "1", exe, "--windows", "700"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_ranks[0]: OK" in r.stdout and "every gathered row equals the root's own" in r.stdout
+    assert not os.path.exists(str(tmp_path / "id"))              # rank 0 removed the id file once everybody had joined
+    print(r.stdout.strip())

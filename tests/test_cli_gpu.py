@@ -239,6 +239,22 @@ def test_bench_multi_gpu_flow_on_rccl_single_rank():
     assert sh["windows_per_s_incl_gather"] > 1e6 and abs(sh["gathered_MB"] - 68.0) < 1e-9 and "dce_gather_results" in sh["transport"]
 
 
+def test_bench_device_map_and_per_rank_record():
+    """A launcher whose LOCAL_RANK is not a device index (DCE_DEVICE_MAP) and a permuted HIP_VISIBLE_DEVICES: the rank lands on
+    the mapped visible device, and the N>1 line carries every rank's own ms_per_step, the slow rank and the exchange's own time."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, DCE_FORCE_DIST="1", MASTER_PORT="29587", LOCAL_RANK="2", DCE_DEVICE_MAP="7,7,0",
+               HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0").split(",")[-1])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--settle-s", "0.2",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    pr = j["per_rank"]
+    assert len(pr["ms_per_step"]) == 1 and pr["rank_of_max"] == 0 and pr["ms_per_step_min"] == pr["ms_per_step_max"] > 0
+    assert abs(j["ms_per_step"] - pr["ms_per_step_max"]) < 1e-6 * j["ms_per_step"] + 1e-9
+    assert 0 < j["rccl"]["gather_alone_us"] < 5000
+
+
 def test_bench_reports_a_fallback_when_rccl_cannot_be_bound():
     """If libdce.so cannot bind RCCL (DCE_RCCL_LIB=none stands in for a box without a usable librccl) the ranks agree on
     it before any collective of the data path and the per-step gather runs over torch.distributed -- and the line SAYS so

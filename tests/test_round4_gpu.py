@@ -122,3 +122,31 @@ def test_batch_size_regimes_stay_within_the_mode_tolerance(precision, orc):
         else:
             assert d < 2e-2 * scale
     m.close()
+
+
+def test_packed_rows_must_be_word_aligned():
+    """The kernels write and read packed rows as 32-bit words: a device buffer at an odd byte offset is refused with DCE_ERR_ARG by
+    every entry point that takes one (include/dce.h), not handed to a kernel."""
+    import torch
+    from deep_contact_estimator_amd import contact_cnn, synth
+    m = contact_cnn(device=0, max_batch=64); m.load_state_dict(synth.make_state_dict(1)).eval()
+    x = torch.randn((8, 150, 54), device="cuda")
+    buf = torch.empty(8 * 68 + 8, dtype=torch.uint8, device="cuda")
+    odd = buf[1:1 + 8 * 68].view(8, 68)
+    assert odd.data_ptr() % 4 == 1 and odd.is_contiguous()
+    with pytest.raises(RuntimeError, match="4-byte aligned"):
+        m.predict_packed(x, out=odd)
+    good = m.predict_packed(x)
+    odd.copy_(good)
+    with pytest.raises(RuntimeError, match="4-byte aligned"):
+        m.unpack_results(odd)
+    m.close()
+
+
+def test_layer_taps_refuse_a_bf16_fc_context():
+    from deep_contact_estimator_amd import contact_cnn, synth
+    m = contact_cnn(device=0, max_batch=64, precision="bf16_fc"); m.load_state_dict(synth.make_state_dict(1)).eval()
+    x = np.random.default_rng(0).standard_normal((2, 150, 54), dtype=np.float32)
+    with pytest.raises(RuntimeError, match="DCE_BF16_FC"):
+        m.conv_layer_taps(x)
+    m.close()
