@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("DCE_LIB") or os.path.join(_HERE, "libdce.so")   # DCE
 _i64p = C.POINTER(C.c_int64)
 SYMBOLS = {
     "dce_abi_version": (C.c_int, []),
+    "dce_build_flags": (C.c_int, []),
     "dce_device_count": (C.c_int, []),
     "dce_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64]),
     "dce_destroy": (None, [C.c_void_p]),
@@ -44,7 +45,15 @@ SYMBOLS = {
     "dce_last_plan": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "dce_sync": (C.c_int, [C.c_void_p]),
     "dce_last_error": (C.c_char_p, [C.c_void_p]),
+    "dce_debug_split3": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
 }
+
+BUILD_EXPERIMENTS, BUILD_TRACE, BUILD_ASAN = 1, 2, 4
+
+
+def has_experiments() -> bool:
+    """Is the loaded library the experiments build (the A/B kernel variants exist and their switches work)?"""
+    return bool(load().dce_build_flags() & BUILD_EXPERIMENTS)
 
 _lib = None
 

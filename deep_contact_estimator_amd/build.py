@@ -104,5 +104,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_experiments() -> str:
+    """libdce_experiments.so: the product kernels PLUS the variants that were measured slower and kept for the A/B (the
+    four-row-tile Winograd workgroup, the lockstep GEMM schedule, the paired three-term conv stack) and the probe macros.
+    Select with DCE_LIB=<path>; dce_build_flags() & DCE_BUILD_EXPERIMENTS tells which one is loaded."""
+    return build_variant("experiments", ["-DDCE_EXPERIMENTS=1"])
+
+
+def build_asan() -> str:
+    """libdce_asan.so: the HOST side of every translation unit (the C ABI shim: staging ring, per-thread tuning scope, the
+    RCCL dlopen path) instrumented with AddressSanitizer + UndefinedBehaviorSanitizer; device code unchanged.  Run with
+    LD_PRELOAD=$(asan_runtime()) ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 DCE_LIB=<path> (tools/run_asan.sh)."""
+    return build_variant("asan", ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g1", "-O1"])
+
+
+def asan_runtime() -> str:
+    out = subprocess.run([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--experiments" in sys.argv:
+        print(build_experiments())
+    elif "--asan" in sys.argv:
+        print(build_asan())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -47,6 +47,9 @@ static_assert(NW == 2, "per-window NaN flags are written for two windows");
 static_assert(NW * 4 * 216 <= 8 * RS1 && (WRED_ROW * RS1) % 2 == 0, "z-score scratch fits, 8-B aligned");
 constexpr int MT = 2, NTW = 5;                               // row / column tiles per wave
 constexpr int WINO1_MAX_N = 256;                             // <= this many windows: conv_wino1_kernel (one window per workgroup)
+#if !DCE_EXPERIMENTS && (defined(WINO_EXP) || defined(WINO_PEEL) || defined(WINO_PKINIT) || defined(WINO_RELU_ASM) || defined(WINO1_PF) || defined(WINO_INTERLEAVE) || defined(WINO_PK))
+#error "the WINO_* probe / ablation macros are experiment switches: build with -DDCE_EXPERIMENTS=1"
+#endif
 #ifndef WINO_EXP
 #define WINO_EXP 0           // bit flags for ablations / timing probes (tools/micro/wino_loop.hip); 0 in the product:
                              //   2 no LDS reads, 4 one weight line, 8 no input-transform VALU, 16 no output-transform VALU,
@@ -697,6 +700,7 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
     }
 }
 
+#if DCE_EXPERIMENTS
 // ------------------------------------------------------------------------------------------
 // The same two-window workgroup with FOUR row tiles per wave (round 3; conv_wino_rt4_kernel).
 //
@@ -720,6 +724,8 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
 // MFMAs plus ~4 cycles for each of the ~9,400 other instructions its two waves per SIMD issue.
 // Register order of a wave's four row tiles: r[0], r[1] = the row pair that also serves the half tile, r[2], r[3] = the
 // other pair of the wave's 64 channels (so the half tile needs no runtime register choice).
+#endif  // DCE_EXPERIMENTS
+
 // ------------------------------------------------------------------------------------------
 #ifndef WINO4_SPLIT
 #define WINO4_SPLIT 0
@@ -1476,10 +1482,12 @@ hipError_t init_conv_wino()
                           reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 2, 3, 2, true>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 4, 2, 1, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     // the TAPS instantiations (dce_conv_layer_taps: parity tests of the layers inside the fused stack)
+#if DCE_EXPERIMENTS
     for (const void* k : {reinterpret_cast<const void*>(&conv_wino_rt4_kernel<true, float>), reinterpret_cast<const void*>(&conv_wino_rt4_kernel<false, float>),
                           reinterpret_cast<const void*>(&conv_wino_rt4_kernel<true, unsigned short>), reinterpret_cast<const void*>(&conv_wino_rt4_kernel<false, unsigned short>),
                           reinterpret_cast<const void*>(&conv_wino_rt4_kernel<false, float, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, DCE_TRACE ? 100 * 1024 : WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
+#endif
     for (const void* k : {reinterpret_cast<const void*>(&conv_wino_kernel<false, float, true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false, true>),
                           reinterpret_cast<const void*>(&conv_wino1x8_kernel<false, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
@@ -1500,7 +1508,9 @@ hipError_t launch_conv_wino_taps(int kernel, const float* src, int64_t n, const 
     case 1: hipLaunchKernelGGL((conv_wino1x8_kernel<false, true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, none, taps); break;
     case 2: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2, true>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, none, taps); break;
     case 3: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1, true>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, none, taps); break;
+#if DCE_EXPERIMENTS
     case 6: hipLaunchKernelGGL((conv_wino_rt4_kernel<false, float, true>), dim3((unsigned)((n + NW - 1) / NW)), dim3(256), lds, st, src, n, pk, f, none, taps); break;
+#endif
     case 5: hipLaunchKernelGGL((conv_wino1_kernel<false, true>), dim3((unsigned)n), dim3(256), lds, st, src, n, pk, f, none, taps); break;
     default: return hipErrorInvalidValue;
     }
@@ -1560,6 +1570,7 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
         else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
         return hipGetLastError();
     }
+#if DCE_EXPERIMENTS
     if (tu.conv4 > 0 && feat_bf16 != 2) {           // DCE_CONV4=1: four row tiles per wave (A/B; measured 3.8 % SLOWER end to end, see the kernel's header)
         plan_note("conv_wino2_rt4");
         if (feat_bf16) {
@@ -1573,6 +1584,7 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
         }
         return hipGetLastError();
     }
+#endif
     if (feat_bf16 == 2) {                                // DCE_FP32_SPLIT: the features leave as three bf16 planes (conv_common.h put_feat3)
         plan_note("conv_wino2_feat3");
         Feat3* f = static_cast<Feat3*>(feat);

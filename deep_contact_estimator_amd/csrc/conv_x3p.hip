@@ -33,6 +33,8 @@
 #include "conv_x3_common.h"
 #include <cfloat>
 
+#if DCE_EXPERIMENTS
+
 namespace dce {
 
 #if DCE_TRACE
@@ -655,3 +657,19 @@ extern "C" int dce_debug_trace_read_x3p(unsigned long long* out, int nblocks)
 }
 
 #endif
+
+#else   // !DCE_EXPERIMENTS: the default library carries neither the kernel nor its dispatch (dce_api.hip never selects it)
+
+namespace dce {
+void fc_perm_k_host(const float* w, size_t rows, float* out)
+{
+    for (size_t o = 0; o < rows; ++o)
+        for (int c = 0; c < 128; ++c)
+            for (int t = 0; t < 37; ++t) out[o * FEAT + t * 128 + c] = w[o * FEAT + c * 37 + t];
+}
+hipError_t init_conv_x3p() { return hipSuccess; }
+hipError_t launch_conv_x3p(const float*, int, int64_t, const ConvPackX3&, unsigned short*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_conv_x3p_bf16(const float*, int, int64_t, const ConvPackX3&, unsigned short*, hipStream_t) { return hipErrorNotSupported; }
+}  // namespace dce
+
+#endif  // DCE_EXPERIMENTS

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <dlfcn.h>
 
 using namespace dce;
 
@@ -63,12 +64,12 @@ Tuning tuning_from_env()
     t.wino1_w8 = num("DCE_WINO1_WAVES", 8) != 4;
     t.one_per_cu = getenv("DCE_ONE_PER_CU") != nullptr;
     t.trace_wino1 = getenv("DCE_TRACE_WINO1") != nullptr;
-    t.conv4 = (int)num("DCE_CONV4", 0);
+    t.conv4 = DCE_EXPERIMENTS ? (int)num("DCE_CONV4", 0) : 0;
     t.x3_min_tiles = (int)num("DCE_X3_MIN_TILES", t.x3_min_tiles);
     t.x3_unfused = getenv("DCE_X3_UNFUSED") != nullptr;
     t.x3_conv = num("DCE_X3_CONV", t.x3_conv ? 1 : 0) != 0;
     t.x3_conv_min = num("DCE_X3_CONV_MIN", t.x3_conv_min);
-    t.x3_pair = num("DCE_X3_PAIR", t.x3_pair ? 1 : 0) != 0;
+    t.x3_pair = DCE_EXPERIMENTS && num("DCE_X3_PAIR", t.x3_pair ? 1 : 0) != 0;      // (conv_x3p.hip exists in the experiments build only)
     t.x3_pair_min = num("DCE_X3_PAIR_MIN", t.x3_pair_min);
     return t;
 }
@@ -84,6 +85,35 @@ const Tuning& tune()
 
 namespace {
 
+// roctx ranges around the entry points of the path, so that a profile of a host program (rocprofv3 --marker-trace, or any tool that
+// listens to roctx) shows one named range per call next to the kernels it launched.  The marker library is bound at run time --
+// librocprofiler-sdk-roctx first (what rocprofv3 listens to), the older libroctx64 otherwise -- and only if it can be: libdce.so has
+// no link-time dependency on it.  DCE_ROCTX=0 switches the ranges off; without a tool attached a push/pop pair costs ~20 ns.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("DCE_ROCTX");
+        if (e && atoi(e) == 0) return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~RoctxRange() { if (on) roctx().pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
 
 struct Timer {   // records a [begin,end] event pair around one launch when profiling is on
     dce_ctx* c; int slot; hipEvent_t a = nullptr, b = nullptr;
@@ -329,6 +359,25 @@ extern "C" {
 
 int dce_abi_version(void) { return 2; }
 
+int dce_build_flags(void)
+{
+    int f = 0;
+#if DCE_EXPERIMENTS
+    f |= DCE_BUILD_EXPERIMENTS;
+#endif
+#if defined(DCE_TRACE) && DCE_TRACE
+    f |= DCE_BUILD_TRACE;
+#endif
+#if defined(__SANITIZE_ADDRESS__)
+    f |= DCE_BUILD_ASAN;
+#elif defined(__has_feature)
+#if __has_feature(address_sanitizer)
+    f |= DCE_BUILD_ASAN;
+#endif
+#endif
+    return f;
+}
+
 int dce_device_count(void)
 {
     int n = 0;
@@ -537,6 +586,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
 int dce_forward_windows(dce_ctx* c, const float* windows, int64_t n, int on_device,
                         float* logits, int32_t* pred, uint8_t* contacts)
 {
+    RoctxRange range_("dce_forward_windows");
     int rc = check_ready(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
@@ -548,6 +598,7 @@ int dce_forward_windows(dce_ctx* c, const float* windows, int64_t n, int on_devi
 int dce_infer_sequence(dce_ctx* c, const float* seq, int64_t T, int window, int on_device,
                        float* logits, int32_t* pred, uint8_t* contacts)
 {
+    RoctxRange range_("dce_infer_sequence");
     int rc = check_ready(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
@@ -560,6 +611,7 @@ int dce_infer_sequence(dce_ctx* c, const float* seq, int64_t T, int window, int 
 
 int dce_forward_windows_packed(dce_ctx* c, const float* windows, int64_t n, int on_device, uint8_t* packed)
 {
+    RoctxRange range_("dce_forward_windows_packed");
     int rc = check_ready(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
@@ -571,6 +623,7 @@ int dce_forward_windows_packed(dce_ctx* c, const float* windows, int64_t n, int 
 
 int dce_infer_sequence_packed(dce_ctx* c, const float* seq, int64_t T, int window, int on_device, uint8_t* packed)
 {
+    RoctxRange range_("dce_infer_sequence_packed");
     int rc = check_ready(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
@@ -807,6 +860,7 @@ void online_build_graph(dce_ctx* c)
 
 int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pred, uint8_t* contacts)
 {
+    RoctxRange range_("dce_online_push");
     int rc = check_ready(c);
     if (rc) return rc;
     DEVICE_GUARD(c);

@@ -5,6 +5,14 @@
 #include <stdint.h>
 #include <vector>
 
+// -DDCE_EXPERIMENTS=1 (python -m deep_contact_estimator_amd.build --experiments -> libdce_experiments.so, select with DCE_LIB): the
+// kernel variants that were built, measured slower than what ships and kept for the record and the A/B -- the four-row-tile
+// Winograd workgroup (DCE_CONV4=1), the lockstep schedule of the phased GEMM (DCE_GEMM=lockstep), the paired three-term conv stack
+// (DCE_X3_PAIR=1) -- and the timing-probe macros.  The default libdce.so contains none of them: their switches are ignored there.
+#ifndef DCE_EXPERIMENTS
+#define DCE_EXPERIMENTS 0
+#endif
+
 namespace dce {
 
 // ---- geometry of contact_cnn (reference src/contact_cnn.py:8-58) ------------------------

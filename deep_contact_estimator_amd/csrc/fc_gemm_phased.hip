@@ -448,15 +448,17 @@ template <> struct PhTile<1> { static constexpr int TM = 1, TN = 1, ROWB = 256; 
 //         result is the stable one; it decides.
 static bool use_lockstep(bool /*bf16*/)
 {
-    return tune().gemm_lockstep;
+    return DCE_EXPERIMENTS && tune().gemm_lockstep;       // (the lockstep schedule -- the one with register spills -- is instantiated in the experiments build only)
 }
 
 template <bool BF16, bool OUT_BF16, int T> static hipError_t grant_phased()
 {
     using P = PhTile<T>;
+#if DCE_EXPERIMENTS
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<P::TM, P::TN, P::ROWB>::LDS);
     if (e != hipSuccess) return e;
+#endif
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<P::TM, P::TN, P::ROWB>::LDS);
 }
@@ -464,9 +466,12 @@ template <bool BF16, bool OUT_BF16, int T> static hipError_t grant_phased()
 hipError_t init_fc_gemm_phased()
 {
     hipError_t e;
-    for (const void* k : {reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true, true>),
-                          reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true, false>),
+    for (const void* k : {
+#if DCE_EXPERIMENTS
+                          reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true, true>),
                           reinterpret_cast<const void*>(&fc_gemm_phased_kernel<true, false, 1, 1, 256, true, true>),
+#endif
+                          reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true, false>),
                           reinterpret_cast<const void*>(&fc_gemm_phased_kernel<true, false, 1, 1, 256, true, false>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<1, 1, 256>::LDS)) != hipSuccess) return e;
     if ((e = grant_phased<false, false, 2>()) != hipSuccess) return e;
@@ -527,10 +532,12 @@ static hipError_t launch_phased_cfg(const void* A, const void* W, const float* b
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
     plan_note(use_lockstep(BF16) ? (T == 2 ? "fc_lockstep256x128" : "fc_lockstep128x64") : (T == 2 ? "fc_phased256x128" : "fc_phased128x64"));
+#if DCE_EXPERIMENTS
     if (use_lockstep(BF16))
         hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, true>), dim3(grid), dim3(512), Cfg::LDS, st,
                            A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, nullptr, nullptr, 0ll);
     else
+#endif
         hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, false>), dim3(grid), dim3(512), Cfg::LDS, st,
                            A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, nullptr, nullptr, 0ll);
     return hipGetLastError();
@@ -577,8 +584,11 @@ hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, co
 #define FC23_LAUNCH(BF, LS) hipLaunchKernelGGL((fc_gemm_phased_kernel<BF, false, 1, 1, 256, true, LS>), dim3(grid), dim3(512), Cfg::LDS, st, \
                                                h1, W2, b2, h2v, (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, pr)
     plan_note(use_lockstep(false) ? "fc23_fused_lockstep128x64" : "fc23_fused_phased128x64");
-    if (bf16) { if (use_lockstep(true)) FC23_LAUNCH(true, true); else FC23_LAUNCH(true, false); }
-    else      { if (use_lockstep(false)) FC23_LAUNCH(false, true); else FC23_LAUNCH(false, false); }
+#if DCE_EXPERIMENTS
+    if (use_lockstep(bf16)) { if (bf16) FC23_LAUNCH(true, true); else FC23_LAUNCH(false, true); }
+    else
+#endif
+    { if (bf16) FC23_LAUNCH(true, false); else FC23_LAUNCH(false, false); }
 #undef FC23_LAUNCH
     return hipGetLastError();
 }

@@ -34,6 +34,7 @@
 #ifndef DCE_H
 #define DCE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -79,6 +80,15 @@ typedef struct dce_ctx dce_ctx;   /* opaque; owns device weights, scratch and (b
 
 /* Library/ABI version, for binding sanity checks. */
 int  dce_abi_version(void);
+
+/* How this libdce.so was built: bit set of DCE_BUILD_*.  The default library is 0: product kernels only.  EXPERIMENTS: it also
+ * carries the variants that were measured slower and kept for A/B (csrc/dce_kernels.h; python -m deep_contact_estimator_amd.build
+ * --experiments), whose switches (DCE_CONV4, DCE_GEMM=lockstep, DCE_X3_PAIR) the default library ignores.  TRACE: phase time
+ * stamps inside the kernels.  ASAN: the host side is instrumented with AddressSanitizer + UBSan (build --asan). */
+#define DCE_BUILD_EXPERIMENTS 1
+#define DCE_BUILD_TRACE       2
+#define DCE_BUILD_ASAN        4
+int  dce_build_flags(void);
 
 /* Number of visible HIP devices, or a negative dce_status. */
 int  dce_device_count(void);
@@ -240,6 +250,11 @@ int  dce_sync(dce_ctx* ctx);
 
 /* Message for the last failing call on this ctx (or on creation when ctx == NULL). */
 const char* dce_last_error(dce_ctx* ctx);
+
+/* Test hook: the three bf16 terms (a = t1 + t2 + t3 exactly for every normal fp32 a, round-to-nearest-even each) the
+ * DCE_FP32_SPLIT kernels split their operands into -- the host routine that prepares fc.0's weights; planes = [3][n] uint16
+ * (tests/test_x3_gpu.py::test_split_terms_are_exact).  No device involved. */
+void dce_debug_split3(const float* x, size_t n, unsigned short* planes);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,23 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Tests marked `experiments` need the A/B variants: skipped unless the experiments library is the one loaded."""
+    marked = [it for it in items if it.get_closest_marker("experiments")]
+    if not marked:
+        return
+    try:
+        ok = has_experiments()
+    except Exception:                                      # no library built yet (CPU collection without a build)
+        ok = False
+    if not ok:
+        skip = pytest.mark.skip(reason="needs libdce_experiments.so (tests/test_experiments_gpu.py runs these with DCE_LIB set)")
+        for it in marked:
+            it.add_marker(skip)
+
+
 def pytest_configure(config):
+    config.addinivalue_line("markers", "experiments: needs libdce_experiments.so (skipped with the product library)")
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
@@ -55,3 +71,14 @@ def case_inputs():
             cache[key] = (sd, seq)
         return cache[key]
     return get
+
+
+def has_experiments() -> bool:
+    """True when the loaded libdce is the experiments build (DCE_LIB=.../libdce_experiments.so): only there do the A/B variants
+    exist (DCE_CONV4=1, DCE_GEMM=lockstep, DCE_X3_PAIR=1).  tests/test_experiments_gpu.py re-runs the tests that need it in a
+    subprocess with that library; in the default run they skip."""
+    from deep_contact_estimator_amd import _lib
+    return _lib.has_experiments()
+
+
+needs_experiments = pytest.mark.experiments

@@ -1,0 +1,38 @@
+"""GPU (-m gpu): the A/B kernel variants live in a library of their own (libdce_experiments.so, -DDCE_EXPERIMENTS=1: the four-row-tile
+Winograd workgroup, the lockstep GEMM schedule, the paired three-term conv stack).  The product library carries none of them; the
+tests that exercise them (marked `experiments`, skipped in the default run) plus the tests that loop over kernel families /
+schedules are re-run here in a subprocess with DCE_LIB pointing at that library."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_product_library_has_no_experiment_kernels():
+    """(CPU) dce_build_flags() == 0 for libdce.so, and its switches for the variants are inert by construction."""
+    from deep_contact_estimator_amd import _lib
+    if os.environ.get("DCE_LIB"):
+        pytest.skip("DCE_LIB names another build")
+    assert _lib.load().dce_build_flags() == 0
+
+
+@pytest.mark.gpu
+def test_experiment_variants_in_their_own_build():
+    if os.environ.get("DCE_LIB"):
+        pytest.skip("already running under a DCE_LIB build")
+    from deep_contact_estimator_amd import build
+    lib = os.path.join(build.HERE, "libdce_experiments.so")
+    if not os.path.exists(lib):
+        build.build_experiments()
+    env = dict(os.environ, DCE_LIB=lib, PYTHONPATH=ROOT)
+    sel = "rt4 or paired or ab_switches or layer_taps_bit_identical or tapped_kernels or phased_gemm_equals_tile"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_round3_gpu.py"), os.path.join(ROOT, "tests", "test_round4_gpu.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py")], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+    print(r.stdout.strip().splitlines()[-1])

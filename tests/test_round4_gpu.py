@@ -61,6 +61,7 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs):
     m.close()
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
 def test_paired_conv_stack_vs_one_window_kernel_and_oracle(precision, orc):
     """conv_x3p.hip (DCE_X3_PAIR=1: one 8-wave workgroup per CU, two windows per wave, write-backs inside the other window's K
