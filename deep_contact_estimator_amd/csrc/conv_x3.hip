@@ -60,7 +60,7 @@ void conv_x3_pack_host(int l, const float* w, unsigned short* out)
                         }
 }
 
-template <bool ZS, bool TAPS = false, int OUT = 0>
+template <bool ZS, bool TAPS = false, int OUT = 0, bool PERMK = false>
 __global__ __launch_bounds__(256, 2)
 void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems,
                     LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr)
@@ -189,6 +189,43 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         bias_acc(pk.b[3], 32 * wv);
         cx_layer<256, 4, false, CX_ILV != 0>(cx_lds + j * 256, sw4, g, w3 + (size_t)wv * (12 * 2 * 3 * 64), acc);
         TRACE_MARK(8);
+        if constexpr (PERMK) {
+            // ---- conv4 + ReLU + MaxPool (t = 74 dropped) straight from the accumulators to HBM in the K order k' = t' * 128 + c: a lane
+            //      holds four consecutive channels of one pooled position = 8 bytes per plane, so the features need neither the trip
+            //      through LDS nor its two barriers (the reference's flatten order c * 37 + t' would be 2-byte stores: 9.6k cycles per
+            //      workgroup).  fc.0's weights for this path have their K axis permuted the same way (dce_finalize_weights,
+            //      fc_perm_k_host): no product changes, only the order of a summation that claims no bit pattern.
+            static_assert(OUT != 1 && !TAPS, "the fp32 features of the mid-size batches and the taps keep the reference's order");
+            unsigned short* const out = OUT == 2 ? feat3 + (size_t)win * FEAT : feat3 + (size_t)(win >> 1) * (2 * FEAT) + (int)(win & 1) * 32;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int co = 32 * wv + 16 * rt + 4 * g;
+#pragma unroll
+                for (int ct = 0; ct < CX_NT; ++ct) {
+                    const int t = 16 * ct + j;
+                    float v[4] = {acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(v[r], cx_neighbour(v[r])), 0.f);
+                    unsigned lo[3], hi[3];
+                    cx_split2(v[0], v[1], lo);
+                    cx_split2(v[2], v[3], hi);
+                    if (window_bad) {                                  // a non-finite sample: NaN in every term of the window's features
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) lo[p] = hi[p] = 0x7fc07fc0u;
+                    }
+                    if ((j & 1) == 0 && (t >> 1) < 37) {
+                        const int k = (t >> 1) * 128 + co;
+                        if constexpr (OUT == 2) *reinterpret_cast<uint2*>(out + k) = make_uint2(lo[0], hi[0]);
+                        else {
+#pragma unroll
+                            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(out + p * plane_elems + (k >> 5) * 64 + (k & 31)) = make_uint2(lo[p], hi[p]);
+                        }
+                    }
+                }
+            }
+            TRACE_MARK(9);
+            return;
+        }
         // ---- conv4 + bias + ReLU + MaxPool (t = 74 dropped) + flatten k = c * 37 + t' -> three planes [k] in LDS (the layer's
         //      input is dead once every wave is through its MFMAs), then 16-byte stores into fc_gemm_x3.hip's layout: 7 per
         //      thread, where storing from the accumulators' layout took 120 two-byte stores per lane (9.6k cycles per workgroup)
@@ -288,6 +325,9 @@ hipError_t init_conv_x3()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
     if (e != hipSuccess) return e;
+    for (const void* k : {reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 0, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 0, true>),
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS)) != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
 }
 
@@ -313,19 +353,31 @@ hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const Con
 }
 
 // ... with (n, 4736) bf16 features out: the DCE_BF16_FC precision
-hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st)
+hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk)
 {
     if (n <= 0) return hipSuccess;
+    if (permk) {                                       // features in the K order t' * 128 + c, straight from the accumulators
+        plan_note("conv_x3_bf16_permk");
+        if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+        return hipGetLastError();
+    }
     plan_note("conv_x3_bf16");
     if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
     else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
     return hipGetLastError();
 }
 
-hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st)
+hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st, int permk)
 {
     if (n <= 0) return hipSuccess;
     const size_t plane_elems = (size_t)((n + 1) & ~(int64_t)1) * FEAT;
+    if (permk) {
+        plan_note("conv_x3_permk");
+        if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 0, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
+        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 0, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
+        return hipGetLastError();
+    }
     plan_note("conv_x3");
     if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
     else        hipLaunchKernelGGL((conv_x3_kernel<false>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);

@@ -69,6 +69,7 @@ Tuning tuning_from_env()
     t.x3_unfused = getenv("DCE_X3_UNFUSED") != nullptr;
     t.x3_conv = num("DCE_X3_CONV", t.x3_conv ? 1 : 0) != 0;
     t.x3_conv_min = num("DCE_X3_CONV_MIN", t.x3_conv_min);
+    t.x3_permk = num("DCE_X3_PERMK", t.x3_permk ? 1 : 0) != 0;
     t.x3_pair = DCE_EXPERIMENTS && num("DCE_X3_PAIR", t.x3_pair ? 1 : 0) != 0;      // (conv_x3p.hip exists in the experiments build only)
     t.x3_pair_min = num("DCE_X3_PAIR_MIN", t.x3_pair_min);
     return t;
@@ -163,14 +164,15 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         // chip-filling batch: two windows per workgroup, a phase apart (conv_x3p.hip); its features -- and the fc.0 weights used
         // behind it -- are in the K order t' * 128 + c.  A tap of the features keeps the reference's flatten order (conv_x3.hip).
         const bool pair = c->tuning.x3_conv && c->tuning.x3_pair && c->winograd && !c->src_row_dev && !c->want_feat && n >= c->tuning.x3_pair_min;
+        const bool x3c = c->tuning.x3_conv && c->winograd && !c->src_row_dev && n >= c->tuning.x3_conv_min;      // conv_x3.hip
+        const bool permk = x3c && c->tuning.x3_permk && !c->want_feat && c->fc1w_bf16p != nullptr;                 // ... with its features in the K order t' * 128 + c
         { Timer t(c, 0);
           // from 128 windows the conv stack runs on three-term bf16 operands (conv_x3.hip: fp32-grade results at 1.27x the
           // fp32 Winograd kernel's rate), its features rounded to bf16 as the Winograd kernel's are; DCE_X3_CONV=0 switches back
           if (pair) HIP_TRY(c, launch_conv_x3p_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream));
-          else if (c->tuning.x3_conv && c->winograd && !c->src_row_dev && n >= c->tuning.x3_conv_min)
-              HIP_TRY(c, launch_conv_x3_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream));
+          else if (x3c) HIP_TRY(c, launch_conv_x3_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream, permk));
           else HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream, c->src_row_dev)); }
-        { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, pair ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
+        { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, (pair || permk) ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
         if (fc23_fused_ok(n, 1)) {
             { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch,
                                                           c->want_h2 ? c->h2 : nullptr, n, c->stream)); }
@@ -185,9 +187,10 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         const bool x3 = c->precision == DCE_FP32_SPLIT && fc_gemm_x3_ok(n, FC1, FEAT);
         const bool x3_fused = x3 && c->winograd && !c->want_feat && !c->tuning.x3_unfused;
         const bool pair = x3_fused && c->tuning.x3_conv && c->tuning.x3_pair && !c->src_row_dev && n >= c->tuning.x3_pair_min;     // conv_x3p.hip (K order t' * 128 + c)
+        const bool permk = x3_fused && c->tuning.x3_conv && !c->src_row_dev && c->tuning.x3_permk && c->fc1w_x3p != nullptr;        // conv_x3.hip, features straight out in that order
         { Timer t(c, 0);
           if (pair) HIP_TRY(c, launch_conv_x3p(src, zscore, n, c->pkx3, c->feat3, c->stream));
-          else if (x3_fused && c->tuning.x3_conv && !c->src_row_dev) HIP_TRY(c, launch_conv_x3(src, zscore, n, c->pkx3, c->feat3, c->stream));
+          else if (x3_fused && c->tuning.x3_conv && !c->src_row_dev) HIP_TRY(c, launch_conv_x3(src, zscore, n, c->pkx3, c->feat3, c->stream, permk));
           else if (x3_fused) HIP_TRY(c, launch_conv_wino(src, zscore, n, c->pk, c->feat3, 2, c->stream, c->src_row_dev));
           else if (c->precision == DCE_FP32_SPLIT && !x3 && c->tuning.x3_conv && c->winograd && !c->src_row_dev && !c->want_feat && n >= c->tuning.x3_conv_min)
               HIP_TRY(c, launch_conv_x3_f32(src, zscore, n, c->pkx3, c->feat, c->stream));      // mid-size batch: three-term conv stack, fp32 FC kernels
@@ -199,7 +202,7 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
             // fc.0 on the bf16 matrix pipe with three-term operands (fc_gemm_x3.hip); everything else as in DCE_FP32
             Timer t(c, 1);
             if (!x3_fused) HIP_TRY(c, launch_split3(c->feat, c->feat3, n, FEAT, c->stream));
-            HIP_TRY(c, launch_fc_gemm_x3(c->feat3, pair ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream));
+            HIP_TRY(c, launch_fc_gemm_x3(c->feat3, (pair || permk) ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream));
         } else
         { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
         if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1) && !fc_split_ok(n, FC2, FC1)) {
@@ -526,7 +529,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         }
     };
     const bool want_cx = precision == DCE_FP32_SPLIT || (precision == DCE_BF16_FC && c->tuning.x3_conv);
-    const bool want_pair = want_cx && c->tuning.x3_pair;              // conv_x3p.hip: fc.0's weights once more, K axis in its feature order
+    const bool want_pair = want_cx && (c->tuning.x3_pair || c->tuning.x3_permk);      // fc.0's weights once more, K axis in the conv kernels' feature order t' * 128 + c
     std::vector<float> w1p;
     if (want_pair) { w1p.resize(c->host_w[8].size()); fc_perm_k_host(c->host_w[8].data(), FC1, w1p.data()); }
     size_t off_bf[2] = {0, 0}, off_bfp = 0;

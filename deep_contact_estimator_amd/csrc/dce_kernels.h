@@ -38,6 +38,7 @@ struct Tuning {
     bool x3_conv = true;                                    // DCE_X3_CONV=0: DCE_FP32_SPLIT keeps the fp32 Winograd conv stack (three-plane feature output) instead of conv_x3.hip (A/B)
     long long x3_conv_min = 128;                            // DCE_X3_CONV_MIN: from this many windows the mode's conv stack runs on conv_x3.hip also BELOW the fc.0 threshold (fp32 features out)
     bool x3_unfused = false;                                // DCE_X3_UNFUSED: fp32 features + split3 kernel instead of the conv kernel's three-plane output (A/B)
+    bool x3_permk = true;                                   // DCE_X3_PERMK=0: conv_x3.hip's features go through LDS into the reference's flatten order (A/B) instead of straight out in the order t' * 128 + c
     bool x3_pair = false;                                   // DCE_X3_PAIR=1: chip-filling batches on conv_x3p.hip (two windows per 8-wave workgroup; measured 5-9 % SLOWER than conv_x3.hip, kept for the record and the A/B) instead of conv_x3.hip
     long long x3_pair_min = 1024;                           // DCE_X3_PAIR_MIN: windows per launch from which conv_x3p.hip runs
     int x3_min_tiles = 192;                                 // DCE_X3_MIN_TILES: 256x128 tiles a launch needs for the split-bf16 fc.0 kernel
@@ -154,8 +155,10 @@ struct ConvPackX3 { const unsigned short* w[4]; const float* b[4]; };
 size_t     conv_x3_pack_halfs(int layer);
 void       conv_x3_pack_host(int layer, const float* w, unsigned short* out);
 hipError_t init_conv_x3();
-hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st);
-hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st);
+//   permk: the features leave straight from the accumulators in the K order k' = t' * 128 + c (no LDS staging, no barriers); fc.0
+//   behind it then takes weights whose K axis is permuted the same way (fc_perm_k_host)
+hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st, int permk = 0);
+hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk = 0);
 hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st);
 hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3& pk, unsigned short* feat3, float* feat32,
                                const LayerTaps& taps, hipStream_t st);

@@ -28,11 +28,11 @@ def test_experiment_variants_in_their_own_build():
     if not os.path.exists(lib):
         build.build_experiments()
     env = dict(os.environ, DCE_LIB=lib, PYTHONPATH=ROOT)
-    sel = "rt4 or paired or ab_switches or layer_taps_bit_identical or tapped_kernels or phased_gemm_equals_tile"
+    sel = "rt4 or paired or ab_switches or layer_taps_bit_identical or tapped_kernels or phased_gemm_equals_tile or reference_hooks"
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_round3_gpu.py"), os.path.join(ROOT, "tests", "test_round4_gpu.py"),
                         os.path.join(ROOT, "tests", "test_gpu_parity.py")], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
-    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1] and "failed" not in r.stdout.splitlines()[-1], tail
     print(r.stdout.strip().splitlines()[-1])

@@ -49,6 +49,9 @@ def test_conv_layer_taps_vs_reference_hooks(kernel, name, golden, case_inputs, m
     """conv1, conv2, pool1, conv3, conv4 of the reference's window 0 (forward hooks on block1[1], block1[3], block1[5],
     block2[1], block2[3]) for EVERY conv kernel family, and the oracle's taps for the other windows of the launch
     (so that both windows of a two-window workgroup and every segment of a cut window are covered)."""
+    from conftest import has_experiments
+    if kernel == "wino2rt4" and not has_experiments():
+        pytest.skip("the four-row-tile workgroup lives in the experiments build (tests/test_experiments_gpu.py runs it there)")
     g = golden(name)
     sd, _ = case_inputs(g)
     m = model_of(int(g["wseed"]), str(g["bias"]))
@@ -138,7 +141,7 @@ def test_bf16_fc_vs_independent_restatement(n, model_of, orc):
     if n < 128:
         assert np.array_equal(t16["feat"], orc.bf16_bits(want16))
     else:
-        assert m16.last_plan()[0] == "conv_x3_bf16", m16.last_plan()
+        assert m16.last_plan()[0].startswith("conv_x3_bf16"), m16.last_plan()
         fd = got16 != want16
         assert fd.mean() < 2e-3, f"{fd.sum()} of {fd.size} features round differently"
         _, fe = np.frexp(np.maximum(np.abs(want16), np.abs(got16)))

@@ -151,3 +151,27 @@ def test_layer_taps_refuse_a_bf16_fc_context():
     with pytest.raises(RuntimeError, match="DCE_BF16_FC"):
         m.conv_layer_taps(x)
     m.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
+def test_features_straight_from_the_accumulators_equal_the_staged_ones(precision):
+    """conv_x3.hip writes its features straight from the accumulators in the K order t' * 128 + c (DCE_X3_PERMK, default) with fc.0's
+    weights permuted alike, or through LDS in the reference's flatten order (DCE_X3_PERMK=0): the same products, another order of the
+    fc.0 summation -- logits agree within the mode's noise, NaN windows are contained either way, a feature tap still hands out
+    the reference's order."""
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    a = _model(precision, env={"DCE_X3_PERMK": "1"}); a.load_state_dict(sd).eval()
+    b = _model(precision, env={"DCE_X3_PERMK": "0"}); b.load_state_dict(sd).eval()
+    for n in (4096, 4099, 3000 if precision == "fp32_split" else 129):
+        x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
+        x[3, 0, 0] = np.nan
+        ra, rb = a.predict(x), b.predict(x)
+        assert a.last_plan()[0].endswith("_permk") and not b.last_plan()[0].endswith("_permk"), (a.last_plan(), b.last_plan())
+        scale = np.nanmax(np.abs(rb["logits"]))
+        d = np.nanmax(np.abs(ra["logits"].astype(np.float64) - rb["logits"]))
+        assert d < (2e-5 if precision == "fp32_split" else 2e-2) * scale, (n, d)
+        assert np.isnan(ra["logits"][3]).all() and np.isnan(rb["logits"][3]).all() and np.isfinite(ra["logits"][4]).all()
+    t = a.forward_taps(np.random.default_rng(1).standard_normal((256, 150, 54), dtype=np.float32))
+    assert not a.last_plan()[0].endswith("_permk")                       # a feature tap keeps the reference's flatten order
+    a.close(); b.close()
