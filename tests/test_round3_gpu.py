@@ -170,9 +170,15 @@ def test_bf16_fc_vs_independent_restatement(n, model_of, orc):
     # (5) end to end: predict() is the same bits as the tap run, and stays within the accumulated rounding-boundary
     # band of the restatement (a few 1-ulp differences in feat / h1 move a logit by ~1e-4 of the logit scale)
     out = m16.predict(x)
-    assert np.array_equal(out["logits"], t16["logits"])
     ref = orc.Oracle(sd, bf16_fc=True).forward_windows(x[sl])
     scale = np.abs(ref["logits"]).max()
+    if m16.last_plan()[0].endswith("_permk"):
+        # from 128 windows predict() takes the features straight from the accumulators in the K order t' * 128 + c (the tap run
+        # keeps the reference's flatten order): the same bf16 products, fc.0's fp32 accumulation in another order -- an h1 entry
+        # at a bf16 rounding boundary may round the other way
+        assert np.abs(out["logits"] - t16["logits"]).max() <= 2e-3 * scale
+    else:
+        assert np.array_equal(out["logits"], t16["logits"])
     err = np.abs(out["logits"][sl] - ref["logits"]).max()
     assert err <= 2e-3 * scale, (err, scale)
     srt = np.sort(ref["logits"], axis=1)

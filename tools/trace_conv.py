@@ -80,3 +80,21 @@ for k in np.unique(key8):
 tot = both + one + none
 print("groups", len(np.unique(key8)), "blocks per group", np.bincount(np.unique(key8, return_inverse=True)[1]).tolist()[:8])
 print(f"CU time with MFMA phases of: two workgroups {both / tot:.3f}, one {one / tot:.3f}, none {none / tot:.3f}")
+
+# ---- by generation on a CU (2048 workgroups over 512 slots = 4 generations): is the launch-level loss in the first generation
+#      (every CU's two workgroups in their prologue at once) or in the tail?
+gen_tot, gen_pro, gen_start, gen_end = [[] for _ in range(8)], [[] for _ in range(8)], [[] for _ in range(8)], [[] for _ in range(8)]
+for k in np.unique(key8):
+    idx = np.where(key8 == k)[0]
+    if len(idx) < 4:
+        continue
+    idx = idx[np.argsort(t[idx, 0])]
+    for r, b in enumerate(idx[:8]):
+        g = r // 2
+        gen_tot[g].append(t[b, 9] - t[b, 0]); gen_pro[g].append(d[b, 0]); gen_start[g].append(t[b, 0] - t0); gen_end[g].append(t[b, 9] - t0)
+print("by generation on a CU (two workgroups per generation): workgroup total / prologue / start / end, cycles (mean)")
+for g in range(8):
+    if gen_tot[g]:
+        print(f"  generation {g}: total {np.mean(gen_tot[g]):9.0f}  prologue {np.mean(gen_pro[g]):8.0f}  start {np.mean(gen_start[g]):9.0f}  end {np.mean(gen_end[g]):9.0f}  (n={len(gen_tot[g])})")
+span = t[:, 9].max() - t0
+print(f"kernel span {span} cycles; a CU's last workgroup ends at {np.mean([max(v) for v in [gen_end[g] for g in range(8) if gen_end[g]]]):.0f} on average")
