@@ -66,7 +66,8 @@ __device__ __forceinline__ void put_feat3(Feat3* planes, size_t plane_elems, int
 // of O(1-10) and spreads of O(0.01) one fp32 ulp of the mean is already 5e-5 standard
 // deviations, so the mean must be the correctly rounded one, not an fp32 running sum.
 // red: >= NWIN*4*216 floats of LDS scratch (two sets of 216 doubles per window).
-template <bool ZS, int NWIN>
+// STAGE: 0 both halves; 1 only the loads (a persistent workgroup issues them a layer ahead); 2 only the arithmetic on x.
+template <bool ZS, int NWIN, int STAGE = 0>
 __device__ __forceinline__ void load_windows(const float* __restrict__ src, int64_t win_stride,
                                              int nvalid, float* __restrict__ red,
                                              float (&x)[NWIN][38], int tid)
@@ -79,14 +80,16 @@ __device__ __forceinline__ void load_windows(const float* __restrict__ src, int6
     // row group 0 and a missing window (odd n) re-reads window 0; neither is ever stored.  Only
     // the last row group (t = 148..151) has rows past the window: those two read 0.
     const int gl = loader ? g : 0;
+    if constexpr (STAGE != 2) {
 #pragma unroll
-    for (int w = 0; w < NWIN; ++w) {
-        const float* wsrc = src + (w < nvalid ? w : 0) * win_stride + gl * CH + c;
+        for (int w = 0; w < NWIN; ++w) {
+            const float* wsrc = src + (w < nvalid ? w : 0) * win_stride + gl * CH + c;
 #pragma unroll
-        for (int m = 0; m < 37; ++m) x[w][m] = wsrc[4 * m * CH];
-        x[w][37] = gl < 2 ? wsrc[148 * CH] : 0.f;             // rows 148 + gl
+            for (int m = 0; m < 37; ++m) x[w][m] = wsrc[4 * m * CH];
+            x[w][37] = gl < 2 ? wsrc[148 * CH] : 0.f;             // rows 148 + gl
+        }
     }
-    if (ZS) {
+    if (ZS && STAGE != 1) {
         double* dred = reinterpret_cast<double*>(red);
 #pragma unroll
         for (int w = 0; w < NWIN; ++w) {

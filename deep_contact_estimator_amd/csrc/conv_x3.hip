@@ -60,7 +60,7 @@ void conv_x3_pack_host(int l, const float* w, unsigned short* out)
                         }
 }
 
-template <bool ZS, bool TAPS = false, int OUT = 0, bool PERMK = false>
+template <bool ZS, bool TAPS = false, int OUT = 0, bool PERMK = false, bool PERSIST = false>
 __global__ __launch_bounds__(256, 2)
 void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems,
                     LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr)
@@ -68,18 +68,43 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
     // OUT: 0 the features leave as three bf16 planes (fc_gemm_x3.hip's layout); 1 as (n, 4736) fp32 in feat32 (batches below
     // the split-bf16 fc.0 kernel's threshold, whose fc.0 runs on the fp32 kernels); 2 as (n, 4736) bf16, round-to-nearest-even,
     // in feat3 (the DCE_BF16_FC precision, whose FC layers take bf16 operands)
+    // PERSIST (with PERMK only; experiments build, DCE_X3_PERSIST=1 -- measured 2-4 % SLOWER than one workgroup per window, with and
+    // without a start offset between the two workgroups of a CU: profiles/r4h_ab_conv_x3_persist.txt): gridDim.x workgroups walk the windows blockIdx.x, + gridDim.x, ..; the next window's samples are
+    // requested when conv3's MFMAs are through, so that their HBM latency passes under conv3's write-back and conv4 instead of
+    // opening the next prologue (the loads sit in registers: 38 per thread z-scored, 32 pre-normalised)
+    static_assert(!PERSIST || (PERMK && !TAPS), "the persistent form has the register-only feature tail");
     extern __shared__ __attribute__((aligned(16))) char cx_lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    float x[1][38];
+    float2 v[16];
+    auto request = [&](int64_t w, int tid_) {
+        if constexpr (ZS) load_windows<ZS, 1, 1>(src + w * (int64_t)CH, 0, 1, nullptr, x, tid_);
+        else {
+            // pre-normalised window: 4050 pairs of neighbouring channels, 16 per thread -- one 8-byte load, one split, three
+            // 4-byte LDS stores each (the per-channel mapping of load_windows costs 38 loads and 114 two-byte stores per thread)
+            const float2* wsrc = reinterpret_cast<const float2*>(src + w * (int64_t)(WIN * CH));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = wsrc[tid_ + 256 * q < WIN * CH / 2 ? tid_ + 256 * q : 0];
+        }
+    };
+    if constexpr (PERSIST) request(blockIdx.x, threadIdx.x);
+    for (int64_t win = blockIdx.x;;) {
+    int tid = threadIdx.x;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid));              // (or the address arithmetic of every phase is hoisted out of the loop and spilled)
+    const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int64_t win = blockIdx.x;
+
+    const uint4* w0 = reinterpret_cast<const uint4*>(pk.w[0]) + lane;
+    const uint4* w1 = reinterpret_cast<const uint4*>(pk.w[1]) + lane;
+    const uint4* w2 = reinterpret_cast<const uint4*>(pk.w[2]) + lane;
+    const uint4* w3 = reinterpret_cast<const uint4*>(pk.w[3]) + lane;
 
     TRACE_MARK(0);
     // ---- prologue: the window (z-scored if ZS) -> three-term planes, [t + 1][channel], channels 54..63 and the pad rows zero
+    if constexpr (!PERSIST) request(win, tid);
     int window_bad;
     if constexpr (ZS) {
-        float x[1][38];
-        load_windows<ZS, 1>(src + win * (int64_t)CH, 0, 1, reinterpret_cast<float*>(cx_lds), x, tid);
+        load_windows<ZS, 1, 2>(src, 0, 1, reinterpret_cast<float*>(cx_lds), x, tid);
         bool bad = false;
 #pragma unroll
         for (int m = 0; m < 38; ++m) bad |= !(fabsf(x[0][m]) <= FLT_MAX);
@@ -101,13 +126,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
             }
         }
     } else {
-        // pre-normalised window: 4050 pairs of neighbouring channels, 16 per thread -- one 8-byte load, one split, three
-        // 4-byte LDS stores each (the per-channel mapping of load_windows costs 38 loads and 114 two-byte stores per thread)
-        const float2* wsrc = reinterpret_cast<const float2*>(src + win * (int64_t)(WIN * CH));
-        float2 v[16];
         int t = tid / 27, c2 = tid % 27;                               // pair i = tid + 256 q: row i / 27, channels 2 (i % 27), + 1
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = wsrc[tid + 256 * q < WIN * CH / 2 ? tid + 256 * q : 0];
         {   // zero fill: 3936 x 16 bytes = 15 full rounds of the workgroup + 96 (constant offsets: no loop bookkeeping)
             uint4* z = reinterpret_cast<uint4*>(cx_lds) + tid;
 #pragma unroll
@@ -145,10 +164,6 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
             for (int ct = 0; ct < CX_NT; ++ct) acc[rt][ct] = cx_f32x4{bv.x, bv.y, bv.z, bv.w};
         }
     };
-    const uint4* w0 = reinterpret_cast<const uint4*>(pk.w[0]) + lane;
-    const uint4* w1 = reinterpret_cast<const uint4*>(pk.w[1]) + lane;
-    const uint4* w2 = reinterpret_cast<const uint4*>(pk.w[2]) + lane;
-    const uint4* w3 = reinterpret_cast<const uint4*>(pk.w[3]) + lane;
 
     // ---- stage 1 (T = 150, 64 channels in and out): wave = row-tile pair wv & 1, column tiles 5 (wv >> 1) ..
     {
@@ -177,6 +192,9 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         bias_acc(pk.b[2], 32 * wv);
         cx_layer<128, 2, false, CX_ILV != 0>(cx_lds + j * 128, sw, g, w2 + (size_t)wv * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(6);
+        if constexpr (PERSIST) {
+            if (win + gridDim.x < n) request(win + gridDim.x, tid);
+        }
         __syncthreads();
         cx_store<256, false, 75, TAPS>(cx_lds, acc, 32 * wv, 0, j, g, TAPS ? taps.conv3 + win * 128 * 75 : nullptr);      // 128 channels: 256-byte rows, rows 1..75
         if (tid < 96) {                                                        // rows 0 and 76 of the new layout = the zero padding
@@ -224,7 +242,12 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
                 }
             }
             TRACE_MARK(9);
-            return;
+            if constexpr (PERSIST) {
+                win += gridDim.x;
+                if (win >= n) return;
+                __syncthreads();                                       // every wave is through conv4's input before the next window overwrites it
+                continue;
+            } else return;
         }
         // ---- conv4 + bias + ReLU + MaxPool (t = 74 dropped) + flatten k = c * 37 + t' -> three planes [k] in LDS (the layer's
         //      input is dead once every wave is through its MFMAs), then 16-byte stores into fc_gemm_x3.hip's layout: 7 per
@@ -309,7 +332,23 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         }
     }
     TRACE_MARK(9);
+    return;
+    }
 }
+
+#if DCE_EXPERIMENTS
+// the persistent form's grid: two workgroups per CU (what the LDS admits), every one with the same number of windows +- 1
+static unsigned persist_grid(int64_t n)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return (unsigned)(n < 2 * (int64_t)cus ? n : 2 * (int64_t)cus);
+}
+#endif
 
 hipError_t init_conv_x3()
 {
@@ -326,7 +365,12 @@ hipError_t init_conv_x3()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
     if (e != hipSuccess) return e;
     for (const void* k : {reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 0, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 0, true>),
-                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true>)})
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true>),
+#if DCE_EXPERIMENTS
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 0, true, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 0, true, true>),
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true, true>),
+#endif
+                          })
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS)) != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
 }
@@ -356,6 +400,14 @@ hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const Con
 hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk)
 {
     if (n <= 0) return hipSuccess;
+#if DCE_EXPERIMENTS
+    if (permk == 2) {                                  // ... from persistent workgroups (measured 2-4 % slower: profiles/r4h_ab_conv_x3_persist.txt)
+        plan_note("conv_x3_bf16_permk_persist");
+        if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+        return hipGetLastError();
+    }
+#endif
     if (permk) {                                       // features in the K order t' * 128 + c, straight from the accumulators
         plan_note("conv_x3_bf16_permk");
         if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
@@ -372,6 +424,14 @@ hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPac
 {
     if (n <= 0) return hipSuccess;
     const size_t plane_elems = (size_t)((n + 1) & ~(int64_t)1) * FEAT;
+#if DCE_EXPERIMENTS
+    if (permk == 2) {
+        plan_note("conv_x3_permk_persist");
+        if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 0, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
+        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 0, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
+        return hipGetLastError();
+    }
+#endif
     if (permk) {
         plan_note("conv_x3_permk");
         if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 0, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);

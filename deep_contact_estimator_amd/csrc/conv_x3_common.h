@@ -92,7 +92,9 @@ __device__ __forceinline__ void cx_layer(const char* __restrict__ xrow, const in
             for (int p = 0; p < 3; ++p) bf[b][ct][p] = *reinterpret_cast<const uint4*>(x + ct * 16 * ROWB + p * CX_PLANE);
     };
     // (Requesting the NEXT layer's first weight fragments before the write-back, so that its barriers do not stand in front
-    //  of an L2 round trip, was tried: 24 more live registers, 84-100 B of scratch, 394 us instead of 350.)
+    //  of an L2 round trip, was tried: 24 more live registers, 84-100 B of scratch, 394 us instead of 350; again in round 4 with
+    //  the kernel at 192 registers and no scratch: 296.1 us instead of 294.2 (profiles/r4h_ab_conv_x3_persist.txt) -- the partner
+    //  workgroup's MFMA phase already covers that round trip.)
     fetch(0, 0);
     if constexpr (ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

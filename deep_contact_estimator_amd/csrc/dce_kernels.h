@@ -39,6 +39,8 @@ struct Tuning {
     long long x3_conv_min = 128;                            // DCE_X3_CONV_MIN: from this many windows the mode's conv stack runs on conv_x3.hip also BELOW the fc.0 threshold (fp32 features out)
     bool x3_unfused = false;                                // DCE_X3_UNFUSED: fp32 features + split3 kernel instead of the conv kernel's three-plane output (A/B)
     bool x3_permk = true;                                   // DCE_X3_PERMK=0: conv_x3.hip's features go through LDS into the reference's flatten order (A/B) instead of straight out in the order t' * 128 + c
+    bool x3_persist = false;                                // DCE_X3_PERSIST=1 (experiments build): conv_x3.hip as persistent workgroups (two per CU) that request the next window's samples a layer ahead; measured 2-4 % slower
+    long long x3_persist_min = 1024;                        // DCE_X3_PERSIST_MIN: windows per launch from which they do
     bool x3_pair = false;                                   // DCE_X3_PAIR=1: chip-filling batches on conv_x3p.hip (two windows per 8-wave workgroup; measured 5-9 % SLOWER than conv_x3.hip, kept for the record and the A/B) instead of conv_x3.hip
     long long x3_pair_min = 1024;                           // DCE_X3_PAIR_MIN: windows per launch from which conv_x3p.hip runs
     int x3_min_tiles = 192;                                 // DCE_X3_MIN_TILES: 256x128 tiles a launch needs for the split-bf16 fc.0 kernel

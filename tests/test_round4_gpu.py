@@ -63,6 +63,31 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs):
 
 @pytest.mark.experiments
 @pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
+def test_persistent_conv_stack_equals_one_workgroup_per_window(precision):
+    """conv_x3.hip's persistent form (DCE_X3_PERSIST=1, experiments build: two workgroups per CU walk the windows, the next window's
+    samples requested a layer ahead) runs the same arithmetic in the same order: the same BYTES as one workgroup per window, at
+    ragged sizes (workgroups with different window counts, fewer windows than workgroups), on both entries, with bad windows."""
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    a = _model(precision, env={"DCE_X3_PERSIST": "1", "DCE_X3_PERSIST_MIN": "128"}); a.load_state_dict(sd).eval()
+    b = _model(precision, env={"DCE_X3_PERSIST": "0"}); b.load_state_dict(sd).eval()
+    for n in (300, 4096, 4097, 5001):
+        if precision == "fp32_split" and n < 2817: continue
+        x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
+        x[n // 3, 17, 3] = np.nan; x[n - 1, 149, 53] = np.inf
+        ra, rb = a.predict(x), b.predict(x)
+        assert a.last_plan()[0].endswith("_persist") and not b.last_plan()[0].endswith("_persist"), (a.last_plan(), b.last_plan())
+        assert np.array_equal(ra["logits"], rb["logits"], equal_nan=True) and np.array_equal(ra["pred"], rb["pred"]), n
+        assert np.isnan(ra["logits"][n // 3]).all() and np.isnan(ra["logits"][n - 1]).all() and np.isfinite(ra["logits"][0]).all()
+    seq = synth.make_sequence(6000 + 149, seed=3).astype(np.float32)
+    sa, sb = a.infer_sequence(seq), b.infer_sequence(seq)
+    assert a.last_plan()[0].endswith("_persist")
+    assert np.array_equal(sa["logits"], sb["logits"])
+    a.close(); b.close()
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
 def test_paired_conv_stack_vs_one_window_kernel_and_oracle(precision, orc):
     """conv_x3p.hip (DCE_X3_PAIR=1: one 8-wave workgroup per CU, two windows per wave, write-backs inside the other window's K
     loops, features in the K order t' * 128 + c with fc.0's weights permuted alike) against conv_x3.hip on the same windows:

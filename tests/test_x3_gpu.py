@@ -69,7 +69,7 @@ def test_split_mode_meets_the_fp32_contract(n, pair, orc):
     seq = synth.make_sequence(n + 149, seed=2).astype(np.float32)
     w = b.zscore_windows(seq, 0, n)
     out = b.predict(w)
-    assert "fc_x3_256x128" in b.last_plan() and b.last_plan()[0] in ("conv_x3", "conv_x3_permk"), b.last_plan()
+    assert "fc_x3_256x128" in b.last_plan() and b.last_plan()[0] in ("conv_x3", "conv_x3_permk", "conv_x3_permk_persist"), b.last_plan()
     ref = orc.Oracle(sd).forward_windows(w if isinstance(w, np.ndarray) else w.cpu().numpy())
     tol_ok(out["logits"], ref["logits"], f"fp32_split, {n} rows vs oracle")
     flips = _argmax_ok(out["pred"], ref["logits"], ref["pred"])
