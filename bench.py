@@ -85,8 +85,13 @@ def kernel_peak(kernel, precision):
     if precision == "fp32_split" and kernel == "fc1_gemm":
         return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA, six bf16 x bf16 terms per fp32 product (fc_gemm_x3.hip)"
     if precision in ("fp32_split", "bf16_fc") and kernel == "conv_stack":
-        return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA, six terms per product, direct-form conv with its tile padding (conv_x3.hip)"
+        return PEAK_BF16_MFMA_TFLOPS, f"bf16 MFMA, {conv_terms(precision)} bf16 x bf16 terms per product, direct-form conv with its tile padding (conv_x3.hip)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA" if kernel != "fc3_tail" else "fp32 VALU (= fp32 MFMA rate)"
+
+
+def conv_terms(precision):
+    """MFMAs per product of conv_x3.hip: six on three-term operands (fp32_split), three on two-term operands (bf16_fc's default)."""
+    return 3 if precision == "bf16_fc" and os.environ.get("DCE_X3_BF16_TERMS", "2") != "3" else 6
 
 
 def exec_flop(kernel, precision):
@@ -94,7 +99,7 @@ def exec_flop(kernel, precision):
     if precision == "fp32_split" and kernel == "fc1_gemm":
         return 6 * EXEC_FLOP[kernel]
     if precision in ("fp32_split", "bf16_fc") and kernel == "conv_stack":       # direct form on 16x16 tiles: (64*160 + 64*160 + 128*80) * 192 + 128*80*384 MACs
-        return 6 * 2 * ((64 * 160 + 64 * 160 + 128 * 80) * 192 + 128 * 80 * 384)
+        return conv_terms(precision) * 2 * ((64 * 160 + 64 * 160 + 128 * 80) * 192 + 128 * 80 * 384)
     return EXEC_FLOP[kernel]
 
 
@@ -352,8 +357,9 @@ def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000):
 
 
 MODE_TEXT = {
-    "bf16_fc": "BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; conv stack fp32-grade "
-               "(three-term bf16 operands on the bf16 matrix pipe, conv_x3.hip; DCE_X3_CONV=0: the fp32 Winograd kernel), fc.6 fp32",
+    "bf16_fc": "BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; conv stack on two-term bf16 "
+               "operands (three MFMAs per product, ~17 significant bits in front of the features' rounding to bf16, conv_x3.hip NT = 2; "
+               "DCE_X3_BF16_TERMS=3: fp32_split's six-MFMA products, DCE_X3_CONV=0: the fp32 Winograd kernel), fc.6 fp32",
     "fp32_split": "the bench step ({B} windows) with the conv stack and fc.0 on the bf16 matrix pipe, every fp32 operand as three bf16 terms "
                   "(six MFMAs per product, fp32 accumulate: fp32 results, not the fp32 path's bits -- opt-in, include/dce.h DCE_FP32_SPLIT); "
                   "fc.3 and fc.6 fp32 MFMA",

@@ -60,8 +60,8 @@ void conv_x3_pack_host(int l, const float* w, unsigned short* out)
                         }
 }
 
-template <bool ZS, bool TAPS = false, int OUT = 0, bool PERMK = false, bool PERSIST = false>
-__global__ __launch_bounds__(256, 2)
+template <bool ZS, bool TAPS = false, int OUT = 0, bool PERMK = false, bool PERSIST = false, int NT = 3>
+__global__ __launch_bounds__(256, NT == 2 ? 3 : 2)
 void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems,
                     LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr)
 {   // TAPS (dce_conv_layer_taps, parity tests): every layer's output also goes to HBM in fp32, and so do the features.
@@ -72,7 +72,11 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
     // without a start offset between the two workgroups of a CU: profiles/r4h_ab_conv_x3_persist.txt): gridDim.x workgroups walk the windows blockIdx.x, + gridDim.x, ..; the next window's samples are
     // requested when conv3's MFMAs are through, so that their HBM latency passes under conv3's write-back and conv4 instead of
     // opening the next prologue (the loads sit in registers: 38 per thread z-scored, 32 pre-normalised)
+    // NT = 2 (DCE_BF16_FC only, OUT = 2): two-term operands, three MFMAs per product -- ~17 significant bits through the four layers,
+    // 2^8 finer than the bf16 rounding the features leave with; two planes of LDS (42 KB) and ~140 registers: three workgroups per CU
     static_assert(!PERSIST || (PERMK && !TAPS), "the persistent form has the register-only feature tail");
+    static_assert(NT == 3 || (OUT == 2 && !TAPS), "two-term operands only where the features are rounded to bf16");
+    constexpr int LDSB = NT * CX_PLANE;
     extern __shared__ __attribute__((aligned(16))) char cx_lds[];
     float x[1][38];
     float2 v[16];
@@ -109,7 +113,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
 #pragma unroll
         for (int m = 0; m < 38; ++m) bad |= !(fabsf(x[0][m]) <= FLT_MAX);
         window_bad = __syncthreads_or(bad);                            // (also: every thread is done with the z-score scratch)
-        for (int i = tid; i < CX_LDS / 16; i += 256) reinterpret_cast<uint4*>(cx_lds)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < LDSB / 16; i += 256) reinterpret_cast<uint4*>(cx_lds)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         if (tid < 4 * CH) {
             const int c = tid % CH, gq = tid / CH;
@@ -119,7 +123,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
                 cx_split2(x[0][m], x[0][m + 1], p);
                 const int t0 = 4 * m + gq, t1 = t0 + 4;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
+                for (int k = 0; k < NT; ++k) {
                     *reinterpret_cast<unsigned short*>(cx_lds + k * CX_PLANE + cx_addr<128>(t0 + 1, c)) = (unsigned short)p[k];
                     if (t1 < WIN) *reinterpret_cast<unsigned short*>(cx_lds + k * CX_PLANE + cx_addr<128>(t1 + 1, c)) = (unsigned short)(p[k] >> 16);
                 }
@@ -130,8 +134,8 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         {   // zero fill: 3936 x 16 bytes = 15 full rounds of the workgroup + 96 (constant offsets: no loop bookkeeping)
             uint4* z = reinterpret_cast<uint4*>(cx_lds) + tid;
 #pragma unroll
-            for (int r = 0; r < CX_LDS / 16 / 256; ++r) z[256 * r] = make_uint4(0, 0, 0, 0);
-            if (tid < CX_LDS / 16 % 256) z[256 * (CX_LDS / 16 / 256)] = make_uint4(0, 0, 0, 0);
+            for (int r = 0; r < LDSB / 16 / 256; ++r) z[256 * r] = make_uint4(0, 0, 0, 0);
+            if (tid < LDSB / 16 % 256) z[256 * (LDSB / 16 / 256)] = make_uint4(0, 0, 0, 0);
         }
         // non-finite scan: x * 0 is 0 for a finite x and NaN for Inf / NaN (16 packed FMAs; a chain of compares compiles
         // to five instructions per value)
@@ -146,7 +150,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
             if (tid + 256 * q < WIN * CH / 2) {
                 char* d = cx_lds + cx_addr<128>(t + 1, 2 * c2);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(d + k * CX_PLANE) = p[k];
+                for (int k = 0; k < NT; ++k) *reinterpret_cast<unsigned*>(d + k * CX_PLANE) = p[k];
             }
             t += 9; c2 += 13;                                          // 256 = 9 x 27 + 13
             if (c2 >= 27) { c2 -= 27; t += 1; }
@@ -171,18 +175,18 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         const int sw[3] = {cx_swz<128>(base), cx_swz<128>(base + 1), cx_swz<128>(base + 2)};
         const char* xrow = cx_lds + base * 128;
         bias_acc(pk.b[0], 32 * P);
-        cx_layer<128, 2, false, CX_ILV != 0>(xrow, sw, g, w0 + (size_t)P * (6 * 2 * 3 * 64), acc);
+        cx_layer<128, 2, false, CX_ILV != 0, NT>(xrow, sw, g, w0 + (size_t)P * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(2);
         __syncthreads();                                               // every wave has read conv1's input
-        cx_store<128, false, WIN, TAPS>(cx_lds, acc, 32 * P, ct0, j, g, TAPS ? taps.conv1 + win * 64 * 150 : nullptr);
+        cx_store<128, false, WIN, TAPS, NT>(cx_lds, acc, 32 * P, ct0, j, g, TAPS ? taps.conv1 + win * 64 * 150 : nullptr);
         __syncthreads();
         TRACE_MARK(3);
         bias_acc(pk.b[1], 32 * P);
-        cx_layer<128, 2, false, CX_ILV != 0>(xrow, sw, g, w1 + (size_t)P * (6 * 2 * 3 * 64), acc);
+        cx_layer<128, 2, false, CX_ILV != 0, NT>(xrow, sw, g, w1 + (size_t)P * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(4);
         __syncthreads();
-        cx_store<128, true, WIN, TAPS>(cx_lds, acc, 32 * P, ct0, j, g, TAPS ? taps.conv2 + win * 64 * 150 : nullptr, TAPS ? taps.pool1 + win * 64 * 75 : nullptr);     // pooled: rows 1..75 of the stage-2 layout (64 channels)
-        if (tid < 24) reinterpret_cast<uint4*>(cx_lds + (tid >> 3) * CX_PLANE + 76 * 128)[tid & 7] = make_uint4(0, 0, 0, 0);   // row 76 = right pad
+        cx_store<128, true, WIN, TAPS, NT>(cx_lds, acc, 32 * P, ct0, j, g, TAPS ? taps.conv2 + win * 64 * 150 : nullptr, TAPS ? taps.pool1 + win * 64 * 75 : nullptr);     // pooled: rows 1..75 of the stage-2 layout (64 channels)
+        if (tid < 8 * NT) reinterpret_cast<uint4*>(cx_lds + (tid >> 3) * CX_PLANE + 76 * 128)[tid & 7] = make_uint4(0, 0, 0, 0);   // row 76 = right pad
         __syncthreads();
         TRACE_MARK(5);
     }
@@ -190,14 +194,14 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
     {
         const int sw[3] = {cx_swz<128>(j), cx_swz<128>(j + 1), cx_swz<128>(j + 2)};
         bias_acc(pk.b[2], 32 * wv);
-        cx_layer<128, 2, false, CX_ILV != 0>(cx_lds + j * 128, sw, g, w2 + (size_t)wv * (6 * 2 * 3 * 64), acc);
+        cx_layer<128, 2, false, CX_ILV != 0, NT>(cx_lds + j * 128, sw, g, w2 + (size_t)wv * (6 * 2 * 3 * 64), acc);
         TRACE_MARK(6);
         if constexpr (PERSIST) {
             if (win + gridDim.x < n) request(win + gridDim.x, tid);
         }
         __syncthreads();
-        cx_store<256, false, 75, TAPS>(cx_lds, acc, 32 * wv, 0, j, g, TAPS ? taps.conv3 + win * 128 * 75 : nullptr);      // 128 channels: 256-byte rows, rows 1..75
-        if (tid < 96) {                                                        // rows 0 and 76 of the new layout = the zero padding
+        cx_store<256, false, 75, TAPS, NT>(cx_lds, acc, 32 * wv, 0, j, g, TAPS ? taps.conv3 + win * 128 * 75 : nullptr);      // 128 channels: 256-byte rows, rows 1..75
+        if (tid < 32 * NT) {                                                   // rows 0 and 76 of the new layout = the zero padding
             const int p = tid >> 5, r = (tid >> 4) & 1, s = tid & 15;
             reinterpret_cast<uint4*>(cx_lds + p * CX_PLANE + (r ? 76 : 0) * 256)[s] = make_uint4(0, 0, 0, 0);
         }
@@ -205,7 +209,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         TRACE_MARK(7);
         const int sw4[3] = {cx_swz<256>(j), cx_swz<256>(j + 1), cx_swz<256>(j + 2)};
         bias_acc(pk.b[3], 32 * wv);
-        cx_layer<256, 4, false, CX_ILV != 0>(cx_lds + j * 256, sw4, g, w3 + (size_t)wv * (12 * 2 * 3 * 64), acc);
+        cx_layer<256, 4, false, CX_ILV != 0, NT>(cx_lds + j * 256, sw4, g, w3 + (size_t)wv * (12 * 2 * 3 * 64), acc);
         TRACE_MARK(8);
         if constexpr (PERMK) {
             // ---- conv4 + ReLU + MaxPool (t = 74 dropped) straight from the accumulators to HBM in the K order k' = t' * 128 + c: a lane
@@ -366,6 +370,8 @@ hipError_t init_conv_x3()
     if (e != hipSuccess) return e;
     for (const void* k : {reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 0, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 0, true>),
                           reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true>),
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, false, false, 2>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, false, false, 2>),
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true, false, 2>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true, false, 2>),
 #if DCE_EXPERIMENTS
                           reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 0, true, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 0, true, true>),
                           reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true, true>),
@@ -397,9 +403,21 @@ hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const Con
 }
 
 // ... with (n, 4736) bf16 features out: the DCE_BF16_FC precision
-hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk)
+hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk, int terms)
 {
     if (n <= 0) return hipSuccess;
+    if (terms == 2) {                                  // two-term operands (three MFMAs per product), three workgroups per CU
+        constexpr int L2T = 2 * CX_PLANE;
+        plan_note(permk ? "conv_x2_bf16_permk" : "conv_x2_bf16");
+        if (permk) {
+            if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+            else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+        } else {
+            if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, false, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+            else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, false, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+        }
+        return hipGetLastError();
+    }
 #if DCE_EXPERIMENTS
     if (permk == 2) {                                  // ... from persistent workgroups (measured 2-4 % slower: profiles/r4h_ab_conv_x3_persist.txt)
         plan_note("conv_x3_bf16_permk_persist");

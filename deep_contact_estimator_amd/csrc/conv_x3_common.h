@@ -73,23 +73,26 @@ __device__ __forceinline__ void cx_fetch_w0(const uint4* __restrict__ wp, CxW& w
 }
 //   ILV  : the 21 fragment requests of step s+1 are dealt out between the MFMAs of step s (two MFMAs, one request, ...) instead of
 //          going out in a bunch ahead of them, during which the matrix pipe runs dry (~220 cycles of a 960-cycle K-step)
-template <int ROWB, int NKB, bool PRE = false, bool ILV = false>
+//   NT   : terms per operand: 3 = fp32-grade products (six MFMAs each); 2 = ~17 significant bits (a1 b1 + a1 b2 + a2 b1: three MFMAs),
+//          for the precision whose features leave rounded to bf16 anyway.  The packed weights keep their three planes either way.
+template <int ROWB, int NKB, bool PRE = false, bool ILV = false, int NT = 3>
 __device__ __forceinline__ void cx_layer(const char* __restrict__ xrow, const int (&sw)[3], int g,
                                          const uint4* __restrict__ wp, cx_f32x4 (&acc)[2][CX_NT], const CxW* pre = nullptr)
 {
     constexpr int S = 3 * NKB;
-    uint4 af[2][2][3], bf[2][CX_NT][3];                               // [buffer][...][plane]
+    static_assert(NT == 2 || NT == 3, "two or three terms");
+    uint4 af[2][2][NT], bf[2][CX_NT][NT];                             // [buffer][...][plane]
     auto fetch = [&](int s, int b) {                                  // s, b compile-time at every call
         const int kb = s / 3, tap = s % 3;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[b][rt][p] = (PRE && s == 0) ? pre->f[rt][p] : wp[((s * 2 + rt) * 3 + p) * 64];
+            for (int p = 0; p < NT; ++p) af[b][rt][p] = (PRE && s == 0) ? pre->f[rt][p] : wp[((s * 2 + rt) * 3 + p) * 64];
         const char* x = xrow + tap * ROWB + (((4 * kb + g) ^ sw[tap]) << 4);
 #pragma unroll
         for (int ct = 0; ct < CX_NT; ++ct)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[b][ct][p] = *reinterpret_cast<const uint4*>(x + ct * 16 * ROWB + p * CX_PLANE);
+            for (int p = 0; p < NT; ++p) bf[b][ct][p] = *reinterpret_cast<const uint4*>(x + ct * 16 * ROWB + p * CX_PLANE);
     };
     // (Requesting the NEXT layer's first weight fragments before the write-back, so that its barriers do not stand in front
     //  of an L2 round trip, was tried: 24 more live registers, 84-100 B of scratch, 394 us instead of 350; again in round 4 with
@@ -105,9 +108,10 @@ __device__ __forceinline__ void cx_layer(const char* __restrict__ xrow, const in
         //  388 us per 4096 windows instead of 350)
         if constexpr (!ILV) __builtin_amdgcn_sched_barrier(0);
         // six terms per product, small ones first; consecutive MFMAs go to different accumulators
-        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int NP = NT == 3 ? 6 : 3;
+        constexpr int TA[6] = {NT == 3 ? 0 : 1, NT == 3 ? 2 : 0, NT == 3 ? 1 : 0, 0, 1, 0}, TB[6] = {NT == 3 ? 2 : 0, NT == 3 ? 0 : 1, NT == 3 ? 1 : 0, 1, 0, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NP; ++t)
 #pragma unroll
             for (int ct = 0; ct < CX_NT; ++ct)
 #pragma unroll
@@ -117,10 +121,10 @@ __device__ __forceinline__ void cx_layer(const char* __restrict__ xrow, const in
         if constexpr (ILV) {
             if (s + 1 < S) {                                          // the order of this K-step's region: weights (L2) first, then the LDS reads
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                for (int i = 0; i < 2 * NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
 #pragma unroll
-                for (int i = 0; i < 3 * CX_NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x008, 60 - 2 * (6 + 3 * CX_NT), 0);
+                for (int i = 0; i < NT * CX_NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * CX_NT * NP - 2 * (2 * NT + NT * CX_NT), 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -134,7 +138,7 @@ __device__ __forceinline__ float cx_neighbour(float v)                // the val
 
 // bias + ReLU (+ MaxPool over column pairs) of a wave's tiles -> three-term planes of the next layer's input, in LDS
 //   T : columns of this layer; POOL: the next layer sees T / 2 positions
-template <int ROWB_OUT, bool POOL, int T, bool TAPS = false>
+template <int ROWB_OUT, bool POOL, int T, bool TAPS = false, int NT = 3>
 __device__ __forceinline__ void cx_store(char* __restrict__ lds, const cx_f32x4 (&acc)[2][CX_NT],
                                          int co0, int ct0, int j, int g,
                                          float* __restrict__ tap = nullptr, float* __restrict__ tap_pool = nullptr)
@@ -166,7 +170,7 @@ __device__ __forceinline__ void cx_store(char* __restrict__ lds, const cx_f32x4 
             if (ok) {
                 char* d = lds + cx_addr<ROWB_OUT>(row, co);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(d + p * CX_PLANE) = make_uint2(lo[p], hi[p]);
+                for (int p = 0; p < NT; ++p) *reinterpret_cast<uint2*>(d + p * CX_PLANE) = make_uint2(lo[p], hi[p]);
             }
         }
     }

@@ -141,9 +141,11 @@ def test_bf16_fc_vs_independent_restatement(n, model_of, orc):
     if n < 128:
         assert np.array_equal(t16["feat"], orc.bf16_bits(want16))
     else:
-        assert m16.last_plan()[0].startswith("conv_x3_bf16"), m16.last_plan()
+        # (... by default on TWO-term operands, conv_x2_*: ~17 significant bits, so about one value in 2^8 sits close enough to a
+        #  bf16 rounding boundary to land on its other side; the bound on each such value below is unchanged)
+        assert m16.last_plan()[0].startswith(("conv_x2_bf16", "conv_x3_bf16")), m16.last_plan()
         fd = got16 != want16
-        assert fd.mean() < 2e-3, f"{fd.sum()} of {fd.size} features round differently"
+        assert fd.mean() < (2e-2 if m16.last_plan()[0].startswith("conv_x2") else 2e-3), f"{fd.sum()} of {fd.size} features round differently"
         _, fe = np.frexp(np.maximum(np.abs(want16), np.abs(got16)))
         fbad = fd & (np.abs(got16 - feat32) > np.ldexp(0.5, fe - 8) + 1e-5 * np.abs(feat32).max() + 1e-4 * np.abs(feat32))
         assert not fbad.any(), f"{fbad.sum()} features differ by more than a rounding-boundary flip"

@@ -48,7 +48,7 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs):
         flips = out["pred"] != g["pred"]
         assert err < 2e-2 * scale, (err, scale)
         assert flips.mean() < 0.02 and (g["margin"][flips] < 4 * err + 1e-6).all()
-        assert any(k.startswith("conv_x3") for k in plan) and "fc_phased256x128" in plan, plan
+        assert plan[0].startswith("conv_x2_bf16") and "fc_phased256x128" in plan, plan      # two-term operands: three MFMAs per product
     else:
         # (three bounds: on this sequence the reference's own fp32 z-score puts 5 of its 65,536 logits 1.9 bounds away from the
         #  fp64-statistics evaluation -- tests/test_oracle.py::test_chip_filling_golden_pins_the_oracle)
@@ -61,6 +61,47 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs):
     m.close()
 
 
+@pytest.mark.parametrize("n", [128, 515, 4096, 4099])
+def test_bf16_fc_conv_stack_on_two_term_operands(n, orc):
+    """DCE_BF16_FC's conv stack by default: conv_x3.hip with NT = 2 -- operands as two bf16 terms, a1 b1 + a1 b2 + a2 b1 (three MFMAs per
+    product, ~17 significant bits), two LDS planes, three workgroups per CU -- against the same kernel on three-term operands
+    (DCE_X3_BF16_TERMS=3, fp32-grade).  The features leave rounded to bf16 (8 bits), so the two may differ only where a value sits
+    within ~2^-17 of a rounding boundary: few values, one bf16 ulp each; the logits agree far inside the mode's band and the error
+    against the fp64 oracle is the same.  Non-finite windows, odd sizes, both feature orders (a tap keeps the reference's flatten
+    order), the z-score entry."""
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    a = _model("bf16_fc"); a.load_state_dict(sd).eval()
+    b = _model("bf16_fc", env={"DCE_X3_BF16_TERMS": "3"}); b.load_state_dict(sd).eval()
+    x = np.random.default_rng(50 + n).standard_normal((n, 150, 54), dtype=np.float32)
+    x[n // 2, 3, 7] = np.inf
+    ta, tb = a.forward_taps(x), b.forward_taps(x)
+    assert a.last_plan()[0] == "conv_x2_bf16" and b.last_plan()[0] == "conv_x3_bf16", (a.last_plan(), b.last_plan())
+    fa, fb = orc.bf16_from_bits(ta["feat"]), orc.bf16_from_bits(tb["feat"])
+    assert np.isnan(fa[n // 2]).all() and np.isnan(fb[n // 2]).all()
+    fa, fb = np.delete(fa, n // 2, 0), np.delete(fb, n // 2, 0)
+    d = fa != fb
+    assert d.mean() < 2e-2, d.mean()
+    _, e = np.frexp(np.maximum(np.abs(fa), np.abs(fb)))
+    # one bf16 ulp (8 significand bits); next to zero (ReLU'd sums that cancel) the two-term products' absolute error, ~2^-17 of the
+    # sum of the products' magnitudes, is what separates the two
+    assert (np.abs(fa - fb)[d] <= np.ldexp(1.0, e[d] - 8) + 1e-4 * np.abs(fb).max()).all()
+    ra, rb = a.predict(x), b.predict(x)
+    assert a.last_plan()[0] == "conv_x2_bf16_permk" and b.last_plan()[0] == "conv_x3_bf16_permk"
+    ok = np.arange(n) != n // 2
+    assert np.isnan(ra["logits"][n // 2]).all() and ra["pred"][n // 2] == 0
+    ref = orc.Oracle(sd).forward_windows(x[ok][:600])
+    scale = np.abs(ref["logits"]).max()
+    ea, eb = (np.abs(r["logits"][ok][:600].astype(np.float64) - ref["logits"]).max() for r in (ra, rb))
+    assert ea < 2e-2 * scale and ea < 1.5 * eb + 1e-3 * scale, (ea, eb, scale)
+    assert np.abs(ra["logits"][ok].astype(np.float64) - rb["logits"][ok]).max() < 5e-3 * scale
+    seq = synth.make_sequence(n + 149, seed=n).astype(np.float32)
+    sa, sb = a.infer_sequence(seq), b.infer_sequence(seq)
+    assert a.last_plan()[0] == "conv_x2_bf16_permk"
+    assert np.abs(sa["logits"].astype(np.float64) - sb["logits"]).max() < 5e-3 * np.abs(sb["logits"]).max()
+    a.close(); b.close()
+
+
 @pytest.mark.experiments
 @pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
 def test_persistent_conv_stack_equals_one_workgroup_per_window(precision):
@@ -69,8 +110,8 @@ def test_persistent_conv_stack_equals_one_workgroup_per_window(precision):
     ragged sizes (workgroups with different window counts, fewer windows than workgroups), on both entries, with bad windows."""
     from deep_contact_estimator_amd import synth
     sd = synth.make_state_dict(1, "uniform")
-    a = _model(precision, env={"DCE_X3_PERSIST": "1", "DCE_X3_PERSIST_MIN": "128"}); a.load_state_dict(sd).eval()
-    b = _model(precision, env={"DCE_X3_PERSIST": "0"}); b.load_state_dict(sd).eval()
+    a = _model(precision, env={"DCE_X3_PERSIST": "1", "DCE_X3_PERSIST_MIN": "128", "DCE_X3_BF16_TERMS": "3"}); a.load_state_dict(sd).eval()
+    b = _model(precision, env={"DCE_X3_PERSIST": "0", "DCE_X3_BF16_TERMS": "3"}); b.load_state_dict(sd).eval()
     for n in (300, 4096, 4097, 5001):
         if precision == "fp32_split" and n < 2817: continue
         x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deep_contact_estimator_amd import contact_cnn, synth, _lib
 B = 4096
-m = contact_cnn(device=0, max_batch=B, precision="fp32_split"); m.load_state_dict(synth.make_state_dict(1)).eval()
+PREC = sys.argv[1] if len(sys.argv) > 1 else "fp32_split"
+m = contact_cnn(device=0, max_batch=B, precision=PREC); m.load_state_dict(synth.make_state_dict(1)).eval()
 x = torch.randn((B, 150, 54), device="cuda")
 for _ in range(3): m.predict(x)
 torch.cuda.synchronize()
@@ -22,4 +23,4 @@ for i, nme in enumerate(names):
     print(f"  {nme:9s} {d[:, i].mean():9.0f} {np.percentile(d[:, i], 10):9.0f} {np.percentile(d[:, i], 90):9.0f}")
 tot = t[:, 9] - t[:, 0]
 print("block total", tot.mean(), " kernel span", t[:, 9].max() - t[:, 0].min(), " MFMA-phase share", (d[:, [1, 3, 5, 7]].sum(1) / tot).mean())
-print("pure MFMA cycles per wave: conv1/2/3 5760 each, conv4 11520 (60 MFMAs x 16 cycles x 6 / 12 K-steps)")
+print("pure MFMA cycles per wave: conv1/2/3 5760 each, conv4 11520 (60 MFMAs x 16 cycles x 6 / 12 K-steps); half of that on two-term operands")
