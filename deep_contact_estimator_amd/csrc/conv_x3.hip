@@ -63,7 +63,7 @@ void conv_x3_pack_host(int l, const float* w, unsigned short* out)
 template <bool ZS, bool TAPS = false, int OUT = 0, bool PERMK = false, bool PERSIST = false, int NT = 3>
 __global__ __launch_bounds__(256, NT == 2 ? 3 : 2)
 void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems,
-                    LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr)
+                    LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr, const long long* __restrict__ src_row = nullptr)
 {   // TAPS (dce_conv_layer_taps, parity tests): every layer's output also goes to HBM in fp32, and so do the features.
     // OUT: 0 the features leave as three bf16 planes (fc_gemm_x3.hip's layout); 1 as (n, 4736) fp32 in feat32 (batches below
     // the split-bf16 fc.0 kernel's threshold, whose fc.0 runs on the fp32 kernels); 2 as (n, 4736) bf16, round-to-nearest-even,
@@ -77,6 +77,7 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
     static_assert(!PERSIST || (PERMK && !TAPS), "the persistent form has the register-only feature tail");
     static_assert(NT == 3 || (OUT == 2 && !TAPS), "two-term operands only where the features are rounded to bf16");
     constexpr int LDSB = NT * CX_PLANE;
+    if (src_row) src += *src_row * CH;                                 // online graph: the window start lives in device memory
     extern __shared__ __attribute__((aligned(16))) char cx_lds[];
     float x[1][38];
     float2 v[16];
@@ -403,38 +404,39 @@ hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const Con
 }
 
 // ... with (n, 4736) bf16 features out: the DCE_BF16_FC precision
-hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk, int terms)
+hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk, int terms,
+                               const long long* src_row)
 {
     if (n <= 0) return hipSuccess;
     if (terms == 2) {                                  // two-term operands (three MFMAs per product), three workgroups per CU
         constexpr int L2T = 2 * CX_PLANE;
         plan_note(permk ? "conv_x2_bf16_permk" : "conv_x2_bf16");
         if (permk) {
-            if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
-            else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+            if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
+            else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
         } else {
-            if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, false, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
-            else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, false, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+            if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, false, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
+            else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, false, false, 2>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
         }
         return hipGetLastError();
     }
 #if DCE_EXPERIMENTS
     if (permk == 2) {                                  // ... from persistent workgroups (measured 2-4 % slower: profiles/r4h_ab_conv_x3_persist.txt)
         plan_note("conv_x3_bf16_permk_persist");
-        if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
-        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+        if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
+        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
         return hipGetLastError();
     }
 #endif
     if (permk) {                                       // features in the K order t' * 128 + c, straight from the accumulators
         plan_note("conv_x3_bf16_permk");
-        if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
-        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+        if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
+        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
         return hipGetLastError();
     }
     plan_note("conv_x3_bf16");
-    if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
-    else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr);
+    if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
+    else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
     return hipGetLastError();
 }
 

@@ -70,6 +70,7 @@ Tuning tuning_from_env()
     t.x3_conv = num("DCE_X3_CONV", t.x3_conv ? 1 : 0) != 0;
     t.x3_conv_min = num("DCE_X3_CONV_MIN", t.x3_conv_min);
     t.x3_permk = num("DCE_X3_PERMK", t.x3_permk ? 1 : 0) != 0;
+    t.x3_bf16_min = num("DCE_X3_BF16_MIN", t.x3_bf16_min);
     t.x3_bf16_terms = num("DCE_X3_BF16_TERMS", t.x3_bf16_terms) == 2 ? 2 : 3;
     t.x3_persist = DCE_EXPERIMENTS && num("DCE_X3_PERSIST", t.x3_persist ? 1 : 0) != 0;
     t.x3_persist_min = num("DCE_X3_PERSIST_MIN", t.x3_persist_min);
@@ -167,13 +168,13 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
         // chip-filling batch: two windows per workgroup, a phase apart (conv_x3p.hip); its features -- and the fc.0 weights used
         // behind it -- are in the K order t' * 128 + c.  A tap of the features keeps the reference's flatten order (conv_x3.hip).
         const bool pair = c->tuning.x3_conv && c->tuning.x3_pair && c->winograd && !c->src_row_dev && !c->want_feat && n >= c->tuning.x3_pair_min;
-        const bool x3c = c->tuning.x3_conv && c->winograd && !c->src_row_dev && n >= c->tuning.x3_conv_min;      // conv_x3.hip
+        const bool x3c = c->tuning.x3_conv && c->winograd && n >= c->tuning.x3_bf16_min && (!c->src_row_dev || zscore);     // conv_x3.hip (online pushes: its z-score entry reads the window start from device memory)
         const bool permk = x3c && c->tuning.x3_permk && !c->want_feat && c->fc1w_bf16p != nullptr;                 // ... with its features in the K order t' * 128 + c
         { Timer t(c, 0);
           // from 128 windows the conv stack runs on three-term bf16 operands (conv_x3.hip: fp32-grade results at 1.27x the
           // fp32 Winograd kernel's rate), its features rounded to bf16 as the Winograd kernel's are; DCE_X3_CONV=0 switches back
           if (pair) HIP_TRY(c, launch_conv_x3p_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream));
-          else if (x3c) HIP_TRY(c, launch_conv_x3_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream, permk ? (c->tuning.x3_persist && n >= c->tuning.x3_persist_min ? 2 : 1) : 0, c->tuning.x3_bf16_terms));
+          else if (x3c) HIP_TRY(c, launch_conv_x3_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream, permk ? (c->tuning.x3_persist && n >= c->tuning.x3_persist_min ? 2 : 1) : 0, c->tuning.x3_bf16_terms, c->src_row_dev));
           else HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream, c->src_row_dev)); }
         { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, (pair || permk) ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
         if (fc23_fused_ok(n, 1)) {

@@ -39,6 +39,7 @@ struct Tuning {
     long long x3_conv_min = 128;                            // DCE_X3_CONV_MIN: from this many windows the mode's conv stack runs on conv_x3.hip also BELOW the fc.0 threshold (fp32 features out)
     bool x3_unfused = false;                                // DCE_X3_UNFUSED: fp32 features + split3 kernel instead of the conv kernel's three-plane output (A/B)
     bool x3_permk = true;                                   // DCE_X3_PERMK=0: conv_x3.hip's features go through LDS into the reference's flatten order (A/B) instead of straight out in the order t' * 128 + c
+    long long x3_bf16_min = 1;                              // DCE_X3_BF16_MIN: DCE_BF16_FC's conv stack runs on conv_x3.hip from this many windows (default: always -- one window per workgroup is also the fastest form at batch 1: 18.7 us against 20.8 for the fp32 quarter-window kernel and 62 for the two-window kernel the mode used below 128 windows)
     int x3_bf16_terms = 2;                                  // DCE_X3_BF16_TERMS=3: DCE_BF16_FC's conv stack on three-term operands (six MFMAs per product) as DCE_FP32_SPLIT's; default two terms (three MFMAs, ~17 significant bits ahead of the features' 8-bit rounding: same error against an fp64 evaluation, profiles/r4h_bf16_terms_audit.json; 308 -> 171 us per 4096 windows)
     bool x3_persist = false;                                // DCE_X3_PERSIST=1 (experiments build): conv_x3.hip as persistent workgroups (two per CU) that request the next window's samples a layer ahead; measured 2-4 % slower
     long long x3_persist_min = 1024;                        // DCE_X3_PERSIST_MIN: windows per launch from which they do
@@ -161,7 +162,7 @@ hipError_t init_conv_x3();
 //   permk: the features leave straight from the accumulators in the K order k' = t' * 128 + c (no LDS staging, no barriers); fc.0
 //   behind it then takes weights whose K axis is permuted the same way (fc_perm_k_host)
 hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st, int permk = 0);
-hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk = 0, int terms = 3);
+hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk = 0, int terms = 3, const long long* src_row = nullptr);
 hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st);
 hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3& pk, unsigned short* feat3, float* feat32,
                                const LayerTaps& taps, hipStream_t st);

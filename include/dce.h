@@ -61,8 +61,11 @@ typedef enum dce_status {
 
 typedef enum dce_precision {
     DCE_FP32            = 0,   /* fp32 MFMA everywhere (exact fp32 fmaf chains) -- the headline path */
-    DCE_BF16_FC         = 1,   /* bf16 operands (fp32 accumulate) on fc.0 / fc.3; the conv stack keeps fp32 results (from 128 windows per
-                                  call on three-term bf16 operands, csrc/conv_x3.hip, as in DCE_FP32_SPLIT; below that the fp32 kernels) */
+    DCE_BF16_FC         = 1,   /* bf16 operands (fp32 accumulate) on fc.0 / fc.3, whose inputs -- the features and h1 -- are rounded to bf16
+                                  (8 significant bits).  The conv stack in front of that rounding runs on the bf16 matrix pipe with every
+                                  operand as TWO bf16 terms (~17 significant bits, three MFMAs per product; csrc/conv_x3.hip, NT = 2) at
+                                  every batch size: the mode's error against an fp64 evaluation is that of its bf16 FC operands, with
+                                  two terms as with three (DCE_X3_BF16_TERMS=3; profiles/r4h_bf16_terms_audit.json) */
     DCE_FP32_SPLIT      = 2    /* fp32 results with the conv stack and fc.0 of chip-filling batches on the bf16 matrix pipe: every fp32
                                   operand enters as three bf16 terms (a = a1 + a2 + a3 exactly), six bf16 MFMAs per product, fp32
                                   accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; the conv stack from 128
@@ -70,10 +73,11 @@ typedef enum dce_precision {
 } dce_precision;
 /* Batch-size regimes.  DCE_FP32 gives a window the same bits whatever the size of the call it arrives in (one fixed summation tree in
  * every kernel family).  The two other precisions pick kernels by the number of windows in a launch (a call of more than max_batch
- * windows is several launches: the last one may fall into another regime): below 128 windows the DCE_FP32 kernels, from 128 the
- * three-term conv stack, DCE_FP32_SPLIT from 2817 the split fc.0 -- so the same window may differ in its last bits between a small and
- * a large call (fp32_split: both within the fp32 tolerance of the reference, <= 2e-5 of the largest logit apart; bf16_fc: a feature
- * within fp32 noise of a bf16 rounding boundary may round the other way, <= 2e-2 of the largest logit).  Tested:
+ * windows is several launches: the last one may fall into another regime).  DCE_FP32_SPLIT: below 128 windows the DCE_FP32 kernels, from
+ * 128 the three-term conv stack, from 2817 the split fc.0 -- the same window may differ in its last bits between a small and a large call
+ * (both within the fp32 tolerance of the reference, <= 2e-5 of the largest logit apart).  DCE_BF16_FC: one conv kernel at every size, FC
+ * kernels by size (different fp32 summation orders: an h1 value at a bf16 rounding boundary may round the other way, <= 2e-2 of the
+ * largest logit).  Tested:
  * tests/test_round4_gpu.py::test_batch_size_regimes_stay_within_the_mode_tolerance.  A caller that needs call-size invariance uses DCE_FP32. */
 
 typedef struct dce_ctx dce_ctx;   /* opaque; owns device weights, scratch and (by default) a stream */

@@ -512,7 +512,8 @@ def test_max_batch_one(orc):
 
 def test_online_mode_bf16_fc():
     """Online pushes in the bf16-FC precision mode reproduce that mode's own sequence results bit for
-    bit (two-window conv kernel with the device-side window start, bf16 64x64 GEMM tiles)."""
+    bit (the mode's conv stack -- conv_x3.hip on two-term operands, one workgroup per window -- with the device-side window start,
+    bf16 64x64 GEMM tiles)."""
     from deep_contact_estimator_amd import contact_cnn, synth
     m = contact_cnn(device=0, max_batch=256, precision="bf16_fc")
     m.load_state_dict(synth.make_state_dict(1, "uniform"))
