@@ -34,6 +34,9 @@
 #ifndef PH_TRACE
 #define PH_TRACE 0
 #endif
+#if defined(PH_EXP) && !DCE_EXPERIMENTS
+#error "PH_EXP timing probes give wrong results: experiments build only"
+#endif
 #ifndef PH_FOLD_MFMA
 #define PH_FOLD_MFMA 0       // 1: the summation tree's fold clears the accumulators with an MFMA of zeros instead of 16 v_mov per tile
                              // (measured: fc.0 533.1 vs 532.1 us, no gain -- the fold's cost is the 32 v_pk_add_f32, which wait for
@@ -178,8 +181,15 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
         if (j < Cfg::NA && m0 + grow >= M) grow = M - 1 - m0;   // rows past M re-read the last one (never stored)
         voff[j] = (unsigned)(grow * rowb + 16 * col);
     }
+#if defined(PH_EXP) && (PH_EXP & 1)
+    // timing probe (wrong results; needs DCE_EXPERIMENTS): every workgroup reads the SAME A and W rows -- 3.6 MB, L2-resident after
+    // the first launch -- so that the operand loads see L2-hit latency instead of the fabric's
+    const char* sA = static_cast<const char*>(Av);
+    const char* sW = static_cast<const char*>(Wv);
+#else
     const char* sA = static_cast<const char*>(Av) + (size_t)m0 * rowb;
     const char* sW = static_cast<const char*>(Wv) + (size_t)n0 * rowb;
+#endif
     const unsigned lds_wave = lds_addr(smem) + wid * 1024;     // chunk `wid` of buffer 0
 
     // ---- fragment reads: lane (i, h) reads row (wave corner + 32 a + i), logical 16-byte column 2 kq + h
