@@ -42,7 +42,7 @@ Tuning tuning_from_env()
     Tuning t;
     auto num = [](const char* k, long long dflt) { const char* e = getenv(k); return e ? atoll(e) : dflt; };
     auto off = [](const char* k) { const char* e = getenv(k); return e && atoi(e) == 0; };
-    if (const char* e = getenv("DCE_GEMM")) { t.gemm_tile = strcmp(e, "tile") == 0; t.gemm_lockstep = strcmp(e, "lockstep") == 0; }
+    if (const char* e = getenv("DCE_GEMM")) { t.gemm_tile = strcmp(e, "tile") == 0; t.gemm_lockstep = strcmp(e, "lockstep") == 0; t.gemm_pipe = DCE_EXPERIMENTS && strcmp(e, "pipe") == 0; }
     t.phased_min_tiles = (int)num("DCE_PHASED_MIN_TILES", t.phased_min_tiles);
     t.phased_min_tiles1 = (int)num("DCE_PHASED_MIN_TILES1", t.phased_min_tiles1);
     t.phased_min = (int)num("DCE_GEMM_PHASED_MIN", t.phased_min);

@@ -440,6 +440,201 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
     else store_tile(std::false_type{});
 }
 
+
+#if DCE_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------------------------
+// fc_gemm_pipe_kernel -- the bf16 256 x 128 tile WITHOUT workgroup barriers in its K loop (round 4; DCE_GEMM=pipe).
+// The phased schedule above hands the matrix pipe from one wave group to the other twice per K-tile; at fp32 rate that hand-over is
+// 6 % of a phase, at bf16 rate (a 64-k K-tile = 512 cycles of MFMAs per wave) it is a third (profiles/r3c_trace_gemm.txt), and the
+// kernel does not wait for memory (profiles/r4i_gemm_probes.txt).  Here all eight waves run the same loop over 32-k K-tiles (64-byte
+// rows, 24 KB per tile, SIX LDS buffers), each wave with two register sets of fragments (tile u multiplies while tile u+1 is read),
+// and what the barriers guaranteed is tracked per LDS buffer by two counters in LDS that only ever count up:
+//     landed[b] : waves whose share of the tile now in buffer b has arrived (s_waitcnt vmcnt, then ds_add)    -> RAW, before reading
+//     freed[b]  : waves whose fragment reads of the tile in buffer b have returned (lgkmcnt(0), then ds_add)  -> WAR, before refilling
+// A wave that finds a counter short spins on it (ds_read + s_sleep) with half of the tile's MFMAs already issued and with the other
+// wave of its SIMD free to go on: nobody waits for the slowest wave at a fixed point of every tile.  Step u of a wave (fragments of
+// tile u in `cur`, requested during step u-1):
+//     S0  lgkmcnt(0): cur has arrived (= this wave is through with buffer u % 6)          -> freed[u % 6] += 1
+//     S1  the four MFMAs of k-quarter 0
+//     S2  wait freed[(u - LAG) % 6] (posted LAG + 1/2 tiles ago)  -> LDS-DMA of tile u + 6 - LAG into that buffer
+//         vmcnt: own share of tile u+2 has landed (issued 4 - LAG tiles ago)               -> landed[(u+2) % 6] += 1
+//         wait landed[(u+1) % 6] (posted one tile ago)
+//     S3  the four MFMAs of k-quarter 1, the eight fragment reads of tile u+1 dealt out between them
+// MEASURED (profiles/r4j_gemm_pipe.txt): correct and bit-equal to the phased kernel only with the own-share wait one tile more
+// conservative than the instruction count says (with "all but the 4 newest tiles" the results are wrong and differ from run to run:
+// on this part a satisfied vmcnt does not yet make an LDS-DMA's bytes visible to another wave's ds_read -- the phased kernel has a
+// barrier's worth of time between the two), and SLOWER than the phased kernel either way: 103-116 us against 68 for fc.0.  Per 32-k
+// tile a wave has 256 cycles of MFMAs and two LDS round trips of polling; the polls of the two waves of a SIMD do not hide behind each
+// other's MFMAs.  Experiments build only.
+#ifndef PP_LAG
+#define PP_LAG 0
+#endif
+template <bool OUT_BF16>
+__global__ __launch_bounds__(512, 2)
+void fc_gemm_pipe_kernel(const void* __restrict__ Av, const void* __restrict__ Wv, const float* __restrict__ bias, void* __restrict__ Cv,
+                         int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
+{
+    constexpr int BM = 256, BN = 128, ROWB = 64, TILE = (BM + BN) * ROWB, NBUF = 6, NG = 3, KQ = 2, TM = 2, TN = 2, LAG = PP_LAG;
+    static_assert(NBUF * TILE + 64 <= 160 * 1024 && (LAG == 0 || LAG == 1), "");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, li = bid >> 3;
+    const int sid = (li >> 5) * 8 + xcd;
+    const int within = li & 31;
+    const int sn = 1 << sn_log2, sm = 32 >> sn_log2;
+    const int nsn = ntiles >> sn_log2;
+    const int tm = (sid / nsn) * sm + (within >> sn_log2);
+    const int tn = (sid % nsn) * sn + (within & (sn - 1));
+    if (tm >= mtiles) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wid & 3) * 64, wn = (wid >> 2) * 64;
+    const int i = lane & 31, h = lane >> 5;
+
+    // global -> LDS: 1 KB chunk c = 16 rows x 64 B of the stacked tile (rows 0..255 A, 256..383 W); wave wid brings chunks wid, wid + 8
+    // (A) and wid + 16 (W); lane l fills slot l % 4 of row 16 c + l / 4 with the logical 16-byte column slot ^ swz(row), swz(r) = (r >> 2) & 3
+    const size_t rowb = (size_t)K * 2;
+    unsigned voff[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int r = 16 * (wid + 8 * j) + lane / 4;
+        const int col = (lane % 4) ^ ((r >> 2) & 3);
+        const int grow = j < 2 ? r : r - BM;             // (the launcher sends only whole tiles here: M % 256 == 0)
+        voff[j] = (unsigned)(grow * rowb + 16 * col);
+    }
+    const char* sA = static_cast<const char*>(Av) + (size_t)m0 * rowb;
+    const char* sW = static_cast<const char*>(Wv) + (size_t)n0 * rowb;
+    const unsigned lds_wave = lds_addr(smem) + wid * 1024;
+    const unsigned cnt = lds_addr(smem) + NBUF * TILE;                  // freed[6] at +0, landed[6] at +32
+    if (tid < 16) reinterpret_cast<unsigned*>(smem + NBUF * TILE)[tid] = 0u;
+    __syncthreads();
+
+    // fragment reads: lane (i, h) reads row (wave corner + 32 a + i), logical column 2 kq + h: k = 16 kq + 8 h + (0..7)
+    const int sw = (i >> 2) & 3;                          // wave corners are multiples of 32 rows: swz(row) = swz(i)
+    unsigned pa[KQ], pb[KQ];
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+        const int fo = 16 * ((2 * kq + h) ^ sw);
+        pa[kq] = (wm + i) * ROWB + fo;
+        pb[kq] = (BM + wn + i) * ROWB + fo;
+        asm volatile("" : "+v"(pa[kq]), "+v"(pb[kq]));
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto cnt_add = [&](unsigned addr) {
+        if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(1u) : "memory");
+    };
+    auto cnt_wait = [&](unsigned addr, unsigned want) {
+        for (;;) {
+            unsigned v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= want) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto vm_wait = [&](int newer) {                       // at most `newer` tiles' worth of this wave's LDS-DMA still in flight
+        newer = newer > 0 ? newer - 1 : 0;              // one tile more than the count says: see MEASURED above
+        if (newer >= 4)      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (newer == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (newer == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto load_frags = [&](auto bufc, float4 (&af)[KQ][TM], float4 (&bf)[KQ][TN]) {
+        constexpr int b = decltype(bufc)::value;
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[kq][a] = *reinterpret_cast<const float4*>(smem + b * TILE + pa[kq] + a * 32 * ROWB);
+#pragma unroll
+            for (int c = 0; c < TN; ++c) bf[kq][c] = *reinterpret_cast<const float4*>(smem + b * TILE + pb[kq] + c * 32 * ROWB);
+        }
+    };
+    auto math_q = [&](const float4 (&af)[KQ][TM], const float4 (&bf)[KQ][TN], int kq) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kq][a]), __builtin_bit_cast(bf16x8, bf[kq][b]), acc[a][b], 0, 0, 0);
+    };
+
+    const int KT = (int)(rowb / ROWB);                    // >= 8 (checked by the launcher)
+    float4 afA[KQ][TM], bfA[KQ][TN], afB[KQ][TM], bfB[KQ][TN];
+#pragma unroll
+    for (int u = 0; u < NBUF - LAG; ++u) issue_tile<2, 1>(lds_wave + u * TILE, sA + u * ROWB, sW + u * ROWB, voff);
+    vm_wait(NBUF - LAG - 2);                              // tiles 0 and 1 of this wave have landed
+    cnt_add(cnt + 32);
+    cnt_add(cnt + 36);
+    cnt_wait(cnt + 32, 8u);
+    load_frags(std::integral_constant<int, 0>{}, afA, bfA);
+
+    auto step = [&](int u, auto bufc, const float4 (&afC)[KQ][TM], const float4 (&bfC)[KQ][TN], float4 (&afN)[KQ][TM], float4 (&bfN)[KQ][TN]) {
+        constexpr int buf = decltype(bufc)::value, nb = (buf + 1) % NBUF, b2 = (buf + 2) % NBUF, fb = (buf + NBUF - LAG) % NBUF;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   // S0
+        cnt_add(cnt + 4 * buf);
+        __builtin_amdgcn_sched_barrier(0);
+        math_q(afC, bfC, 0);                                                               // S1
+        __builtin_amdgcn_sched_barrier(0);
+        const int last = u + NBUF - LAG < KT ? u + NBUF - LAG : KT - 1;                    // newest tile in flight after this step's issue
+        if (u >= LAG && u + NBUF - LAG < KT) {                                             // S2
+            cnt_wait(cnt + 4 * fb, 8u * (unsigned)((u - LAG) / NBUF + 1));
+            const size_t ko = (size_t)(u + NBUF - LAG) * ROWB;
+            issue_tile<2, 1>(lds_wave + fb * TILE, sA + ko, sW + ko, voff);
+        }
+        if (u + 2 < KT) {
+            vm_wait(last - (u + 2));
+            cnt_add(cnt + 32 + 4 * b2);
+        }
+        if (u + 1 < KT) {
+            cnt_wait(cnt + 32 + 4 * nb, 8u * (unsigned)((u + 1) / NBUF + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(std::integral_constant<int, nb>{}, afN, bfN);                       // S3
+            math_q(afC, bfC, 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            math_q(afC, bfC, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int u = 0; u < KT; u += 6) {
+        step(u, std::integral_constant<int, 0>{}, afA, bfA, afB, bfB);
+        if (u + 1 < KT) step(u + 1, std::integral_constant<int, 1>{}, afB, bfB, afA, bfA);
+        if (u + 2 < KT) step(u + 2, std::integral_constant<int, 2>{}, afA, bfA, afB, bfB);
+        if (u + 3 < KT) step(u + 3, std::integral_constant<int, 3>{}, afB, bfB, afA, bfA);
+        if (u + 4 < KT) step(u + 4, std::integral_constant<int, 4>{}, afA, bfA, afB, bfB);
+        if (u + 5 < KT) step(u + 5, std::integral_constant<int, 5>{}, afB, bfB, afA, bfA);
+    }
+
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn + 32 * b + i;
+        const float bv = bias[col];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[a][b][r] + bv;
+                if (relu) v = v < 0.f ? 0.f : v;
+                if constexpr (OUT_BF16) static_cast<unsigned short*>(Cv)[(size_t)row * N + col] = f32_to_bf16(v);
+                else static_cast<float*>(Cv)[(size_t)row * N + col] = v;
+            }
+    }
+}
+
+#endif  // DCE_EXPERIMENTS
+
 // tile 2 = 256 x 128 with 128-byte K-tiles; tile 1 = 128 x 64 with 256-byte K-tiles (same 48 KB per K-tile,
 // twice the MFMAs per phase that 128-byte K-tiles would give the small wave tile)
 template <int T> struct PhTile;
@@ -476,6 +671,10 @@ template <bool BF16, bool OUT_BF16, int T> static hipError_t grant_phased()
 hipError_t init_fc_gemm_phased()
 {
     hipError_t e;
+#if DCE_EXPERIMENTS
+    for (const void* k : {reinterpret_cast<const void*>(&fc_gemm_pipe_kernel<true>), reinterpret_cast<const void*>(&fc_gemm_pipe_kernel<false>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 384 * 64 + 64)) != hipSuccess) return e;
+#endif
     for (const void* k : {
 #if DCE_EXPERIMENTS
                           reinterpret_cast<const void*>(&fc_gemm_phased_kernel<false, false, 1, 1, 256, true, true>),
@@ -541,6 +740,15 @@ static hipError_t launch_phased_cfg(const void* A, const void* W, const float* b
     const int sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
+#if DCE_EXPERIMENTS
+    if constexpr (BF16 && T == 2) {
+        if (tune().gemm_pipe && !use_lockstep(true) && M % 256 == 0 && K % 32 == 0 && K >= 256) {       // no workgroup barriers in the K loop (fc_gemm_pipe_kernel; whole tiles only)
+            plan_note("fc_pipe256x128");
+            hipLaunchKernelGGL((fc_gemm_pipe_kernel<OUT_BF16>), dim3(grid), dim3(512), 6 * 384 * 64 + 64, st, A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+            return hipGetLastError();
+        }
+    }
+#endif
     plan_note(use_lockstep(BF16) ? (T == 2 ? "fc_lockstep256x128" : "fc_lockstep128x64") : (T == 2 ? "fc_phased256x128" : "fc_phased128x64"));
 #if DCE_EXPERIMENTS
     if (use_lockstep(BF16))

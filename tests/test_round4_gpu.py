@@ -103,6 +103,24 @@ def test_bf16_fc_conv_stack_on_two_term_operands(n, orc):
 
 
 @pytest.mark.experiments
+def test_barrier_free_bf16_gemm_equals_the_phased_kernel():
+    """fc_gemm_pipe_kernel (DCE_GEMM=pipe, experiments build: LDS counters instead of workgroup barriers in the K loop; measured
+    slower, profiles/r4j_gemm_pipe.txt) walks K in the same 16-k blocks as the phased kernel: the same bytes, on every repeat."""
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    a = _model("bf16_fc", env={"DCE_GEMM": "pipe"}); a.load_state_dict(sd).eval()
+    b = _model("bf16_fc", env={"DCE_GEMM": "phased"}); b.load_state_dict(sd).eval()
+    for n in (4096, 8192):
+        x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
+        ra, rb = a.predict(x), b.predict(x)
+        assert "fc_pipe256x128" in a.last_plan() and "fc_phased256x128" in b.last_plan(), (a.last_plan(), b.last_plan())
+        assert np.array_equal(ra["logits"], rb["logits"])
+        for _ in range(20):
+            assert np.array_equal(a.predict(x)["logits"], ra["logits"])
+    a.close(); b.close()
+
+
+@pytest.mark.experiments
 @pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
 def test_persistent_conv_stack_equals_one_workgroup_per_window(precision):
     """conv_x3.hip's persistent form (DCE_X3_PERSIST=1, experiments build: two workgroups per CU walk the windows, the next window's
