@@ -462,8 +462,8 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
 //     S3  the four MFMAs of k-quarter 1, the eight fragment reads of tile u+1 dealt out between them
 // MEASURED (profiles/r4j_gemm_pipe.txt): correct and bit-equal to the phased kernel only with the own-share wait one tile more
 // conservative than the instruction count says (with "all but the 4 newest tiles" the results are wrong and differ from run to run:
-// on this part a satisfied vmcnt does not yet make an LDS-DMA's bytes visible to another wave's ds_read -- the phased kernel has a
-// barrier's worth of time between the two), and SLOWER than the phased kernel either way: 103-116 us against 68 for fc.0.  Per 32-k
+// the counter protocol re-derives clean, so the suspicion -- not proven -- is that a satisfied vmcnt is not yet visibility of an
+// LDS-DMA's bytes to another wave's ds_read; the phased kernel has a workgroup barrier between the two), and SLOWER than the phased kernel either way: 103-116 us against 68 for fc.0.  Per 32-k
 // tile a wave has 256 cycles of MFMAs and two LDS round trips of polling; the polls of the two waves of a SIMD do not hide behind each
 // other's MFMAs.  Experiments build only.
 #ifndef PP_LAG
