@@ -397,6 +397,30 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
         "path_frac_of_roof": (B * steps / dt) / path_roof(precision),
     }
     m.close()
+    if precision == "bf16_fc" and conv_terms(precision) == 3:
+        # the same step with the conv stack on THREE-term operands (fp32-grade features in front of their rounding to bf16: the
+        # round-3 form of the mode), so that the line shows what the two-term stack buys and what it changes
+        old = os.environ.get("DCE_X3_BF16_TERMS")
+        os.environ["DCE_X3_BF16_TERMS"] = "3"
+        try:
+            m3 = contact_cnn(device=dev.index, max_batch=B, precision=precision)
+            m3.load_state_dict(sd).eval()
+            settle(torch, lambda: m3.predict(windows), min(settle_s, 0.5))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o3 = run_steps(m3, windows, steps)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            f3 = int((o3["pred"] != ref_out["pred"]).sum().item())
+            res["three_term_conv_stack"] = {
+                "switch": "DCE_X3_BF16_TERMS=3", "windows_per_s": B * steps / dt3, "ms_per_step": dt3 / steps * 1e3, "plan": m3.last_plan(),
+                "vs_fp32_same_input": {"max_abs_dlogit": float((o3["logits"] - lr).abs().max().item()), "argmax_flips": f3},
+                "vs_two_term_same_input": {"max_abs_dlogit": float((o3["logits"] - lg).abs().max().item()),
+                                           "argmax_differences": int((o3["pred"] != out["pred"]).sum().item())}}
+            m3.close()
+        finally:
+            if old is None: os.environ.pop("DCE_X3_BF16_TERMS", None)
+            else: os.environ["DCE_X3_BF16_TERMS"] = old
     # BASELINE configs[2] in this precision too: the 1e6-window sequence, HBM-resident, max_batch 32768 (median of 3 after a warm call)
     ms = contact_cnn(device=dev.index, max_batch=32768, precision=precision)
     ms.load_state_dict(sd).eval()
