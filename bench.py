@@ -703,11 +703,11 @@ def main():
             kd = kernels[dom]
             traffic, traffic_src, traffic_stale = None, None, None
             pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc_path) and args.precision == "fp32":      # the counters were collected on the fp32 kernels
+            if os.path.exists(pmc_path) and args.precision in ("fp32", "bf16_fc"):      # counters exist for the fp32 kernels and for the bf16-FC step's
                 try:
                     from deep_contact_estimator_amd import build as dce_build
                     pmc = json.load(open(pmc_path))
-                    ent = pmc.get(dom, {})
+                    ent = pmc.get(dom, {}) if args.precision == "fp32" else pmc.get({"conv_stack": "conv_x3", "fc1_gemm": "fc1_gemm_bf16", "fc2_gemm": "fc2_gemm_bf16"}.get(dom, dom) + "@bf16_fc", {})
                     traffic = ent.get("hbm_bytes_per_launch")
                     # stale = the counters were collected on a library built from other sources than the one timed here
                     prof_hash, here_hash = pmc.get("_meta", {}).get("source_hash"), dce_build.built_hash()

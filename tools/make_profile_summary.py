@@ -74,7 +74,7 @@ def main(tag):
     # bf16-FC mode: per-CU-cycle rates of the GEMMs (GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ counters over all 256 CUs x 4 SIMDs
     # as the fp32 table's MFMA-busy normalisation has it)
     b16 = {}
-    for part in ("bf16sq", "bf16lds", "bf16tcc"):
+    for part in ("bf16sq", "bf16lds", "bf16tcc", "bf16fetch", "bf16write"):
         p = os.path.join(out, f"{tag}_pmc_{part}", f"{tag}_counter_collection.csv")
         if os.path.exists(p):
             for k, v in pmc_summary.main([p]).items():
@@ -93,6 +93,19 @@ def main(tag):
             hit = c.get("TCC_HIT", 0) / max(c.get("TCC_HIT", 0) + c.get("TCC_MISS", 0), 1)
             lines.append(f"| {k} | {busy:.3f} | {lds:.3f} | {c.get('SQ_LDS_BANK_CONFLICT', 0):.3g} / {c.get('SQ_LDS_IDX_ACTIVE', 0):.3g} | "
                          f"{c.get('SQ_INSTS_LDS', 0):.3g} | {hit:.3f} | {c.get('TCC_REQ', 0):.3g} |")
+    # HBM traffic of the bf16-FC step's kernels against their algorithmic bytes (windows in + bf16 features out; bf16 features + bf16 W1 in, bf16 h1
+    # out; bf16 h1 + bf16 W2 + W3 in, chunk sums out)
+    algo16 = {"conv_x3": (150 * 54 * 4 + 4736 * 2) * B + 2 * (96768 * 3) + 4 * 384, "fc1_gemm_bf16": (4736 * 2 + 2048 * 2) * B + 2 * 2048 * 4736 + 4 * 2048,
+              "fc2_gemm_bf16": (2048 * 2 + 8 * 64) * B + 2 * 512 * 2048 + 4 * (512 + 16 * 512)}
+    if any("FETCH_SIZE" in c for c in b16.values()):
+        lines += ["", "| kernel (bf16-FC step) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes/launch (2*FETCH+WRITE)*1024 | algorithmic bytes/launch | ratio |", "|---|---|---|---|---|---|"]
+        for k, algo in algo16.items():
+            c = b16.get(k)
+            if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                continue
+            hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+            lines.append(f"| {k} | {c['FETCH_SIZE']:.0f} | {c['WRITE_SIZE']:.0f} | {hbm / 1e6:.1f} MB | {algo / 1e6:.1f} MB | {hbm / algo:.2f} |")
+            latest[k + "@bf16_fc"] = {"hbm_bytes_per_launch": hbm, "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"], "algorithmic_bytes_per_launch": algo, "profile": tag}
     # the build these counters were taken on (tools/profile_gpu.sh records the hash of the .so's sources on the box):
     # bench.py marks roofline.traffic stale when the library it times was built from other sources
     hp = os.path.join(out, f"{tag}_source_hash.txt")

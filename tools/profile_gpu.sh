@@ -21,5 +21,8 @@ BB="$B --precision bf16_fc"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_bf16sq -o ${TAG} -- $BB > $OUT/${TAG}_pmc_bf16sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_bf16lds -o ${TAG} -- $BB > $OUT/${TAG}_pmc_bf16lds.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT TCC_MISS TCC_REQ TCC_READ --output-format csv -d $OUT/${TAG}_pmc_bf16tcc -o ${TAG} -- $BB > $OUT/${TAG}_pmc_bf16tcc.log 2>&1
+# ... and what they (and the mode's conv stack) move through HBM
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_bf16fetch -o ${TAG} -- $BB > $OUT/${TAG}_pmc_bf16fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_bf16write -o ${TAG} -- $BB > $OUT/${TAG}_pmc_bf16write.log 2>&1
 find $OUT -name "${TAG}*" -type f | head -40
 for f in $OUT/${TAG}_*.log; do echo "== $f"; grep -E '"metric"|rror' $f | cut -c1-300; done
