@@ -678,7 +678,7 @@ def main():
             "metric": METRIC, "value": wps, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16_fc": "f32 conv (three-term bf16 operands, f32 accumulate) + bf16 FC (f32 accumulate)",
+            "dtype": {"fp32": "f32", "bf16_fc": "bf16 FC operands (f32 accumulate); conv stack on two-term bf16 operands (~17 bits, f32 accumulate) in front of the features' rounding to bf16",
                       "fp32_split": "f32 (conv stack and fc.0: f32 operands as three bf16 terms on bf16 MFMA, f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: {B} pre-normalised windows (B,150,54) fp32 per GPU per step, "
