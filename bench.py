@@ -335,11 +335,11 @@ def extra_small_batches(torch, model, windows, sizes=(1, 30, 64, 256, 512, 1024)
                         "per workgroup <= 256)", "batches": res}
 
 
-def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000):
+def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000, precision="fp32"):
     """SURVEY 8(f) rank 4 / the reference's README.md:67-83: push one (54,) host sample, get one estimate back (dce_online_push:
     sample in the kernel arguments / pinned memory, the newest window through the small-batch kernels, result polled from pinned
     memory).  Per-sample latency through the Python binding, plain launches."""
-    m = contact_cnn(device=dev.index, max_batch=64)
+    m = contact_cnn(device=dev.index, max_batch=64, precision=precision)
     m.load_state_dict(sd).eval()
     m.online_reset()
     pushes = max(min(pushes, seq_np.shape[0] - 350), 0)
@@ -396,6 +396,11 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
         "path_roof_windows_per_s": path_roof(precision),
         "path_frac_of_roof": (B * steps / dt) / path_roof(precision),
     }
+    if precision == "bf16_fc":
+        # the reference's shipped batch sizes in this precision: its conv stack is one workgroup per window at every size, fc.0 / fc.3
+        # stream their bf16 weights past up to 64 windows (fc_stream_bf16.hip)
+        sb = extra_small_batches(torch, m, windows, sizes=(1, 30, 64, 256, 1024))
+        res["small_batches"] = {"workload": "model.predict on b pre-normalised device-resident windows in this precision", "batches": sb["batches"]}
     m.close()
     if precision == "bf16_fc" and conv_terms(precision) == 3:
         # the same step with the conv stack on THREE-term operands (fp32-grade features in front of their rounding to bf16: the
@@ -784,6 +789,7 @@ def main():
                 "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s),
                 "fp32_split": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s, precision="fp32_split"),
             }
+            res["extra"]["bf16_fc"]["online_push"] = extra_online(contact_cnn, sd, dev, seq_np, pushes=1000, precision="bf16_fc")
     if rank == 0:
         if world == 1 and not multi and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, windows.cpu().numpy(), seq_np, out["logits"].cpu().numpy(),

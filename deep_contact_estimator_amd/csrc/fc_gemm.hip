@@ -502,6 +502,7 @@ hipError_t launch_fc_gemm_bf16(const void* A, const void* W, const float* bias, 
     if (M <= 0) return hipSuccess;
     if (N % 128 || K % 64 || M > (1 << 30)) return hipErrorInvalidValue;
     if (fc_gemm_phased_ok(M, N, K, 1)) return launch_fc_gemm_phased(A, W, bias, C, 1, out_bf16, M, N, K, relu, st);
+    if (tune().bf16_stream && fc_stream_bf16_ok(M, N, K)) return launch_fc_stream_bf16(A, W, bias, C, out_bf16, M, N, K, relu, st);
     const int64_t big_blocks = ((M + 127) / 128) * (N / 128);
     if (big_blocks >= 384)
         return out_bf16 ? launch_gemm_cfg<2, 2, true, true>(A, W, bias, C, M, N, K, relu, st)

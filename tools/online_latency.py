@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def child():
     from deep_contact_estimator_amd import contact_cnn, synth
-    m = contact_cnn(device=0, max_batch=64); m.load_state_dict(synth.make_state_dict(1, "uniform"))
+    m = contact_cnn(device=0, max_batch=64, precision=os.environ.get("DCE_LAT_PRECISION", "fp32")); m.load_state_dict(synth.make_state_dict(1, "uniform"))
     seq = synth.make_sequence(150 + 6000, 5).astype(np.float32)
     m.online_reset()
     for t in range(400): m.online_push(seq[t])
