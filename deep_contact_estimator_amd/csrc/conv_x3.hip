@@ -3,7 +3,7 @@
 // operand -- activations and weights -- enters the MFMAs as THREE bf16 terms (a = a1 + a2 + a3 exactly), six bf16 x bf16
 // MFMAs per product, fp32 accumulate (fc_gemm_x3.hip has the arithmetic).  Used by the DCE_FP32_SPLIT precision from 128 windows per
 // call (features out as three bf16 planes for fc_gemm_x3.hip, or as fp32 below that kernel's threshold) and by DCE_BF16_FC (features
-// out rounded to bf16: the first term of the last split); never by the default DCE_FP32 precision.
+// out rounded to bf16: the first term of the last split; on two-term operands, see NT = 2 below); never by the default DCE_FP32 precision.
 //
 // Why not Winograd here: its input transform would have to produce three-term operands on the fly (six more VALU
 // operations per transformed value, on a kernel that is already bound by what it issues between MFMAs).  In the direct form
@@ -23,6 +23,14 @@
 // the fragments of step s+1 are requested before the MFMAs of step s.  Write-back (in place, between two barriers; the bias
 // is the accumulators' initial value): ReLU, MaxPool (neighbouring columns sit in neighbouring lanes: one DPP quad_perm), split
 // into the three terms (v_cvt_pk_bf16_f32), 8-byte stores.  conv4 + pool go through LDS once more and leave as 16-byte stores.
+//
+// NT = 2 (round 4; DCE_BF16_FC only, at every batch size and in the online pushes; plan conv_x2_bf16*): the same kernel on TWO terms per
+// operand -- a1 b1 + a1 b2 + a2 b1, three MFMAs per product, ~17 significant bits in front of features that leave rounded to bf16 (8 bits).
+// The third plane is neither written nor read (the packed weights keep theirs, the kernel skips it): 42 KB of LDS and 146 registers
+// -> THREE workgroups per CU, i.e. three independent waves per SIMD to cover each other's prologues and write-backs: 170 us per 4096
+// windows against 308 for NT = 3 in the same mode, 0.84 of the matrix pipe while workgroups are resident (the board's ceiling for a
+// dense bf16 stream), HBM traffic 1.02 x algorithmic; the mode's error against an fp64 evaluation is the same with two terms and with
+// three (profiles/r4h_bf16_terms_audit.json).  DCE_FP32_SPLIT keeps NT = 3: its contract is the fp32 tolerance.
 #include <cfloat>
 #include <cstring>
 #include <type_traits>
