@@ -30,7 +30,7 @@ struct Tuning {
     int phased_sn = 3;                                      // DCE_PHASED_SN: log2 of the super-tile's N extent
     int fc23_mode = 0;                                      // DCE_FC23=split (1) | always (2)
     bool gemm_peel = true, conv_peel = true;                // DCE_GEMM_PEEL=0, DCE_CONV_PEEL=0
-    bool bf16_stream = true;                                // DCE_BF16_STREAM=0: DCE_BF16_FC's fc.0 / fc.3 at <= 64 windows on the 64 x 64 tile GEMM (44 + 21 us per call) instead of fc_stream_bf16.hip
+    bool bf16_stream = true;                                // DCE_BF16_STREAM=0: DCE_BF16_FC's fc.0 / fc.3 at <= 256 windows on the 64 x 64 tile GEMM (44 + 21 us per call) instead of fc_stream_bf16.hip
     bool gemm_small_deep = true;                            // DCE_GEMM_SMALL=0
     long long split_min = 9, split_max = 64;                 // DCE_SPLIT_MIN / DCE_SPLIT_MAX: windows served by the four-range MFMA kernel (fc_gemm_split.hip)
     long long chain_min = 9, chain_max = 640, chain_max3 = 2048, chain_bn16_max = 64;   // DCE_CHAIN_*
@@ -182,7 +182,7 @@ void       fc_perm_k_host(const float* w, size_t rows, float* out);
 // LDS-DMA staging, two wave groups one phase apart; fp32 (bit-identical to the tile kernels: same K order) and
 // bf16.  launch_fc_gemm / launch_fc_gemm_bf16 dispatch here when fc_gemm_phased_ok(M, N, K, bf16).
 hipError_t init_fc_gemm_phased();
-// fc_stream_bf16.hip: fc.0 / fc.3 of DCE_BF16_FC for calls of up to 64 windows (weights streamed past the activations, eight waves deal the K-steps)
+// fc_stream_bf16.hip: fc.0 / fc.3 of DCE_BF16_FC for calls of up to 256 windows (weights streamed past the activations, eight waves deal the K-steps)
 bool fc_stream_bf16_ok(int64_t M, int N, int K);
 hipError_t launch_fc_stream_bf16(const void* A, const void* W, const float* bias, void* C, int out_bf16, int64_t M, int N, int K, int relu, hipStream_t st);
 bool       fc_gemm_phased_ok(int64_t M, int N, int K, int bf16);

@@ -1,13 +1,15 @@
-// fc_stream_bf16.hip -- fc.0 / fc.3 of the DCE_BF16_FC precision for calls of up to 64 windows (reference src/contact_cnn.py:48-54:
+// fc_stream_bf16.hip -- fc.0 / fc.3 of the DCE_BF16_FC precision for calls of up to 256 windows (reference src/contact_cnn.py:48-54:
 // Linear + ReLU, twice; BASELINE configs[4] at the reference's shipped batch sizes 1 and 30):
 //     C[M,N] = act(A[M,K] W[N,K]^T + bias),  A, W bf16, K-contiguous,  fp32 accumulate,  C bf16 (h1) or fp32 (h2)
 // At these sizes the layer is the stream of its weights (fc.0: 19.4 MB) past a handful of activation rows; the 64 x 64 tile GEMM the
-// mode used here put 32 workgroups on that stream (44 us + 21 us per call whatever the batch; it still serves 65 .. 511 windows, where
-// a sixteen-block form of this kernel measured slower: 50 us at 127 windows).  Here one workgroup owns 16 output
+// mode used here put 32 workgroups on that stream (44 us + 21 us per call whatever the batch; it still serves 257 .. 511 windows).
+// Here one workgroup owns 16 output
 // features and its eight waves deal the K-steps (32 k) out among themselves: per step a lane loads 16 bytes of one weight row
 // (operand A of v_mfma_f32_16x16x32_bf16: lane (i, g) = row n0 + i, k = 8 g ..) and 16 bytes of each 16-row block of activations
 // (operand B: lane (j, g) = row 16 mt + j), one MFMA per block; nothing goes through LDS until the eight partial tiles are added,
-// in wave order, and leave with bias and ReLU.  Every output is the same chain of operations whatever M is (the K-steps of a wave in
+// in wave order, and leave with bias and ReLU.  Above 64 windows the grid grows a second dimension -- one workgroup per 16 features AND
+// per 64 windows, each streaming its weight rows again (from L2 / the Infinity Cache: the four-block launch at 256 windows keeps 512
+// workgroups busy) -- where a sixteen-block workgroup (128 KB of partial tiles) measured slower than the tile GEMM.  Every output is the same chain of operations whatever M is (the K-steps of a wave in
 // order, then the waves in order): a window's h1 / h2 do not depend on how many windows share the call -- the online pushes give the
 // bits of the sequence call (tests/test_gpu_parity.py::test_online_mode_bf16_fc).
 #include "dce_kernels.h"
@@ -38,12 +40,12 @@ void fc_stream_bf16_kernel(const unsigned short* __restrict__ A, const unsigned 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16, mb = blockIdx.y * (16 * MT);         // blockIdx.y: which block of 16 MT windows (65 .. 256 windows: 2 .. 4 of them)
     const uint4* wrow = reinterpret_cast<const uint4*>(W + (size_t)(n0 + i) * K) + g;          // + 4 per K-step
     const uint4* arow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = 16 * mt + i < M ? 16 * mt + i : M - 1;             // rows past M re-read the last one (never stored)
+        const int m = mb + 16 * mt + i < M ? mb + 16 * mt + i : M - 1;   // rows past M re-read the last one (never stored)
         arow[mt] = reinterpret_cast<const uint4*>(A + (size_t)m * K) + g;
     }
     sb_f32x4 acc[MT];
@@ -81,7 +83,7 @@ void fc_stream_bf16_kernel(const unsigned short* __restrict__ A, const unsigned 
         float v = sb_part[((0 * MT + mt) * 64 + l) * 4 + r];
 #pragma unroll
         for (int w = 1; w < SB_WAVES; ++w) v += sb_part[((w * MT + mt) * 64 + l) * 4 + r];
-        const int m = 16 * mt + (l & 15), n = n0 + 4 * (l >> 4) + r;
+        const int m = mb + 16 * mt + (l & 15), n = n0 + 4 * (l >> 4) + r;
         v += bias[n];
         if (relu) v = v < 0.f ? 0.f : v;                                 // keeps NaN like torch
         if (m < M) {
@@ -95,14 +97,14 @@ template <int MT, bool OUT_BF16>
 hipError_t launch_sb(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int relu, hipStream_t st)
 {
     const size_t lds = (size_t)SB_WAVES * MT * 64 * 16;
-    hipLaunchKernelGGL((fc_stream_bf16_kernel<MT, OUT_BF16>), dim3(N / 16), dim3(64 * SB_WAVES), lds, st,
+    hipLaunchKernelGGL((fc_stream_bf16_kernel<MT, OUT_BF16>), dim3(N / 16, (M + 16 * MT - 1) / (16 * MT)), dim3(64 * SB_WAVES), lds, st,
                        static_cast<const unsigned short*>(A), static_cast<const unsigned short*>(W), bias, C, M, N, K, relu);
     return hipGetLastError();
 }
 
 }  // namespace
 
-bool fc_stream_bf16_ok(int64_t M, int N, int K) { return M >= 1 && M <= 64 && N % 16 == 0 && K % 32 == 0 && K >= 32 * SB_WAVES; }
+bool fc_stream_bf16_ok(int64_t M, int N, int K) { return M >= 1 && M <= 256 && N % 16 == 0 && K % 32 == 0 && K >= 32 * SB_WAVES; }
 
 hipError_t launch_fc_stream_bf16(const void* A, const void* W, const float* bias, void* C, int out_bf16, int64_t M, int N, int K, int relu, hipStream_t st)
 {

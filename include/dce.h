@@ -76,8 +76,8 @@ typedef enum dce_precision {
  * windows is several launches: the last one may fall into another regime).  DCE_FP32_SPLIT: below 128 windows the DCE_FP32 kernels, from
  * 128 the three-term conv stack, from 2817 the split fc.0 -- the same window may differ in its last bits between a small and a large call
  * (both within the fp32 tolerance of the reference, <= 2e-5 of the largest logit apart).  DCE_BF16_FC: one conv kernel at every size, FC
- * kernels by size -- up to 64 windows per launch one weight-streaming kernel whose results do not depend on the number of windows (an
- * online push gives the bits of a sequence call in launches of <= 64), above that tile / phased GEMMs with other fp32 summation orders:
+ * kernels by size -- up to 256 windows per launch one weight-streaming kernel whose results do not depend on the number of windows (an
+ * online push gives the bits of a sequence call in launches of <= 256), above that tile / phased GEMMs with other fp32 summation orders:
  * an h1 value at a bf16 rounding boundary may round the other way, <= 2e-2 of the largest logit.  Tested:
  * tests/test_round4_gpu.py::test_batch_size_regimes_stay_within_the_mode_tolerance.  A caller that needs call-size invariance uses DCE_FP32. */
 
