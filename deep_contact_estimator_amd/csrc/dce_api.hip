@@ -70,6 +70,7 @@ Tuning tuning_from_env()
     t.x3_conv = num("DCE_X3_CONV", t.x3_conv ? 1 : 0) != 0;
     t.x3_conv_min = num("DCE_X3_CONV_MIN", t.x3_conv_min);
     t.x3_permk = num("DCE_X3_PERMK", t.x3_permk ? 1 : 0) != 0;
+    t.gemm_ki = DCE_EXPERIMENTS && num("DCE_GEMM_KI", t.gemm_ki ? 1 : 0) != 0;
     t.bf16_stream = num("DCE_BF16_STREAM", t.bf16_stream ? 1 : 0) != 0;
     t.x3_bf16_min = num("DCE_X3_BF16_MIN", t.x3_bf16_min);
     t.x3_bf16_terms = num("DCE_X3_BF16_TERMS", t.x3_bf16_terms) == 2 ? 2 : 3;

@@ -23,6 +23,7 @@ constexpr int WIN = 150, CH = 54, NCLS = 16, FEAT = 4736, FC1 = 2048, FC2 = 512;
 // contexts of one process (tests, tools/race_screen.py) can run different kernel variants side by side.
 struct Tuning {
     bool gemm_tile = false, gemm_lockstep = false;          // DCE_GEMM=tile | lockstep   (default: phased)
+    bool gemm_ki = false;                                   // DCE_GEMM_KI=1 (experiments build): the bf16 256 x 128 tile on fc_gemm_ki_kernel (the two wave groups deal the K-tiles out between them: math phases twice as long; same launch time at a lower clock)
     bool gemm_pipe = false;                                 // DCE_GEMM=pipe (experiments build): the bf16 256 x 128 tile on fc_gemm_pipe_kernel (LDS counters instead of workgroup barriers in the K loop; measured slower)
     int phased_min_tiles = 192, phased_min_tiles1 = 128;    // DCE_PHASED_MIN_TILES, DCE_PHASED_MIN_TILES1
     int phased_min = 1;                                     // DCE_GEMM_PHASED_MIN (2: only the 256x128 tile)

@@ -443,6 +443,189 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
 
 #if DCE_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------------------------
+// fc_gemm_ki_kernel -- the bf16 256 x 128 tile with the two wave groups dealing the K-TILES out between them (round 4).
+// In the phased kernel above both groups multiply the SAME K-tile (each its half of the tile's columns): a math phase is 16 MFMAs
+// per wave = 512 cycles at bf16 rate, and the hand-over at each of the two phase changes per K-tile costs as much again
+// (profiles/r3c_trace_gemm.txt: 1024 cycles of MFMAs in a 1850-cycle period).  Here group 0 owns the even K-tiles and group 1 the odd
+// ones, each for the WHOLE 256 x 128 tile (wave tile 64 x 128: 32 MFMAs = 1024 cycles per math phase), still one phase apart:
+//     phase 2k   : group 0  load(tile 2k)   | group 1  math(tile 2k-1)     -- workgroup barrier --
+//     phase 2k+1 : group 0  math(tile 2k)   | group 1  load(tile 2k+1)     -- workgroup barrier --
+// so the same two hand-overs now stand beside twice the MFMAs.  The group that loads tile t also issues the whole LDS-DMA of tile
+// t+2 (12 pieces per wave) into the buffer of tile t-1, which the OTHER group finished reading a phase ago; it waits for those pieces
+// at the end of its own math(t).  The two groups' partial sums over their halves of K meet once, after the loop: each wave hands
+// two of its four column blocks to its partner wave through LDS (the tile buffers are free by then) and finishes the other two.
+// Another summation order than the phased kernel's: bf16 precision only, which claims no bit pattern.
+// MEASURED (profiles/r4o_gemm_ki.txt): the loop is what it was built to be -- 3045 cycles per pair of K-tiles against 3700 (a load phase
+// is now ~1000 cycles: 24 fragment reads and 12 LDS-DMA instructions issued beside the other group's MFMA stream, the CU's address
+// path alone takes 768 cycles for a tile's 48 KB) -- and the launch takes 71 us against 69: ~128k cycles at 1.80 GHz against ~150k at
+// 2.17 GHz.  What the denser loop gains the board's power management takes back in clock, as with fc_gemm_x3.hip and with the conv
+// stack at 32768 windows: this GEMM sits at ~1.15 PFLOP/s whichever way its phases are cut.  Experiments build only (DCE_GEMM_KI=1).
+template <bool OUT_BF16>
+__global__ __launch_bounds__(512, 2)
+void fc_gemm_ki_kernel(const void* __restrict__ Av, const void* __restrict__ Wv, const float* __restrict__ bias, void* __restrict__ Cv,
+                       int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
+{
+    using Cfg = PhCfg<2, 2, 128>;
+    constexpr int BM = Cfg::BM, KQ = Cfg::KQ, TM = 2, TN = 4, ROWB = 128, TILE = Cfg::TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, li = bid >> 3;
+    const int sid = (li >> 5) * 8 + xcd;
+    const int within = li & 31;
+    const int sn = 1 << sn_log2, sm = 32 >> sn_log2;
+    const int nsn = ntiles >> sn_log2;
+    const int tm = (sid / nsn) * sm + (within >> sn_log2);
+    const int tn = (sid % nsn) * sn + (within & (sn - 1));
+    if (tm >= mtiles) return;
+    const int m0 = tm * BM, n0 = tn * Cfg::BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, w4 = wid & 3;
+    const int wm = w4 * 64;
+    const int i = lane & 31, h = lane >> 5;
+
+    // global -> LDS: the loading group's wave w4 brings chunks w4 + 4 m (m = 0..11) of the tile's 48: two issue_tile calls, chunks
+    // w4 + 8 j and w4 + 4 + 8 j -- 32 rows further down both panels, same slots (swz(r + 32) = swz(r)): one set of per-lane offsets
+    const size_t rowb = (size_t)K * 2;
+    unsigned voff[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int c = w4 + 8 * j;
+        const int r = Cfg::CROWS * c + lane / Cfg::SLOTS;
+        const int col = (lane % Cfg::SLOTS) ^ Cfg::swz(r);
+        const int grow = j < Cfg::NA ? r : r - BM;       // (whole tiles only: the launcher checks M % 256 == 0)
+        voff[j] = (unsigned)(grow * rowb + 16 * col);
+    }
+    const char* sA = static_cast<const char*>(Av) + (size_t)m0 * rowb;
+    const char* sW = static_cast<const char*>(Wv) + (size_t)n0 * rowb;
+    const unsigned lds_wave = lds_addr(smem) + w4 * 1024;
+    auto issue = [&](int t) {
+        const size_t ko = (size_t)t * ROWB;
+        const unsigned dst = lds_wave + (unsigned)(t % 3) * TILE;
+        issue_tile<4, 2>(dst, sA + ko, sW + ko, voff);
+        issue_tile<4, 2>(dst + 4 * 1024, sA + ko + 32 * rowb, sW + ko + 32 * rowb, voff);
+    };
+
+    const int sw = Cfg::swz(i);
+    unsigned pa[KQ];                                      // A rows of this wave; the W rows sit (BM - wm) rows further down: an immediate
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+        pa[kq] = (wm + i) * ROWB + 16 * ((2 * kq + h) ^ sw);
+        asm volatile("" : "+v"(pa[kq]));
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int KT = (int)(rowb / ROWB);                    // >= 4, even or odd
+    float4 af[KQ][TM], bf[KQ][TN];
+    auto load_frags = [&](unsigned boff) {               // boff: byte offset of the tile's buffer (wave-uniform, run time: both groups run this one loop)
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+            const char* base = smem + (boff + pa[kq]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[kq][a] = *reinterpret_cast<const float4*>(base + a * 32 * ROWB);
+#pragma unroll
+            for (int c = 0; c < TN; ++c) bf[kq][c] = *reinterpret_cast<const float4*>(base + (BM - wm + c * 32) * ROWB);
+        }
+    };
+    auto math = [&]() {
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kq][a]), __builtin_bit_cast(bf16x8, bf[kq][b]), acc[a][b], 0, 0, 0);
+    };
+    auto bar = [&](bool drain) {                         // end of a phase: own fragment reads returned (and, behind a math phase, own LDS-DMA landed)
+        __builtin_amdgcn_sched_barrier(0);               // (MFMAs carry no memory dependence: without this the scheduler moves them across the barrier)
+        if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: each group brings its first tile; everybody waits for both
+    { const int t = 62; PH_MARK(0); }
+    if (grp < KT) issue(grp);
+    bar(true);
+    if (grp == 1) bar(false);                             // group 1 runs one phase behind group 0
+    int buf = grp;                                        // tile t lives in buffer t % 3
+#pragma unroll 1
+    for (int t = grp; t < KT; t += 2) {
+        PH_MARK(0);
+        if (t + 2 < KT) issue(t + 2);                    // into the buffer of tile t-1: the other group read it a phase ago
+        load_frags((unsigned)buf * TILE);
+        PH_MARK(1);
+        bar(false);
+        PH_MARK(2);
+        math();
+        PH_MARK(3);
+        bar(true);
+        buf = buf == 0 ? 2 : buf - 1;                    // (buf + 2) % 3
+    }
+    // the group that ran out of tiles first keeps in step with the other's remaining phases: both execute KT + 1 phases' barriers
+    {
+        const int mine = (KT - grp + 1) / 2;             // tiles this group processed: 2 barriers each (+ 1 for group 1's delay)
+        const int done = 2 * mine + grp, total = KT + 1;
+        for (int p = done; p < total; ++p) bar(false);
+    }
+
+    // ---- the two halves of K meet: group 0 finishes column blocks 0, 1 and group 1 blocks 2, 3; each hands the other two to its
+    //      partner wave (same w4) through LDS: [w4][to group][a][b'][quarter][lane] x 16 bytes = 128 KB (the tile buffers are free)
+    {
+        { const int t = 62; PH_MARK(1); }
+        float4* ex = reinterpret_cast<float4*>(smem);
+        const bool g0 = grp == 0;                        // (selects, not a run-time index into acc: that would put the accumulators in scratch)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v;
+                    v.x = g0 ? acc[a][2 + b][4 * q] : acc[a][b][4 * q];
+                    v.y = g0 ? acc[a][2 + b][4 * q + 1] : acc[a][b][4 * q + 1];
+                    v.z = g0 ? acc[a][2 + b][4 * q + 2] : acc[a][b][4 * q + 2];
+                    v.w = g0 ? acc[a][2 + b][4 * q + 3] : acc[a][b][4 * q + 3];
+                    ex[((((w4 * 2 + (1 - grp)) * TM + a) * 2 + b) * 4 + q) * 64 + lane] = v;
+                }
+        bar(false);
+        { const int t = 62; PH_MARK(2); }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + 32 * ((g0 ? 0 : 2) + b) + i;
+            const float bv = bias[col];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 o = ex[((((w4 * 2 + grp) * TM + a) * 2 + b) * 4 + q) * 64 + lane];
+                    const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * q + e;
+                        const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        float v = ((g0 ? acc[a][b][r] : acc[a][2 + b][r]) + ov[e]) + bv;
+                        if (relu) v = v < 0.f ? 0.f : v;
+                        if constexpr (OUT_BF16) static_cast<unsigned short*>(Cv)[(size_t)row * N + col] = f32_to_bf16(v);
+                        else static_cast<float*>(Cv)[(size_t)row * N + col] = v;
+                    }
+                }
+        }
+        { const int t = 62; PH_MARK(3); }
+    }
+}
+
+#endif  // DCE_EXPERIMENTS (fc_gemm_ki_kernel)
+
+#if DCE_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------------------------
 // fc_gemm_pipe_kernel -- the bf16 256 x 128 tile WITHOUT workgroup barriers in its K loop (round 4; DCE_GEMM=pipe).
 // The phased schedule above hands the matrix pipe from one wave group to the other twice per K-tile; at fp32 rate that hand-over is
 // 6 % of a phase, at bf16 rate (a 64-k K-tile = 512 cycles of MFMAs per wave) it is a third (profiles/r3c_trace_gemm.txt), and the
@@ -672,6 +855,10 @@ hipError_t init_fc_gemm_phased()
 {
     hipError_t e;
 #if DCE_EXPERIMENTS
+    for (const void* k : {reinterpret_cast<const void*>(&fc_gemm_ki_kernel<true>), reinterpret_cast<const void*>(&fc_gemm_ki_kernel<false>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg<2, 2, 128>::LDS)) != hipSuccess) return e;
+#endif
+#if DCE_EXPERIMENTS
     for (const void* k : {reinterpret_cast<const void*>(&fc_gemm_pipe_kernel<true>), reinterpret_cast<const void*>(&fc_gemm_pipe_kernel<false>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 384 * 64 + 64)) != hipSuccess) return e;
 #endif
@@ -741,6 +928,13 @@ static hipError_t launch_phased_cfg(const void* A, const void* W, const float* b
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
 #if DCE_EXPERIMENTS
+    if constexpr (BF16 && T == 2) {
+        if (tune().gemm_ki && !use_lockstep(true) && M % 256 == 0 && K % 64 == 0 && K >= 256) {       // K-tiles dealt out between the wave groups (whole tiles only)
+            plan_note("fc_ki256x128");
+            hipLaunchKernelGGL((fc_gemm_ki_kernel<OUT_BF16>), dim3(grid), dim3(512), Cfg::LDS, st, A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+            return hipGetLastError();
+        }
+    }
     if constexpr (BF16 && T == 2) {
         if (tune().gemm_pipe && !use_lockstep(true) && M % 256 == 0 && K % 32 == 0 && K >= 256) {       // no workgroup barriers in the K loop (fc_gemm_pipe_kernel; whole tiles only)
             plan_note("fc_pipe256x128");

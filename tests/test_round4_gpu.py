@@ -103,6 +103,26 @@ def test_bf16_fc_conv_stack_on_two_term_operands(n, orc):
 
 
 @pytest.mark.experiments
+def test_k_tiles_dealt_out_between_the_wave_groups():
+    """fc_gemm_ki_kernel (DCE_GEMM_KI=1, experiments build: group 0 multiplies the even K-tiles, group 1 the odd ones, partial sums meet
+    once through LDS; same launch time as the phased kernel at a lower clock, profiles/r4o_gemm_ki.txt): another fp32 summation order,
+    so h1 may differ at bf16 rounding boundaries -- the logits stay within the mode's batch-size band of the phased kernel's, and every
+    repeat gives the same bytes."""
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    a = _model("bf16_fc", env={"DCE_GEMM_KI": "1"}); a.load_state_dict(sd).eval()
+    b = _model("bf16_fc", env={"DCE_GEMM_KI": "0"}); b.load_state_dict(sd).eval()
+    for n in (4096, 8192):
+        x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
+        ra, rb = a.predict(x), b.predict(x)
+        assert "fc_ki256x128" in a.last_plan() and "fc_phased256x128" in b.last_plan(), (a.last_plan(), b.last_plan())
+        assert np.abs(ra["logits"] - rb["logits"]).max() <= 2e-3 * np.abs(rb["logits"]).max()
+        for _ in range(10):
+            assert np.array_equal(a.predict(x)["logits"], ra["logits"])
+    a.close(); b.close()
+
+
+@pytest.mark.experiments
 def test_barrier_free_bf16_gemm_equals_the_phased_kernel():
     """fc_gemm_pipe_kernel (DCE_GEMM=pipe, experiments build: LDS counters instead of workgroup barriers in the K loop; measured
     slower, profiles/r4j_gemm_pipe.txt) walks K in the same 16-k blocks as the phased kernel: the same bytes, on every repeat."""
