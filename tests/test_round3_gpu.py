@@ -109,9 +109,9 @@ def test_tapped_kernels_produce_the_product_features(model_of):
 # ------------------------------------------------------------------------------------------------
 # bf16-FC mode: independent restatement
 # ------------------------------------------------------------------------------------------------
-# batch sizes chosen per bf16 kernel: phased 256x128 + fused 128x64 (4096), phased 128x64 (3000), tile 128x128 /
-# 64x64 (700 / 40), the online / batch-1 path (1), a ragged size past a round (4100)
-@pytest.mark.parametrize("n", [1, 40, 700, 3000, 4096, 4100])
+# batch sizes chosen per bf16 kernel: phased 256x128 + fused 128x64 (4096), phased 128x64 (3000 / 700), 64x64 tiles (300), the
+# weight-streaming kernel with one, two and four 64-window blocks (1 / 40, 100, 256), a ragged size past a round (4100)
+@pytest.mark.parametrize("n", [1, 40, 100, 256, 300, 700, 3000, 4096, 4100])
 def test_bf16_fc_vs_independent_restatement(n, model_of, orc):
     """DCE_BF16_FC (BASELINE configs[4]: the reference's fc layers, src/contact_cnn.py:47-58, with fc.0 / fc.3 on bf16
     operands) against oracle_forward_windows_bf16fc.  Stage by stage, each layer is checked on the DEVICE's own inputs
