@@ -91,7 +91,7 @@ def kernel_peak(kernel, precision):
 
 def conv_terms(precision):
     """MFMAs per product of conv_x3.hip: six on three-term operands (fp32_split), three on two-term operands (bf16_fc's default)."""
-    return 3 if precision == "bf16_fc" and os.environ.get("DCE_X3_BF16_TERMS", "2") != "3" else 6
+    return 3 if precision == "bf16_fc" and "x3_bf16_terms=3" not in os.environ.get("DCE_TUNE", "") else 6
 
 
 def exec_flop(kernel, precision):
@@ -359,7 +359,7 @@ def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000, precision="fp32"):
 MODE_TEXT = {
     "bf16_fc": "BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; conv stack on two-term bf16 "
                "operands (three MFMAs per product, ~17 significant bits in front of the features' rounding to bf16, conv_x3.hip NT = 2; "
-               "DCE_X3_BF16_TERMS=3: fp32_split's six-MFMA products, DCE_X3_CONV=0: the fp32 Winograd kernel), fc.6 fp32",
+               "option x3_bf16_terms=3: fp32_split's six-MFMA products, x3_conv=0: the fp32 Winograd kernel), fc.6 fp32",
     "fp32_split": "the bench step ({B} windows) with the conv stack and fc.0 on the bf16 matrix pipe, every fp32 operand as three bf16 terms "
                   "(six MFMAs per product, fp32 accumulate: fp32 results, not the fp32 path's bits -- opt-in, include/dce.h DCE_FP32_SPLIT); "
                   "fc.3 and fc.6 fp32 MFMA",
@@ -405,10 +405,8 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
     if precision == "bf16_fc" and conv_terms(precision) == 3:
         # the same step with the conv stack on THREE-term operands (fp32-grade features in front of their rounding to bf16: the
         # round-3 form of the mode), so that the line shows what the two-term stack buys and what it changes
-        old = os.environ.get("DCE_X3_BF16_TERMS")
-        os.environ["DCE_X3_BF16_TERMS"] = "3"
         try:
-            m3 = contact_cnn(device=dev.index, max_batch=B, precision=precision)
+            m3 = contact_cnn(device=dev.index, max_batch=B, precision=precision, tune={"x3_bf16_terms": 3})
             m3.load_state_dict(sd).eval()
             settle(torch, lambda: m3.predict(windows), min(settle_s, 0.5))
             torch.cuda.synchronize()
@@ -418,14 +416,13 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
             dt3 = time.perf_counter() - t0
             f3 = int((o3["pred"] != ref_out["pred"]).sum().item())
             res["three_term_conv_stack"] = {
-                "switch": "DCE_X3_BF16_TERMS=3", "windows_per_s": B * steps / dt3, "ms_per_step": dt3 / steps * 1e3, "plan": m3.last_plan(),
+                "switch": "x3_bf16_terms=3", "note": "BASELINE configs[4] as written: fp32-grade conv results in front of the bf16 FC layers", "windows_per_s": B * steps / dt3, "ms_per_step": dt3 / steps * 1e3, "plan": m3.last_plan(),
                 "vs_fp32_same_input": {"max_abs_dlogit": float((o3["logits"] - lr).abs().max().item()), "argmax_flips": f3},
                 "vs_two_term_same_input": {"max_abs_dlogit": float((o3["logits"] - lg).abs().max().item()),
                                            "argmax_differences": int((o3["pred"] != out["pred"]).sum().item())}}
             m3.close()
         finally:
-            if old is None: os.environ.pop("DCE_X3_BF16_TERMS", None)
-            else: os.environ["DCE_X3_BF16_TERMS"] = old
+            pass
     # BASELINE configs[2] in this precision too: the 1e6-window sequence, HBM-resident, max_batch 32768 (median of 3 after a warm call)
     ms = contact_cnn(device=dev.index, max_batch=32768, precision=precision)
     ms.load_state_dict(sd).eval()

@@ -18,6 +18,8 @@ SYMBOLS = {
     "dce_build_flags": (C.c_int, []),
     "dce_device_count": (C.c_int, []),
     "dce_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64]),
+    "dce_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_char_p]),
+    "dce_split_guard_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dce_destroy": (None, [C.c_void_p]),
     "dce_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "dce_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, _i64p, C.c_int]),
@@ -49,6 +51,22 @@ SYMBOLS = {
 }
 
 BUILD_EXPERIMENTS, BUILD_TRACE, BUILD_ASAN = 1, 2, 4
+
+
+class SplitGuard(C.Structure):
+    """include/dce.h dce_split_guard"""
+    _fields_ = [("precision", C.c_int), ("enabled", C.c_int), ("refused", C.c_int), ("x_hi", C.c_float), ("x_lo", C.c_float),
+                ("z_max", C.c_float), ("gain", C.c_double * 6), ("offs", C.c_double * 6), ("guarded_launches", C.c_uint32),
+                ("windows_out_of_range", C.c_uint32), ("fallbacks_run", C.c_uint32), ("reason", C.c_char * 256)]
+
+
+def tune_spec(tune) -> bytes | None:
+    """dict / str -> the option string of dce_create_ex ("key=value,key=value"); None: the library reads DCE_TUNE."""
+    if tune is None:
+        return None
+    if isinstance(tune, str):
+        return tune.encode()
+    return ",".join(f"{k}={int(v)}" for k, v in tune.items()).encode()
 
 
 def has_experiments() -> bool:

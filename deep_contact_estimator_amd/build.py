@@ -56,18 +56,32 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_variant(name: str, defines: list[str]) -> str:
-    """Experimental A/B build: libdce_<name>.so with extra -D flags (select with DCE_LIB=...)."""
+def build_variant(name: str, defines: list[str], force: bool = True) -> str:
+    """Experimental A/B build: libdce_<name>.so with extra -D flags (select with DCE_LIB=...).  The translation units compile in
+    parallel; the source hash is recorded next to the library (as for libdce.so) and a library whose record matches the sources
+    and the flags is reused unless `force`."""
     out = os.path.join(HERE, f"libdce_{name}.so")
+    stamp = source_hash() + " " + " ".join(defines)
+    if not force and os.path.exists(out) and built_hash(out) == stamp:
+        return out
     hipcc = _hipcc()
     od = os.path.join(OBJDIR, name)
     os.makedirs(od, exist_ok=True)
-    objs = []
+    procs = []
     for s in SOURCES:
         obj = os.path.join(od, s.replace(".hip", ".o"))
-        subprocess.run([hipcc, *CFLAGS, *defines, "-c", os.path.join(CSRC, s), "-o", obj], check=True)
+        cmd = [hipcc, *CFLAGS, *defines, "-c", os.path.join(CSRC, s), "-o", obj]
+        procs.append((cmd, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    objs = []
+    for cmd, obj, p in procs:
+        log, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + log)
         objs.append(obj)
-    subprocess.run([shutil.which("g++") or "g++", "-shared", "-fPIC", *objs, "-o", out], check=True)
+    subprocess.run([shutil.which("g++") or "g++", "-shared", "-fPIC", *objs, "-o", out + ".tmp"], check=True)
+    os.replace(out + ".tmp", out)
+    with open(out + ".srchash", "w") as f:
+        f.write(stamp + "\n")
     return out
 
 
@@ -104,11 +118,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_experiments() -> str:
+def build_experiments(force: bool = False) -> str:
     """libdce_experiments.so: the product kernels PLUS the variants that were measured slower and kept for the A/B (the
     four-row-tile Winograd workgroup, the lockstep GEMM schedule, the paired three-term conv stack) and the probe macros.
     Select with DCE_LIB=<path>; dce_build_flags() & DCE_BUILD_EXPERIMENTS tells which one is loaded."""
-    return build_variant("experiments", ["-DDCE_EXPERIMENTS=1"])
+    return build_variant("experiments", ["-DDCE_EXPERIMENTS=1"], force=force)
 
 
 def build_asan() -> str:

@@ -57,8 +57,11 @@ class contact_cnn:
     """contact_cnn on MI355X.  ``max_batch`` bounds the windows per kernel sequence (scratch
     is 29 KB per window: 0.95 GB at the default, of 288 GB); longer inputs are chunked inside the library."""
 
-    def __init__(self, device=None, max_batch: int = 32768, precision: str = "fp32"):
+    def __init__(self, device=None, max_batch: int = 32768, precision: str = "fp32", tune=None):
+        """tune: the A/B switches of DESIGN.md's appendix for THIS model -- a dict {key: int} or "key=value,key=value"
+        (include/dce.h dce_create_ex); None: the environment variable DCE_TUNE, else the defaults."""
         self._lib = _lib.load()
+        self._tune = tune
         self._ctx = C.c_void_p()
         self._device = device
         self._max_batch = int(max_batch)
@@ -71,7 +74,7 @@ class contact_cnn:
         if not self._ctx:
             dev = _device_index(self._device)
             ctx = C.c_void_p()
-            _lib.check(self._lib.dce_create(C.byref(ctx), dev, self._max_batch), None)
+            _lib.check(self._lib.dce_create_ex(C.byref(ctx), dev, self._max_batch, _lib.tune_spec(self._tune)), None)
             self._ctx = ctx
             self._dev_index = dev
         return self._ctx
@@ -478,6 +481,16 @@ class contact_cnn:
         _lib.check(self._lib.dce_profile_read(self._ctx, ms, cnt, int(reset)), self._ctx)
         names = ("conv_stack", "fc1_gemm", "fc2_gemm", "fc3_tail")
         return {k: {"ms": ms[i], "launches": cnt[i]} for i, k in enumerate(names)}
+
+    def split_guard(self) -> dict:
+        """fp32_split's range guard for this model (dce_split_guard_info): bounds from the checkpoint, whether it was refused,
+        the per-window limits of predict(), and how often the guard fired."""
+        self._finalize()
+        g = _lib.SplitGuard()
+        _lib.check(self._lib.dce_split_guard_info(self._ctx, C.byref(g)), self._ctx)
+        return {"enabled": bool(g.enabled), "refused": bool(g.refused), "x_hi": float(g.x_hi), "x_lo": float(g.x_lo), "z_max": float(g.z_max),
+                "gain": list(g.gain), "offs": list(g.offs), "guarded_launches": int(g.guarded_launches),
+                "windows_out_of_range": int(g.windows_out_of_range), "fallbacks_run": int(g.fallbacks_run), "reason": g.reason.decode()}
 
     def last_plan(self) -> list[str]:
         """Kernel families launched by this model's most recent kernel sequence, in launch order (dce_last_plan)."""

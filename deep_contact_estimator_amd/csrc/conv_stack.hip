@@ -92,6 +92,7 @@ __device__ __forceinline__ A3 load_a(const float4* __restrict__ ap, int g)
 }
 
 // B operand of one (channel group, tap) stage: 4 K-steps x 5 column tiles = 20 values per lane.
+#if DCE_EXPERIMENTS      // the direct-form conv stack of round 1 ships in the experiments build only (option conv_direct=1): the product library runs the Winograd kernels (conv_wino.hip) and conv_x3.hip
 template <int S>
 __device__ __forceinline__ void load_b(const float* __restrict__ bp, int tap, float (&b)[4 * NT])
 {
@@ -406,6 +407,8 @@ hipError_t init_conv_stack()
     return grant_conv_lds<false, unsigned short>();
 }
 
+#endif  // DCE_EXPERIMENTS (the direct-form kernel)
+
 hipError_t launch_conv_wino_taps(int kernel, const float* src, int64_t n, const ConvPack& pk, float* f,
                                  const LayerTaps& taps, hipStream_t st);
 
@@ -414,15 +417,23 @@ hipError_t launch_conv_taps(int kernel, const float* windows, int64_t n, const C
                             const LayerTaps& taps, hipStream_t st)
 {
     if (kernel != 4) return launch_conv_wino_taps(kernel, windows, n, pk, feat, taps, st);
+#if DCE_EXPERIMENTS
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL((conv_stack_kernel<false, float, true>), dim3((unsigned)((n + NW - 1) / NW)), dim3(256),
                        LDS_FLOATS * sizeof(float), st, windows, n, pk, feat, taps);
     return hipGetLastError();
+#else
+    return hipErrorInvalidValue;                       // the direct form is not in this build
+#endif
 }
 
 hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const ConvPack& pk,
                              void* feat, int feat_bf16, hipStream_t st, const long long* src_row)
 {
+#if !DCE_EXPERIMENTS
+    (void)src; (void)zscore; (void)n; (void)pk; (void)feat; (void)feat_bf16; (void)st; (void)src_row;
+    return hipErrorNotSupported;
+#else
     if (src_row) return hipErrorNotSupported;          // the online graph runs on the Winograd kernels only
     if (n <= 0) return hipSuccess;
     size_t lds = LDS_FLOATS * sizeof(float);
@@ -441,6 +452,7 @@ hipError_t launch_conv_stack(const float* src, int zscore, int64_t n, const Conv
         else        hipLaunchKernelGGL((conv_stack_kernel<false, float>), grid, block, lds, st, src, n, pk, f, LayerTaps{});
     }
     return hipGetLastError();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -572,9 +572,10 @@ __device__ __forceinline__ void wino_store_feat(FT* __restrict__ feat, int64_t w
 template <bool ZS, typename FT, bool TAPS = false>
 __global__ __launch_bounds__(256, 2)
 void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT* __restrict__ feat,
-                      const long long* __restrict__ src_row, LayerTaps taps)
+                      const long long* __restrict__ src_row, LayerTaps taps, Gate gate = Gate{})
 {
     extern __shared__ __attribute__((aligned(16))) float act[];
+    if (gate_closed(gate)) return;                        // DCE_FP32_SPLIT's fallback sequence: runs only behind a launch that left the guarded range
     if (src_row) src += *src_row * CH;                    // online graph: the window start lives in device memory
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1599,8 +1600,8 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
         else        hipLaunchKernelGGL((conv_wino_kernel<false, unsigned short>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
     } else {
         float* f = static_cast<float*>(feat);
-        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
-        else        hipLaunchKernelGGL((conv_wino_kernel<false, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+        if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{}, t_gate);
+        else        hipLaunchKernelGGL((conv_wino_kernel<false, float>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{}, t_gate);
     }
     return hipGetLastError();
 }

@@ -71,8 +71,13 @@ void conv_x3_pack_host(int l, const float* w, unsigned short* out)
 template <bool ZS, bool TAPS = false, int OUT = 0, bool PERMK = false, bool PERSIST = false, int NT = 3>
 __global__ __launch_bounds__(256, NT == 2 ? 3 : 2)
 void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, unsigned short* __restrict__ feat3, size_t plane_elems,
-                    LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr, const long long* __restrict__ src_row = nullptr)
-{   // TAPS (dce_conv_layer_taps, parity tests): every layer's output also goes to HBM in fp32, and so do the features.
+                    LayerTaps taps = LayerTaps{}, float* __restrict__ feat32 = nullptr, const long long* __restrict__ src_row = nullptr,
+                    GuardArgs guard = GuardArgs{})
+{   // guard (DCE_FP32_SPLIT on pre-normalised windows; dce_kernels.h GuardArgs): the load stage also takes the window's largest magnitude;
+    // a window above x_hi (a layer's operand could reach bf16's largest finite value: the first term of a split would round to Inf) or
+    // entirely below x_lo (third terms would go subnormal) writes the launch's generation to guard.word[0] -- the gated DCE_FP32 sequence
+    // behind this launch then recomputes it -- and counts itself in guard.word[1].
+    // TAPS (dce_conv_layer_taps, parity tests): every layer's output also goes to HBM in fp32, and so do the features.
     // OUT: 0 the features leave as three bf16 planes (fc_gemm_x3.hip's layout); 1 as (n, 4736) fp32 in feat32 (batches below
     // the split-bf16 fc.0 kernel's threshold, whose fc.0 runs on the fp32 kernels); 2 as (n, 4736) bf16, round-to-nearest-even,
     // in feat3 (the DCE_BF16_FC precision, whose FC layers take bf16 operands)
@@ -151,7 +156,28 @@ void conv_x3_kernel(const float* __restrict__ src, int64_t n, ConvPackX3 pk, uns
         cc_f32x2 nz = {0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 16; ++q) nz = __builtin_elementwise_fma(cc_f32x2{v[q].x, v[q].y}, cc_f32x2{0.f, 0.f}, nz);
-        window_bad = __syncthreads_or(!(nz.x == 0.f) || !(nz.y == 0.f));      // (also: the zero fill is complete)
+        if (guard.word == nullptr) window_bad = __syncthreads_or(!(nz.x == 0.f) || !(nz.y == 0.f));      // (also: the zero fill is complete)
+        else {
+            // the range guard rides on the same barrier: four facts per thread -> per wave (ballots) -> per window (one LDS word per wave)
+            __shared__ unsigned cx_flags[4];
+            float tmax = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tmax = fmaxf(tmax, fmaxf(fabsf(v[q].x), fabsf(v[q].y)));        // (v_max drops NaN; Inf is above every x_hi)
+            unsigned wbits = 0;
+            if (__builtin_amdgcn_ballot_w64(!(nz.x == 0.f) || !(nz.y == 0.f)) != 0) wbits |= 1u;        // a non-finite sample
+            if (__builtin_amdgcn_ballot_w64(tmax > guard.x_hi) != 0) wbits |= 2u;                         // a sample above the guarded range
+            if (__builtin_amdgcn_ballot_w64(tmax >= guard.x_lo) != 0) wbits |= 4u;                        // a sample of ordinary size
+            if (__builtin_amdgcn_ballot_w64(tmax > 0.f) != 0) wbits |= 8u;                                // a non-zero sample
+            if (lane == 0) cx_flags[wv] = wbits;
+            __syncthreads();                                           // (also: the zero fill is complete)
+            const unsigned all = cx_flags[0] | cx_flags[1] | cx_flags[2] | cx_flags[3];
+            window_bad = (int)(all & 1u);
+            // (a non-finite window is NaN on both routes: no fallback for it)
+            if (!(all & 1u) && ((all & 2u) || ((all & 8u) && !(all & 4u))) && tid == 0) {
+                __hip_atomic_store(guard.word, guard.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(guard.word + 1, 1u);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             unsigned p[3];
@@ -402,12 +428,12 @@ hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3
 }
 
 // the same stack with (n, 4736) fp32 features out: DCE_FP32_SPLIT at batches below the split-bf16 fc.0 kernel's threshold
-hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st)
+hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st, const GuardArgs& guard)
 {
     if (n <= 0) return hipSuccess;
     plan_note("conv_x3_f32");
     if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 1>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat);
-    else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 1>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat);
+    else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 1>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat, nullptr, guard);
     return hipGetLastError();
 }
 
@@ -448,7 +474,7 @@ hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const Co
     return hipGetLastError();
 }
 
-hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st, int permk)
+hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st, int permk, const GuardArgs& guard)
 {
     if (n <= 0) return hipSuccess;
     const size_t plane_elems = (size_t)((n + 1) & ~(int64_t)1) * FEAT;
@@ -463,12 +489,12 @@ hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPac
     if (permk) {
         plan_note("conv_x3_permk");
         if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 0, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
-        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 0, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
+        else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 0, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr, nullptr, guard);
         return hipGetLastError();
     }
     plan_note("conv_x3");
     if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
-    else        hipLaunchKernelGGL((conv_x3_kernel<false>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
+    else        hipLaunchKernelGGL((conv_x3_kernel<false>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr, nullptr, guard);
     return hipGetLastError();
 }
 

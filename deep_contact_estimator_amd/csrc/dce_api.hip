@@ -5,6 +5,9 @@
 // No exception or abort crosses the boundary; every failure is a negative dce_status plus a message.
 #include "dce_ctx.h"
 #include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstddef>
 
 #include <cstdarg>
 #include <cstdio>
@@ -36,55 +39,61 @@ namespace dce {
 thread_local std::string g_create_error;
 thread_local const Tuning* t_tuning = nullptr;
 thread_local std::vector<const char*>* t_plan = nullptr;
+thread_local Gate t_gate;
 
-Tuning tuning_from_env()
+// ---- the ONE table of A/B switches (dce_kernels.h Tuning): key, member, kind.  dce_create_ex's option string / DCE_TUNE name them.
+namespace {
+struct TuneKey { const char* key; char kind; size_t off; bool experiments; };     // kind: b bool, i int, l long long
+#define TK(name, kind) {#name, kind, offsetof(Tuning, name), false}
+#define TKX(name, kind) {#name, kind, offsetof(Tuning, name), true}
+const TuneKey kTuneKeys[] = {
+    TK(gemm_tile, 'b'), TK(phased_min_tiles, 'i'), TK(phased_min_tiles1, 'i'), TK(phased_min, 'i'), TK(phased_cost, 'b'), TK(phased_sn, 'i'),
+    TK(fc23, 'i'), TK(gemm_peel, 'b'), TK(conv_peel, 'b'), TK(gemm_small_deep, 'b'), TK(gemv, 'b'),
+    TK(split_min, 'l'), TK(split_max, 'l'), TK(chain_min, 'l'), TK(chain_max, 'l'), TK(chain_max3, 'l'), TK(chain_bn16_max, 'l'),
+    TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
+    TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'),
+    TK(online_graph, 'b'), TK(online_direct, 'b'),
+    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(split_guard, 'b'),
+    TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
+    TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
+};
+#undef TK
+#undef TKX
+}  // namespace
+
+bool tuning_parse(const char* spec, Tuning& t, char* err, int err_len)
 {
-    Tuning t;
-    auto num = [](const char* k, long long dflt) { const char* e = getenv(k); return e ? atoll(e) : dflt; };
-    auto off = [](const char* k) { const char* e = getenv(k); return e && atoi(e) == 0; };
-    if (const char* e = getenv("DCE_GEMM")) { t.gemm_tile = strcmp(e, "tile") == 0; t.gemm_lockstep = strcmp(e, "lockstep") == 0; t.gemm_pipe = DCE_EXPERIMENTS && strcmp(e, "pipe") == 0; }
-    t.phased_min_tiles = (int)num("DCE_PHASED_MIN_TILES", t.phased_min_tiles);
-    t.phased_min_tiles1 = (int)num("DCE_PHASED_MIN_TILES1", t.phased_min_tiles1);
-    t.phased_min = (int)num("DCE_GEMM_PHASED_MIN", t.phased_min);
-    t.phased_cost = !off("DCE_PHASED_COST");
-    t.phased_sn = (int)num("DCE_PHASED_SN", t.phased_sn);
-    if (const char* e = getenv("DCE_FC23")) t.fc23_mode = strcmp(e, "split") == 0 ? 1 : strcmp(e, "always") == 0 ? 2 : 0;
-    t.gemm_peel = !off("DCE_GEMM_PEEL");
-    t.conv_peel = !off("DCE_CONV_PEEL");
-    t.gemm_small_deep = !off("DCE_GEMM_SMALL");
-    t.split_min = num("DCE_SPLIT_MIN", t.split_min);
-    t.split_max = num("DCE_SPLIT_MAX", t.split_max);
-    t.chain_min = num("DCE_CHAIN_MIN", t.chain_min);
-    t.chain_max = num("DCE_CHAIN_MAX", t.chain_max);
-    t.chain_max3 = num("DCE_CHAIN_MAX3", t.chain_max3);
-    t.chain_bn16_max = num("DCE_CHAIN_BN16_MAX", t.chain_bn16_max);
-    t.wino1_max = num("DCE_WINO1_MAX", -1);
-    t.winoh_max = num("DCE_WINOH_MAX", -1);
-    t.winoq_max = num("DCE_WINOQ_MAX", -1);
-    t.wino1_w8 = num("DCE_WINO1_WAVES", 8) != 4;
-    t.one_per_cu = getenv("DCE_ONE_PER_CU") != nullptr;
-    t.trace_wino1 = getenv("DCE_TRACE_WINO1") != nullptr;
-    t.conv4 = DCE_EXPERIMENTS ? (int)num("DCE_CONV4", 0) : 0;
-    t.x3_min_tiles = (int)num("DCE_X3_MIN_TILES", t.x3_min_tiles);
-    t.x3_unfused = getenv("DCE_X3_UNFUSED") != nullptr;
-    t.x3_conv = num("DCE_X3_CONV", t.x3_conv ? 1 : 0) != 0;
-    t.x3_conv_min = num("DCE_X3_CONV_MIN", t.x3_conv_min);
-    t.x3_permk = num("DCE_X3_PERMK", t.x3_permk ? 1 : 0) != 0;
-    t.gemm_ki = DCE_EXPERIMENTS && num("DCE_GEMM_KI", t.gemm_ki ? 1 : 0) != 0;
-    t.bf16_stream = num("DCE_BF16_STREAM", t.bf16_stream ? 1 : 0) != 0;
-    t.x3_bf16_min = num("DCE_X3_BF16_MIN", t.x3_bf16_min);
-    t.x3_bf16_terms = num("DCE_X3_BF16_TERMS", t.x3_bf16_terms) == 2 ? 2 : 3;
-    t.x3_persist = DCE_EXPERIMENTS && num("DCE_X3_PERSIST", t.x3_persist ? 1 : 0) != 0;
-    t.x3_persist_min = num("DCE_X3_PERSIST_MIN", t.x3_persist_min);
-    t.x3_pair = DCE_EXPERIMENTS && num("DCE_X3_PAIR", t.x3_pair ? 1 : 0) != 0;      // (conv_x3p.hip exists in the experiments build only)
-    t.x3_pair_min = num("DCE_X3_PAIR_MIN", t.x3_pair_min);
-    return t;
+    if (!spec) return true;
+    std::string s(spec);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t end = s.find_first_of(",; ", pos);
+        if (end == std::string::npos) end = s.size();
+        const std::string item = s.substr(pos, end - pos);
+        pos = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        const std::string key = item.substr(0, eq), val = eq == std::string::npos ? "1" : item.substr(eq + 1);
+        char* stop = nullptr;
+        const long long v = strtoll(val.c_str(), &stop, 10);
+        if (val.empty() || *stop != '\0') { snprintf(err, (size_t)err_len, "tuning option '%s': '%s' is not an integer", key.c_str(), val.c_str()); return false; }
+        const TuneKey* k = nullptr;
+        for (const TuneKey& c : kTuneKeys) if (key == c.key) { k = &c; break; }
+        if (!k) { snprintf(err, (size_t)err_len, "unknown tuning option '%s' (the table is kTuneKeys in csrc/dce_api.hip; DESIGN.md appendix)", key.c_str()); return false; }
+        if (k->experiments && !DCE_EXPERIMENTS) continue;             // a variant this build does not contain: its switch is ignored
+        char* m = reinterpret_cast<char*>(&t) + k->off;
+        if (k->kind == 'b') *reinterpret_cast<bool*>(m) = v != 0;
+        else if (k->kind == 'i') *reinterpret_cast<int*>(m) = (int)v;
+        else *reinterpret_cast<long long*>(m) = v;
+    }
+    if (t.x3_bf16_terms != 2 && t.x3_bf16_terms != 3) { snprintf(err, (size_t)err_len, "x3_bf16_terms must be 2 or 3"); return false; }
+    return true;
 }
 
 const Tuning& tune()
 {
     if (t_tuning) return *t_tuning;
-    static const Tuning process_default = tuning_from_env();     // a launcher reached outside a C-ABI call
+    static const Tuning process_default = [] { Tuning t; char e[8]; (void)tuning_parse(getenv("DCE_TUNE"), t, e, (int)sizeof e); return t; }();   // a launcher reached outside a C-ABI call
     return process_default;
 }
 
@@ -93,9 +102,11 @@ const Tuning& tune()
 namespace {
 
 // roctx ranges around the entry points of the path, so that a profile of a host program (rocprofv3 --marker-trace, or any tool that
-// listens to roctx) shows one named range per call next to the kernels it launched.  The marker library is bound at run time --
-// librocprofiler-sdk-roctx first (what rocprofv3 listens to), the older libroctx64 otherwise -- and only if it can be: libdce.so has
-// no link-time dependency on it.  DCE_ROCTX=0 switches the ranges off; without a tool attached a push/pop pair costs ~20 ns.
+// listens to roctx) shows one named range per call next to the kernels it launched.  libdce.so has no link-time dependency on a marker
+// library and by default brings none into the process: it binds to one only if something else -- the tool, the application -- has
+// ALREADY loaded it (RTLD_NOLOAD), with local scope (its symbols do not enter the global namespace next to a torch wheel's own copy).
+// DCE_ROCTX=1 loads it (librocprofiler-sdk-roctx first: what rocprofv3 listens to; the older libroctx64 otherwise), DCE_ROCTX=0 switches
+// the ranges off.  Resolved once, at the first dce_create; without a tool attached a push/pop pair costs ~20 ns.
 struct Roctx {
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
@@ -103,8 +114,9 @@ struct Roctx {
     {
         const char* e = getenv("DCE_ROCTX");
         if (e && atoi(e) == 0) return;
+        const int how = RTLD_NOW | RTLD_LOCAL | ((e && atoi(e) != 0) ? 0 : RTLD_NOLOAD);
         for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
-            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            void* h = dlopen(name, how);
             if (!h) continue;
             push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
             pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
@@ -156,86 +168,227 @@ int drain_spans(dce_ctx* c)
     return DCE_OK;
 }
 
+// DCE_FP32_SPLIT's range guard, static half (dce_kernels.h GuardArgs has the why).  For inputs |x| <= X every activation of layer l is
+// bounded by  gain[l] X + offs[l]  with  gain[l] = gain[l-1] S_l,  offs[l] = offs[l-1] S_l + max|b_l|,  S_l = max over outputs of the
+// sum of |w| (ReLU and MaxPool do not raise a bound).  The operands the kernels split are the input, the four conv layers' outputs
+// (the last one = the features) and the weights of conv1..4 and fc.0: all must stay below LIM = 2^126 (bf16's largest finite number
+// is 2^128 - 2^120; the margin covers the accumulators' rounding), so x_hi = min_l (LIM - offs[l]) / gain[l].  A z-scored window
+// reaches |z| <= (n-1)/sqrt(n) = 12.166 at n = 150 (one sample against 149 equal ones), so a checkpoint whose x_hi is below that is
+// REFUSED: the mode then runs the DCE_FP32 kernels for every call and says so (dce_last_plan, dce_split_guard_info).  The small side:
+// a term below 2^-126 may be flushed by the matrix pipe; a layer whose largest |w| is below 2^-40, or a window whose largest |x| is,
+// puts whole operands within 2^86 of that floor, where the third terms (2^-16 .. 2^-24 of a value) of the layers behind it can reach it --
+// such a checkpoint is refused, such a window takes the fp32 kernels.  (Activation scales inside the net are bounded from below only
+// through these two; single tiny weights or samples beside ordinary ones lose nothing that the fp32 sum would keep.)
+void compute_split_guard(dce_ctx* c)
+{
+    dce_ctx::SplitGuard& g = c->guard;
+    g = dce_ctx::SplitGuard{};
+    g.x_hi = FLT_MAX; g.x_lo = 0.f;
+    if (!c->tuning.split_guard) { g.reason = "guard switched off (split_guard=0)"; return; }
+    const double LIM = std::ldexp(1.0, 126), SMALL = std::ldexp(1.0, -40), ZMAX = 149.0 / std::sqrt(150.0);
+    static const int rows[6] = {64, 64, 128, 128, FC1, FC2}, cols[6] = {54 * 3, 64 * 3, 64 * 3, 128 * 3, FEAT, FC1};
+    static const char* names[6] = {"block1.0", "block1.2", "block2.0", "block2.2", "fc.0", "fc.3"};
+    double gain = 1.0, offs = 0.0, x_hi = LIM;
+    char msg[256];
+    for (int l = 0; l < 6; ++l) {
+        const float* w = c->host_w[l < 4 ? 2 * l : 8 + 2 * (l - 4)].data();
+        const float* b = c->host_w[l < 4 ? 2 * l + 1 : 9 + 2 * (l - 4)].data();
+        double smax = 0.0, wmax = 0.0, bmax = 0.0;
+        bool finite = true;
+        for (int o = 0; o < rows[l]; ++o) {
+            double sum = 0.0;
+            for (int k = 0; k < cols[l]; ++k) { const double a = std::fabs((double)w[(size_t)o * cols[l] + k]); sum += a; if (a > wmax) wmax = a; }
+            finite = finite && std::isfinite(sum) && std::isfinite((double)b[o]);
+            if (sum > smax) smax = sum;
+            if (std::fabs((double)b[o]) > bmax) bmax = std::fabs((double)b[o]);
+        }
+        gain *= smax; offs = offs * smax + bmax;
+        g.gain[l] = gain; g.offs[l] = offs;
+        if (l > 4) continue;                                          // fc.3 runs on fp32 operands: its row is information only
+        if (!finite || !std::isfinite(gain) || !std::isfinite(offs)) { snprintf(msg, sizeof msg, "%s holds a non-finite weight or its bound overflows", names[l]); g.refused = true; g.reason = msg; break; }
+        if (wmax >= LIM) { snprintf(msg, sizeof msg, "%s: largest |w| %.3g reaches bf16's range limit", names[l], wmax); g.refused = true; g.reason = msg; break; }
+        if (wmax < SMALL) { snprintf(msg, sizeof msg, "%s: largest |w| %.3g is below 2^-40 (third terms of the split near the subnormal range)", names[l], wmax); g.refused = true; g.reason = msg; break; }
+        if (l == 4) continue;                                         // fc.0's OUTPUT is not split
+        if (offs >= LIM) { snprintf(msg, sizeof msg, "%s: activation bound %.3g reaches bf16's range limit whatever the input", names[l], offs); g.refused = true; g.reason = msg; break; }
+        if (gain > 0.0 && (LIM - offs) / gain < x_hi) x_hi = (LIM - offs) / gain;
+    }
+    if (!g.refused && x_hi < ZMAX * (1.0 + 1e-6)) {
+        snprintf(msg, sizeof msg, "a z-scored window (|z| <= %.3f) can drive a layer's activations to %.3g: inputs are safe only up to %.3g", ZMAX, LIM, x_hi);
+        g.refused = true; g.reason = msg;
+    }
+    if (g.refused) { g.x_hi = 0.f; return; }
+    float xf = x_hi >= (double)FLT_MAX ? FLT_MAX : (float)x_hi;
+    if ((double)xf > x_hi) xf = std::nextafterf(xf, 0.f);
+    g.x_hi = xf; g.x_lo = (float)SMALL;
+    g.reason = "ok";
+}
+
+// The gated DCE_FP32 fallback behind a guarded DCE_FP32_SPLIT launch: binds the gate for the launchers and a tuning without the
+// small-batch kernel families and row cuts (the gated kernels: conv_wino2, tile / phased GEMMs, fused fc.3, combine, tail).
+struct GateScope {
+    dce_ctx* c; TuningScope ts; std::vector<const char*>* plan;
+    explicit GateScope(dce_ctx* c_) : c(c_), ts(&c_->gate_tuning), plan(t_plan)
+    { c->gate_on = true; t_gate = Gate{c->d_guard, c->guard_gen, c->d_guard + 2}; t_plan = nullptr; }
+    ~GateScope() { c->gate_on = false; t_gate = Gate{}; t_plan = plan; }
+};
+
+// ---- The plan of one chunk: which kernel family runs each stage of the path
+//          conv stack (z-score + conv1..4)  ->  fc.0  ->  fc.3 (+ fc.6 chunk sums)  ->  fc.6 + argmax + contact bits.
+// choose_plan() is the ONE place that turns (precision, entry, chunk size, taps, switches) into that choice; run_chunk() executes it.
+// Inside a family the launchers pick the kernel by size (launch_conv_wino: quarter / half / one / two windows per workgroup;
+// launch_fc_gemm: GEMV / four-range / chain / tile / phased), all of one family bit-identical.
+//
+//   precision     windows per chunk              conv stack                       fc.0                      fc.3 / fc.6
+//   DCE_FP32      any                            conv_wino* (fp32 MFMA)           fc_* fp32                 fused 128x64 + combine (one round of tiles) | fc_* fp32 + tail
+//   DCE_BF16_FC   any                            conv_x2_bf16[_permk] (two-term)  bf16 stream / tile / phased  fused bf16 + combine | bf16 + tail
+//   DCE_FP32_SPLIT  < x3_conv_min (128)          = DCE_FP32
+//                 .. < fc.0's 192 tiles (2817)   conv_x3_f32 (three-term)         fc_* fp32                 = DCE_FP32
+//                 >= 2817                        conv_x3[_permk] -> three planes  fc_x3_256x128             = DCE_FP32
+//                 (range guard refused the checkpoint, or -- behind the sequence above -- a window of the launch left the guarded
+//                  range: the DCE_FP32 row, gated on the device word the conv kernel raised)
+enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16 };
+enum class Fc0 { F32, Gemv, X3, Bf16 };
+enum class Fc3 { F32, Gemv, Fused, Bf16, FusedBf16 };
+struct Plan {
+    Conv conv; int permk;                 // permk: features (and fc.0's weights) in the K order t' * 128 + c; 2: from persistent workgroups (experiments)
+    Fc0 fc0; bool split3;                 // split3: fp32 features split by a kernel of their own in front of fc_gemm_x3 (taps, x3_unfused)
+    Fc3 fc3; int64_t fused_rows;          // rows the fused fc.3 + fc.6 kernel takes (whole rounds); the rest goes to the chain kernel + tail
+    bool guarded;                         // DCE_FP32_SPLIT on pre-normalised windows: the conv kernel checks every window's range (SplitGuard)
+};
+
+Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
+{
+    const Tuning& tu = tune();                                        // (bound by run_chunk: the context's switches, or their gated form)
+    const bool wino = !(DCE_EXPERIMENTS && tu.conv_direct);
+    const bool online = c->src_row_dev != nullptr;                    // the online graph: the window start lives in device memory
+    Plan p{Conv::WinoF32, 0, Fc0::F32, false, Fc3::F32, 0, false};
+    if (c->precision == DCE_BF16_FC) {
+        const bool x3c = tu.x3_conv && wino && n >= tu.x3_bf16_min && (!online || zscore);
+        const bool pair = DCE_EXPERIMENTS && tu.x3_conv && tu.x3_pair && wino && !online && !c->want_feat && n >= tu.x3_pair_min;
+        p.conv = pair ? Conv::PairBf16 : x3c ? Conv::X2Bf16 : Conv::WinoBf16;
+        p.permk = pair ? 1 : (x3c && tu.x3_permk && !c->want_feat && c->fc1w_bf16p) ? ((DCE_EXPERIMENTS && tu.x3_persist && n >= tu.x3_persist_min) ? 2 : 1) : 0;
+        p.fc0 = Fc0::Bf16;
+        p.fc3 = fc23_fused_ok(n, 1) ? Fc3::FusedBf16 : Fc3::Bf16;
+        p.fused_rows = n;
+        return p;
+    }
+    const bool split = c->precision == DCE_FP32_SPLIT && !c->guard.refused && !c->gate_on;
+    // DCE_FP32_SPLIT at a chip-filling batch: the conv stack writes the features straight as three bf16 planes (unless a tap wants
+    // them in fp32: then a kernel of its own splits them)
+    const bool x3 = split && fc_gemm_x3_ok(n, FC1, FEAT);
+    const bool fused = x3 && wino && !c->want_feat && !tu.x3_unfused;
+    const bool pair = DCE_EXPERIMENTS && fused && tu.x3_conv && tu.x3_pair && !online && n >= tu.x3_pair_min;
+    if (pair) { p.conv = Conv::PairPlanes; p.permk = 1; }
+    else if (fused && tu.x3_conv && !online) {
+        p.conv = Conv::X3Planes;
+        p.permk = (tu.x3_permk && c->fc1w_x3p) ? ((DCE_EXPERIMENTS && tu.x3_persist && n >= tu.x3_persist_min) ? 2 : 1) : 0;
+    } else if (fused) p.conv = Conv::WinoPlanes;
+    else if (split && !x3 && tu.x3_conv && wino && !online && !c->want_feat && n >= tu.x3_conv_min) p.conv = Conv::X3F32;   // mid-size batch: three-term conv stack, fp32 FC kernels
+    p.guarded = tu.split_guard && !zscore && (p.conv == Conv::X3Planes || p.conv == Conv::X3F32);     // (the A/B routes -- Winograd stack + split, taps -- carry the static guard only)
+    // a handful of windows (online mode, batch_size 1): the weights streamed through all CUs (from 9 windows up launch_fc_gemm
+    // picks the four-range / chain kernels instead); same bits as the GEMMs
+    const bool gemv = tu.gemv && !c->gate_on && n <= FC_GEMV_MAX_M && !fc_split_ok(n, FC1, FEAT) && !fc_gemm_chain_ok(n, FC1, FEAT);
+    p.fc0 = x3 ? Fc0::X3 : gemv ? Fc0::Gemv : Fc0::F32;
+    p.split3 = x3 && !fused;
+    p.fc3 = gemv ? Fc3::Gemv : Fc3::F32;
+    if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1) && !fc_split_ok(n, FC2, FC1)) {
+        // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU unless a tap asks for
+        // it); one small kernel adds them up.  Same summation tree as the tail kernel.  The fused kernel runs whole rounds of 256
+        // tiles = 4096 windows: a batch that ends up to 2048 windows past a round gives that remainder to the chain kernel + tail
+        // (same bits, rows are independent) instead of paying a full round for it.
+        const int64_t rest = n % 4096;
+        p.fc3 = Fc3::Fused;
+        p.fused_rows = (tu.gemm_peel && !c->gate_on && n > 4096 && rest && (rest <= 8 || fc_split_ok(rest, FC2, FC1) || fc_gemm_chain_ok(rest, FC2, FC1))) ? n - rest : n;
+    }
+    return p;
+}
+
+// fc.0's three planes in the reference's K order, for the routes that do not take the conv kernels' order t' * 128 + c (feature taps,
+// x3_unfused, x3_conv=0, x3_permk=0): 58 MB that the product route never reads, so they are split and uploaded on first use
+int ensure_fc1w_x3(dce_ctx* c)
+{
+    if (c->fc1w_x3) return DCE_OK;
+    const auto& v = c->host_w[8];
+    std::vector<unsigned short> planes(3 * v.size());
+    split3_host(v.data(), FC1, FEAT, planes.data());
+    HIP_TRY(c, hipMalloc(&c->fc1w_x3_own, planes.size() * sizeof(unsigned short)));
+    HIP_TRY(c, hipMemcpy(c->fc1w_x3_own, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    c->fc1w_x3 = c->fc1w_x3_own;
+    return DCE_OK;
+}
+
 // One chunk (n <= max_batch) of the path, everything on device.
 //   src: raw sequence rows (zscore=1) or pre-normalised windows (zscore=0)
+int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
+             float* logits, int32_t* pred, uint8_t* contacts, uint8_t* packed)
+{
+    const hipStream_t st = c->stream;
+    unsigned short* featb = reinterpret_cast<unsigned short*>(c->feat);
+    const bool wino = !(DCE_EXPERIMENTS && c->tuning.conv_direct);
+    auto conv_f32 = wino ? launch_conv_wino : launch_conv_stack;
+    const GuardArgs ga = p.guarded ? GuardArgs{c->d_guard, c->guard_gen, c->guard.x_hi, c->guard.x_lo} : GuardArgs{};
+    { Timer t(c, 0);
+      switch (p.conv) {
+      case Conv::WinoF32:    HIP_TRY(c, conv_f32(src, zscore, n, c->pk, c->feat, 0, st, c->src_row_dev)); break;
+      case Conv::WinoBf16:   HIP_TRY(c, conv_f32(src, zscore, n, c->pk, c->feat, 1, st, c->src_row_dev)); break;
+      case Conv::WinoPlanes: HIP_TRY(c, launch_conv_wino(src, zscore, n, c->pk, c->feat3, 2, st, c->src_row_dev)); break;
+      case Conv::X3Planes:   HIP_TRY(c, launch_conv_x3(src, zscore, n, c->pkx3, c->feat3, st, p.permk, ga)); break;
+      case Conv::X3F32:      HIP_TRY(c, launch_conv_x3_f32(src, zscore, n, c->pkx3, c->feat, st, ga)); break;
+      case Conv::X2Bf16:     HIP_TRY(c, launch_conv_x3_bf16(src, zscore, n, c->pkx3, featb, st, p.permk, c->tuning.x3_bf16_terms, c->src_row_dev)); break;
+      case Conv::PairPlanes: HIP_TRY(c, launch_conv_x3p(src, zscore, n, c->pkx3, c->feat3, st)); break;
+      case Conv::PairBf16:   HIP_TRY(c, launch_conv_x3p_bf16(src, zscore, n, c->pkx3, featb, st)); break;
+      } }
+    { Timer t(c, 1);
+      switch (p.fc0) {
+      case Fc0::F32:  HIP_TRY(c, launch_fc_gemm(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, st)); break;
+      case Fc0::Gemv: HIP_TRY(c, launch_fc_gemv(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, st)); break;
+      case Fc0::X3:   // fc.0 on the bf16 matrix pipe with three-term operands (fc_gemm_x3.hip); everything behind it as in DCE_FP32
+          if (!p.permk) { const int rc = ensure_fc1w_x3(c); if (rc) return rc; }
+          if (p.split3) HIP_TRY(c, launch_split3(c->feat, c->feat3, n, FEAT, st));
+          HIP_TRY(c, launch_fc_gemm_x3(c->feat3, p.permk ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, st)); break;
+      case Fc0::Bf16: HIP_TRY(c, launch_fc_gemm_bf16(c->feat, p.permk ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, st)); break;
+      } }
+    const int64_t nf = p.fused_rows;
+    { Timer t(c, 2);
+      switch (p.fc3) {
+      case Fc3::F32:  HIP_TRY(c, launch_fc_gemm(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, st)); break;
+      case Fc3::Gemv: HIP_TRY(c, launch_fc_gemv(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, st)); break;
+      case Fc3::Bf16: HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, st)); break;
+      case Fc3::FusedBf16: HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
+      case Fc3::Fused:
+          HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, nf, st));
+          if (nf < n) HIP_TRY(c, (n - nf <= 8 ? launch_fc_gemv : launch_fc_gemm)(c->h1 + nf * FC1, c->fc2w, c->fc2b, c->h2 + nf * FC2, n - nf, FC2, FC1, 1, st));
+          break;
+      } }
+    { Timer t(c, 3);
+      if (p.fc3 == Fc3::Fused || p.fc3 == Fc3::FusedBf16) {
+          HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, st, packed));
+          if (nf < n) HIP_TRY(c, launch_fc3_tail(c->h2 + nf * FC2, c->fc3w, c->fc3b, n - nf, logits ? logits + nf * NCLS : nullptr, pred ? pred + nf : nullptr,
+                                                 contacts ? contacts + nf * 4 : nullptr, st, nullptr, 0, nullptr, packed ? packed + nf * PACKED_ROW : nullptr));
+      } else HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, st, c->done_flag, c->done_seq, c->seq_counter_dev, packed)); }
+    return DCE_OK;
+}
+
 int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
               float* logits, int32_t* pred, uint8_t* contacts, uint8_t* packed = nullptr)
 {
     TuningScope tuning_scope(&c->tuning);
     struct PlanScope { explicit PlanScope(std::vector<const char*>* p) { p->clear(); t_plan = p; } ~PlanScope() { t_plan = nullptr; } } plan_scope(&c->plan);
     c->prof = c->prof_period > 0 && (c->prof_tick++ % c->prof_period) == 0;
-    if (c->precision == DCE_BF16_FC) {
-        // conv stack in fp32 -> bf16 features; fc.0 / fc.3 on bf16 MFMA with fp32 accumulate
-        // (feat and h1 scratch hold bf16 here); fc.6 + argmax stay fp32
-        // chip-filling batch: two windows per workgroup, a phase apart (conv_x3p.hip); its features -- and the fc.0 weights used
-        // behind it -- are in the K order t' * 128 + c.  A tap of the features keeps the reference's flatten order (conv_x3.hip).
-        const bool pair = c->tuning.x3_conv && c->tuning.x3_pair && c->winograd && !c->src_row_dev && !c->want_feat && n >= c->tuning.x3_pair_min;
-        const bool x3c = c->tuning.x3_conv && c->winograd && n >= c->tuning.x3_bf16_min && (!c->src_row_dev || zscore);     // conv_x3.hip (online pushes: its z-score entry reads the window start from device memory)
-        const bool permk = x3c && c->tuning.x3_permk && !c->want_feat && c->fc1w_bf16p != nullptr;                 // ... with its features in the K order t' * 128 + c
-        { Timer t(c, 0);
-          // from 128 windows the conv stack runs on three-term bf16 operands (conv_x3.hip: fp32-grade results at 1.27x the
-          // fp32 Winograd kernel's rate), its features rounded to bf16 as the Winograd kernel's are; DCE_X3_CONV=0 switches back
-          if (pair) HIP_TRY(c, launch_conv_x3p_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream));
-          else if (x3c) HIP_TRY(c, launch_conv_x3_bf16(src, zscore, n, c->pkx3, reinterpret_cast<unsigned short*>(c->feat), c->stream, permk ? (c->tuning.x3_persist && n >= c->tuning.x3_persist_min ? 2 : 1) : 0, c->tuning.x3_bf16_terms, c->src_row_dev));
-          else HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 1, c->stream, c->src_row_dev)); }
-        { Timer t(c, 1); HIP_TRY(c, launch_fc_gemm_bf16(c->feat, (pair || permk) ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, c->stream)); }
-        if (fc23_fused_ok(n, 1)) {
-            { Timer t(c, 2); HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch,
-                                                          c->want_h2 ? c->h2 : nullptr, n, c->stream)); }
-            { Timer t(c, 3); HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, n, logits, pred, contacts, c->stream, packed)); }
-            if (c->spans.size() > 4096) return drain_spans(c);
-            return DCE_OK;
-        }
-        { Timer t(c, 2); HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, c->stream)); }
-    } else {
-        // DCE_FP32_SPLIT at a chip-filling batch: the conv stack writes the features straight as three bf16 planes
-        // (unless a tap wants them in fp32, or the direct-form conv kernel is selected: then a kernel of its own splits them)
-        const bool x3 = c->precision == DCE_FP32_SPLIT && fc_gemm_x3_ok(n, FC1, FEAT);
-        const bool x3_fused = x3 && c->winograd && !c->want_feat && !c->tuning.x3_unfused;
-        const bool pair = x3_fused && c->tuning.x3_conv && c->tuning.x3_pair && !c->src_row_dev && n >= c->tuning.x3_pair_min;     // conv_x3p.hip (K order t' * 128 + c)
-        const bool permk = x3_fused && c->tuning.x3_conv && !c->src_row_dev && c->tuning.x3_permk && c->fc1w_x3p != nullptr;        // conv_x3.hip, features straight out in that order
-        { Timer t(c, 0);
-          if (pair) HIP_TRY(c, launch_conv_x3p(src, zscore, n, c->pkx3, c->feat3, c->stream));
-          else if (x3_fused && c->tuning.x3_conv && !c->src_row_dev) HIP_TRY(c, launch_conv_x3(src, zscore, n, c->pkx3, c->feat3, c->stream, permk ? (c->tuning.x3_persist && n >= c->tuning.x3_persist_min ? 2 : 1) : 0));
-          else if (x3_fused) HIP_TRY(c, launch_conv_wino(src, zscore, n, c->pk, c->feat3, 2, c->stream, c->src_row_dev));
-          else if (c->precision == DCE_FP32_SPLIT && !x3 && c->tuning.x3_conv && c->winograd && !c->src_row_dev && !c->want_feat && n >= c->tuning.x3_conv_min)
-              HIP_TRY(c, launch_conv_x3_f32(src, zscore, n, c->pkx3, c->feat, c->stream));      // mid-size batch: three-term conv stack, fp32 FC kernels
-          else HIP_TRY(c, (c->winograd ? launch_conv_wino : launch_conv_stack)(src, zscore, n, c->pk, c->feat, 0, c->stream, c->src_row_dev)); }
-        // a handful of windows (online mode): stream the weights through all CUs; same bits as the GEMM
-        // (from 9 windows up launch_fc_gemm picks the MFMA chain kernel of fc_gemm_chain.hip instead)
-        auto fc = (c->gemv && n <= FC_GEMV_MAX_M && !fc_split_ok(n, FC1, FEAT) && !fc_gemm_chain_ok(n, FC1, FEAT)) ? launch_fc_gemv : launch_fc_gemm;
-        if (x3) {
-            // fc.0 on the bf16 matrix pipe with three-term operands (fc_gemm_x3.hip); everything else as in DCE_FP32
-            Timer t(c, 1);
-            if (!x3_fused) HIP_TRY(c, launch_split3(c->feat, c->feat3, n, FEAT, c->stream));
-            HIP_TRY(c, launch_fc_gemm_x3(c->feat3, (pair || permk) ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream));
-        } else
-        { Timer t(c, 1); HIP_TRY(c, fc(c->feat, c->fc1w, c->fc1b, c->h1, n, FC1, FEAT, 1, c->stream)); }
-        if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1) && !fc_split_ok(n, FC2, FC1)) {
-            // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU
-            // unless a tap asks for it); one small kernel adds them up.  Same summation tree as the tail kernel.
-            // The fused kernel runs whole rounds of 256 tiles = 4096 windows: a batch that ends up to 2048 windows
-            // past a round gives that remainder to the chain kernel + tail (same bits, rows are independent) instead
-            // of paying a full round for it.
-            const bool peel = c->tuning.gemm_peel;
-            const int64_t rest = n % 4096, nf = (peel && n > 4096 && rest && (rest <= 8 || fc_split_ok(rest, FC2, FC1) || fc_gemm_chain_ok(rest, FC2, FC1))) ? n - rest : n;
-            { Timer t(c, 2);
-              HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch,
-                                           c->want_h2 ? c->h2 : nullptr, nf, c->stream));
-              if (nf < n) HIP_TRY(c, (n - nf <= 8 ? launch_fc_gemv : launch_fc_gemm)(c->h1 + nf * FC1, c->fc2w, c->fc2b, c->h2 + nf * FC2, n - nf, FC2, FC1, 1, c->stream)); }
-            { Timer t(c, 3);
-              HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, c->stream, packed));
-              if (nf < n) HIP_TRY(c, launch_fc3_tail(c->h2 + nf * FC2, c->fc3w, c->fc3b, n - nf, logits ? logits + nf * NCLS : nullptr,
-                                                     pred ? pred + nf : nullptr, contacts ? contacts + nf * 4 : nullptr, c->stream,
-                                                     nullptr, 0, nullptr, packed ? packed + nf * PACKED_ROW : nullptr)); }
-            if (c->spans.size() > 4096) return drain_spans(c);
-            return DCE_OK;
-        }
-        { Timer t(c, 2); HIP_TRY(c, fc(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, c->stream)); }
+    if (c->precision == DCE_FP32_SPLIT && c->guard.refused) plan_note("split_guard_refused");
+    const Plan p = choose_plan(c, zscore, n);
+    if (p.guarded) { ++c->guard_gen; ++c->guard_launches; }                                     // a generation per guarded launch: no reset of the device word between them
+    int rc = run_plan(c, p, src, zscore, n, logits, pred, contacts, packed);
+    if (rc == DCE_OK && p.guarded) {
+        // A window of this launch outside the guarded range has written this launch's generation to the guard word: the DCE_FP32
+        // kernel sequence behind it runs then (every workgroup of it reads the word first and leaves when it holds another value)
+        // and overwrites the launch's results.  Nothing comes back to the host: device-pointer callers stay asynchronous.
+        plan_note("gated_fp32_fallback");                            // (its kernels are not listed: they run only when the gate opens)
+        GateScope gate(c);
+        rc = run_plan(c, choose_plan(c, zscore, n), src, zscore, n, logits, pred, contacts, packed);
     }
-    { Timer t(c, 3); HIP_TRY(c, launch_fc3_tail(c->h2, c->fc3w, c->fc3b, n, logits, pred, contacts, c->stream, c->done_flag, c->done_seq, c->seq_counter_dev, packed)); }
-    if (c->spans.size() > 4096) return drain_spans(c);
-    return DCE_OK;
+    if (rc == DCE_OK && c->spans.size() > 4096) rc = drain_spans(c);
+    return rc;
 }
 
 int ensure_in(dce_ctx* c, size_t bytes)
@@ -395,7 +548,9 @@ int dce_device_count(void)
     return n;
 }
 
-int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
+int dce_create(dce_ctx** out, int device_id, int64_t max_batch) { return dce_create_ex(out, device_id, max_batch, nullptr); }
+
+int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* options)
 {
     if (!out || max_batch <= 0 || device_id < 0) return fail(nullptr, DCE_ERR_ARG, "dce_create: bad argument");
     *out = nullptr;
@@ -409,9 +564,16 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     if (!c) return fail(nullptr, DCE_ERR_NOMEM, "out of host memory");
     c->device = device_id;
     c->max_batch = max_batch;
-    c->tuning = tuning_from_env();
-    if (const char* e = getenv("DCE_CONV")) c->winograd = strcmp(e, "direct") != 0;
-    if (const char* e = getenv("DCE_SMALL_BATCH")) c->gemv = strcmp(e, "gemm") != 0;
+    {   // the A/B switches: the option string, else DCE_TUNE, over the defaults (one table: kTuneKeys)
+        char msg[256];
+        if (!tuning_parse(options ? options : getenv("DCE_TUNE"), c->tuning, msg, (int)sizeof msg)) {
+            delete c;
+            return fail(nullptr, DCE_ERR_ARG, "dce_create: %s", msg);
+        }
+        Tuning& g = c->gate_tuning = c->tuning;                       // the gated DCE_FP32 fallback: two-window conv kernel, tile / phased GEMMs only
+        g.gemm_peel = g.conv_peel = false; g.gemv = false;
+        g.split_min = 1; g.split_max = 0; g.chain_min = 1; g.chain_max = 0; g.chain_max3 = 0; g.wino1_max = 0;
+    }
 #define CREATE_TRY(expr)                                                                        \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                        \
         fail(nullptr, DCE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));              \
@@ -420,7 +582,10 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     CREATE_TRY(guard.err);
     CREATE_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    (void)roctx();                                       // the marker library, if a tool brought one: resolved here, not on the first hot call
+#if DCE_EXPERIMENTS
     CREATE_TRY(init_conv_stack());
+#endif
     CREATE_TRY(init_conv_wino());
     CREATE_TRY(init_fc_gemm());
     CREATE_TRY(init_fc_gemm_x3());
@@ -430,6 +595,8 @@ int dce_create(dce_ctx** out, int device_id, int64_t max_batch)
     CREATE_TRY(hipMalloc(&c->h1, (size_t)max_batch * FC1 * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h2, (size_t)max_batch * FC2 * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->part, (size_t)max_batch * 8 * NCLS * sizeof(float)));
+    CREATE_TRY(hipMalloc(&c->d_guard, 4 * sizeof(unsigned)));
+    CREATE_TRY(hipMemset(c->d_guard, 0, 4 * sizeof(unsigned)));
 #undef CREATE_TRY
     *out = c;
     return DCE_OK;
@@ -451,7 +618,7 @@ void dce_destroy(dce_ctx* c)
     if (c->xfer_stream) { hipStreamSynchronize(c->xfer_stream); hipStreamDestroy(c->xfer_stream); }
     for (auto& slot : c->ring_ev) for (auto e : slot) if (e) hipEventDestroy(e);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->feat3); hipFree(c->h1); hipFree(c->h2); hipFree(c->part);
-    hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
+    hipFree(c->d_guard); hipFree(c->fc1w_x3_own); hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
     if (c->online_exec) hipGraphExecDestroy(c->online_exec);
     if (c->online_graph) hipGraphDestroy(c->online_graph);
     hipFree(c->d_ring); hipFree(c->d_online_state);
@@ -514,8 +681,12 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     auto reserve = [&](size_t floats) { size_t off = (img.size() + 63) & ~size_t(63); img.resize(off + floats); return off; };
     size_t off_w[4], off_ww[4], off_b[4];
     for (int l = 0; l < 4; ++l) {
-        off_w[l] = reserve(conv_pack_floats(l));
+#if DCE_EXPERIMENTS
+        off_w[l] = reserve(conv_pack_floats(l));                      // direct-form pack (conv_stack.hip: experiments build only)
         conv_pack_host(l, c->host_w[2 * l].data(), img.data() + off_w[l]);
+#else
+        off_w[l] = 0;
+#endif
         off_ww[l] = reserve(conv_wino_pack_floats(l));
         conv_wino_pack_host(l, c->host_w[2 * l].data(), img.data() + off_ww[l]);
         off_b[l] = reserve(c->host_w[2 * l + 1].size());
@@ -560,8 +731,10 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     if (precision == DCE_FP32_SPLIT) {
         // fc.0's weights as three bf16 planes [3][2048][4736]: w = w1 + w2 + w3 exactly
         const auto& v = c->host_w[8];
-        off_x3 = reserve((3 * v.size() + 1) / 2);
-        split3_host(v.data(), FC1, FEAT, reinterpret_cast<unsigned short*>(img.data() + off_x3));
+        if (!want_pair) {                                 // (with the permuted copy below in use, the reference-order planes -- taps, the A/B routes -- are made on first use: ensure_fc1w_x3)
+            off_x3 = reserve((3 * v.size() + 1) / 2);
+            split3_host(v.data(), FC1, FEAT, reinterpret_cast<unsigned short*>(img.data() + off_x3));
+        }
         if (want_pair) {
             off_x3p = reserve((3 * v.size() + 1) / 2);
             split3_host(w1p.data(), FC1, FEAT, reinterpret_cast<unsigned short*>(img.data() + off_x3p));
@@ -572,7 +745,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     HIP_TRY(c, hipMalloc(&c->d_weights, img.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
     for (int l = 0; l < 4; ++l) {
-        c->pk.w[l] = c->d_weights + off_w[l]; c->pk.ww[l] = c->d_weights + off_ww[l];
+        c->pk.w[l] = DCE_EXPERIMENTS ? c->d_weights + off_w[l] : nullptr; c->pk.ww[l] = c->d_weights + off_ww[l];
         c->pk.b[l] = c->d_weights + off_b[l];
     }
     c->fc1w = c->d_weights + off_fc[0]; c->fc1b = c->d_weights + off_fc[1];
@@ -585,9 +758,12 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         c->pkx3.w[l] = want_cx ? reinterpret_cast<const unsigned short*>(c->d_weights + off_cx[l]) : nullptr;
         c->pkx3.b[l] = c->pk.b[l];
     }
-    c->fc1w_x3 = precision == DCE_FP32_SPLIT ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3) : nullptr;
+    if (c->fc1w_x3_own) { HIP_TRY(c, hipFree(c->fc1w_x3_own)); c->fc1w_x3_own = nullptr; }
+    c->fc1w_x3 = precision == DCE_FP32_SPLIT && !want_pair ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3) : nullptr;
     c->fc1w_x3p = precision == DCE_FP32_SPLIT && want_pair ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3p) : nullptr;
     c->precision = precision;
+    c->guard = dce_ctx::SplitGuard{};
+    if (precision == DCE_FP32_SPLIT) compute_split_guard(c);
     c->finalized = true;
     return DCE_OK;
 }
@@ -845,15 +1021,14 @@ int online_enqueue(dce_ctx* c)
     return rc;
 }
 
-// DCE_ONLINE_GRAPH=1: capture online_enqueue once; later pushes are one hipGraphLaunch.  Opt-in:
+// online_graph=1: capture online_enqueue once; later pushes are one hipGraphLaunch.  Opt-in:
 // measured on MI355X / ROCm 7.2 (three alternating runs of tests/c/abi_client.c) the graph launch
 // costs 90.1 us per push against 89.1 us for the same five kernels launched one by one -- the
 // launches already hide behind the first kernel -- so plain launches are the default.  Any capture failure (e.g. a caller stream that cannot be captured)
 // leaves online_exec null and the push falls back to plain launches.
 void online_build_graph(dce_ctx* c)
 {
-    const char* want = getenv("DCE_ONLINE_GRAPH");
-    if (c->online_exec || !want || atoi(want) == 0) return;
+    if (c->online_exec || !c->tuning.online_graph) return;
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return; }
     const int rc = online_enqueue(c);
     hipGraph_t g = nullptr;
@@ -880,7 +1055,7 @@ int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pre
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_online_pin), PIN_FLOATS * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));   // polled by the host while a kernel writes it: must be coherent (fine-grained), whatever the defaults / HIP_HOST_COHERENT say
         memset(c->h_online_pin, 0, PIN_FLOATS * sizeof(float));
         // constant-parameter (graph) form needs the Winograd kernels' indirect window start
-        c->online_mode = (c->winograd && !getenv("DCE_ONLINE_DIRECT")) ? 1 : 0;
+        c->online_mode = (!(DCE_EXPERIMENTS && c->tuning.conv_direct) && !c->tuning.online_direct) ? 1 : 0;
     }
     float* hl = c->h_online_pin;
     int32_t* hp = reinterpret_cast<int32_t*>(c->h_online_pin + 16);
@@ -906,7 +1081,7 @@ int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pre
         if (c->online_exec) HIP_TRY(c, hipGraphLaunch(c->online_exec, c->stream));
         else if ((rc = online_enqueue(c))) return rc;
     } else {
-        // ---- plain launches with per-push parameters (direct-form conv, or DCE_ONLINE_DIRECT)
+        // ---- plain launches with per-push parameters (online_direct=1; the experiments build's direct-form conv)
         if (c->ring_rows == ONLINE_ROWS) {              // keep the last 149 rows, restart at the front
             HIP_TRY(c, hipMemcpyAsync(c->d_ring, c->d_ring + (ONLINE_ROWS - (WIN - 1)) * CH,
                                       (WIN - 1) * CH * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
@@ -931,6 +1106,27 @@ int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pre
     if (pred) memcpy(pred, hp, sizeof(int32_t));
     if (contacts) memcpy(contacts, hc, 4);
     return 1;
+}
+
+int dce_split_guard_info(dce_ctx* c, dce_split_guard* out)
+{
+    if (!c || !out) return DCE_ERR_ARG;
+    DEVICE_GUARD(c);
+    memset(out, 0, sizeof *out);
+    out->precision = c->precision;
+    out->enabled = c->finalized && c->precision == DCE_FP32_SPLIT && c->tuning.split_guard;
+    out->refused = c->guard.refused;
+    out->x_hi = c->guard.x_hi; out->x_lo = c->guard.x_lo;
+    out->z_max = (float)(149.0 / std::sqrt(150.0));
+    for (int l = 0; l < 6; ++l) { out->gain[l] = c->guard.gain[l]; out->offs[l] = c->guard.offs[l]; }
+    snprintf(out->reason, sizeof out->reason, "%s", c->guard.reason.c_str());
+    unsigned w[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(w, c->d_guard, sizeof w, hipMemcpyDeviceToHost));
+    out->guarded_launches = c->guard_launches;
+    out->windows_out_of_range = w[1];
+    out->fallbacks_run = w[2];
+    return DCE_OK;
 }
 
 int dce_profile_enable(dce_ctx* c, int on)

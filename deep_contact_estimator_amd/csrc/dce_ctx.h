@@ -26,9 +26,20 @@ struct dce_ctx {
     bool finalized = false;
     int precision = DCE_FP32;
     std::vector<const char*> plan;         // kernel families launched by the most recent kernel sequence (dce_last_plan)
-    dce::Tuning tuning;                    // the A/B switches as they stood in the environment at dce_create
-    bool winograd = true;                  // conv stack algorithm; DCE_CONV=direct selects the direct form
-    bool gemv = true;                      // FC layers of <= 32 windows as weight-streaming GEMV; DCE_SMALL_BATCH=gemm disables
+    dce::Tuning tuning;                    // the A/B switches: dce_create_ex's option string, else DCE_TUNE, over the defaults
+    dce::Tuning gate_tuning;               // ... the same without the small-batch kernel families and row cuts: what a gated DCE_FP32 fallback sequence runs
+
+    // DCE_FP32_SPLIT's range guard (dce_finalize_weights computes it; include/dce.h dce_split_guard_info)
+    struct SplitGuard {
+        bool refused = false;              // the checkpoint itself leaves the guarded range: the mode runs the DCE_FP32 kernels
+        float x_hi = 0.f, x_lo = 0.f;      // a pre-normalised window passes if max|x| <= x_hi and (max|x| >= x_lo or the window is all zero)
+        double gain[6] = {}, offs[6] = {}; // max|activation of layer l| <= gain[l] X + offs[l] for inputs |x| <= X (conv1..4, fc.0, fc.3)
+        std::string reason;
+    } guard;
+    unsigned* d_guard = nullptr;           // device: [0] generation of the last launch that saw a window out of range, [1] such windows so far, [2] gated fallback sequences that ran
+    unsigned guard_gen = 0;                // generation of the current guarded launch
+    unsigned guard_launches = 0;           // guarded launches so far
+    bool gate_on = false;                  // the kernel sequence being enqueued is the gated DCE_FP32 fallback
 
     float* d_weights = nullptr;            // one allocation: conv packs, biases, fc weights
     dce::ConvPack pk{};
@@ -40,7 +51,8 @@ struct dce_ctx {
     float *feat = nullptr, *h1 = nullptr, *h2 = nullptr;   // scratch, max_batch rows each
     unsigned short* feat3 = nullptr;                        // DCE_FP32_SPLIT: the features as three bf16 planes [3][n][4736]
     dce::ConvPackX3 pkx3{};                                      // ... and the conv weights, packed per lane (conv_x3.hip)
-    const unsigned short* fc1w_x3 = nullptr;                // ... and fc.0's weights, [3][2048][4736] (inside d_weights)
+    const unsigned short* fc1w_x3 = nullptr;                // ... and fc.0's weights, [3][2048][4736] (inside d_weights, or fc1w_x3_own: made on first use when the permuted copy is the one in use)
+    unsigned short* fc1w_x3_own = nullptr;
     const unsigned short* fc1w_x3p = nullptr;               // ... and the same with the K axis in conv_x3p.hip's feature order
     float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
     bool want_feat = false;                                // dce_forward_taps: DCE_FP32_SPLIT keeps the fp32 features (split by a kernel of its own)

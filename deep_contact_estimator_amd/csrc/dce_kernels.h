@@ -18,40 +18,49 @@ namespace dce {
 // ---- geometry of contact_cnn (reference src/contact_cnn.py:8-58) ------------------------
 constexpr int WIN = 150, CH = 54, NCLS = 16, FEAT = 4736, FC1 = 2048, FC2 = 512;
 
-// ---- A/B switches: read from the environment ONCE PER CONTEXT in dce_create and handed to the
-// launchers through a thread-local pointer that every C-ABI entry point sets for the duration of the call, so that two
-// contexts of one process (tests, tools/race_screen.py) can run different kernel variants side by side.
+// ---- A/B switches.  ONE table (kTuneKeys, dce_api.hip) names every switch; a context takes its values from the
+// option string of dce_create_ex (or, without one, the environment variable DCE_TUNE) -- "key=value,key=value" -- and hands them to the
+// launchers through a thread-local pointer that every C-ABI entry point sets for the duration of the call, so that two contexts of
+// one process (tests, tools/race_screen.py) can run different kernel variants side by side.  Keys of variants that exist in the
+// experiments build only are accepted and ignored by the product library; an unknown key fails dce_create.
 struct Tuning {
-    bool gemm_tile = false, gemm_lockstep = false;          // DCE_GEMM=tile | lockstep   (default: phased)
-    bool gemm_ki = false;                                   // DCE_GEMM_KI=1 (experiments build): the bf16 256 x 128 tile on fc_gemm_ki_kernel (the two wave groups deal the K-tiles out between them: math phases twice as long; same launch time at a lower clock)
-    bool gemm_pipe = false;                                 // DCE_GEMM=pipe (experiments build): the bf16 256 x 128 tile on fc_gemm_pipe_kernel (LDS counters instead of workgroup barriers in the K loop; measured slower)
-    int phased_min_tiles = 192, phased_min_tiles1 = 128;    // DCE_PHASED_MIN_TILES, DCE_PHASED_MIN_TILES1
-    int phased_min = 1;                                     // DCE_GEMM_PHASED_MIN (2: only the 256x128 tile)
-    bool phased_cost = true;                                // DCE_PHASED_COST=0: tile minimum only, no rounds model
-    int phased_sn = 3;                                      // DCE_PHASED_SN: log2 of the super-tile's N extent
-    int fc23_mode = 0;                                      // DCE_FC23=split (1) | always (2)
-    bool gemm_peel = true, conv_peel = true;                // DCE_GEMM_PEEL=0, DCE_CONV_PEEL=0
-    bool bf16_stream = true;                                // DCE_BF16_STREAM=0: DCE_BF16_FC's fc.0 / fc.3 at <= 256 windows on the 64 x 64 tile GEMM (44 + 21 us per call) instead of fc_stream_bf16.hip
-    bool gemm_small_deep = true;                            // DCE_GEMM_SMALL=0
-    long long split_min = 9, split_max = 64;                 // DCE_SPLIT_MIN / DCE_SPLIT_MAX: windows served by the four-range MFMA kernel (fc_gemm_split.hip)
-    long long chain_min = 9, chain_max = 640, chain_max3 = 2048, chain_bn16_max = 64;   // DCE_CHAIN_*
-    long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // DCE_WINO1_MAX / DCE_WINOH_MAX / DCE_WINOQ_MAX (-1: kernel default)
-    bool wino1_w8 = true;                                   // DCE_WINO1_WAVES=4 -> false
-    bool one_per_cu = false, trace_wino1 = false;           // DCE_ONE_PER_CU, DCE_TRACE_WINO1 (trace builds)
-    bool x3_conv = true;                                    // DCE_X3_CONV=0: DCE_FP32_SPLIT keeps the fp32 Winograd conv stack (three-plane feature output) instead of conv_x3.hip (A/B)
-    long long x3_conv_min = 128;                            // DCE_X3_CONV_MIN: from this many windows the mode's conv stack runs on conv_x3.hip also BELOW the fc.0 threshold (fp32 features out)
-    bool x3_unfused = false;                                // DCE_X3_UNFUSED: fp32 features + split3 kernel instead of the conv kernel's three-plane output (A/B)
-    bool x3_permk = true;                                   // DCE_X3_PERMK=0: conv_x3.hip's features go through LDS into the reference's flatten order (A/B) instead of straight out in the order t' * 128 + c
-    long long x3_bf16_min = 1;                              // DCE_X3_BF16_MIN: DCE_BF16_FC's conv stack runs on conv_x3.hip from this many windows (default: always -- one window per workgroup is also the fastest form at batch 1: 18.7 us against 20.8 for the fp32 quarter-window kernel and 62 for the two-window kernel the mode used below 128 windows)
-    int x3_bf16_terms = 2;                                  // DCE_X3_BF16_TERMS=3: DCE_BF16_FC's conv stack on three-term operands (six MFMAs per product) as DCE_FP32_SPLIT's; default two terms (three MFMAs, ~17 significant bits ahead of the features' 8-bit rounding: same error against an fp64 evaluation, profiles/r4h_bf16_terms_audit.json; 308 -> 171 us per 4096 windows)
-    bool x3_persist = false;                                // DCE_X3_PERSIST=1 (experiments build): conv_x3.hip as persistent workgroups (two per CU) that request the next window's samples a layer ahead; measured 2-4 % slower
-    long long x3_persist_min = 1024;                        // DCE_X3_PERSIST_MIN: windows per launch from which they do
-    bool x3_pair = false;                                   // DCE_X3_PAIR=1: chip-filling batches on conv_x3p.hip (two windows per 8-wave workgroup; measured 5-9 % SLOWER than conv_x3.hip, kept for the record and the A/B) instead of conv_x3.hip
-    long long x3_pair_min = 1024;                           // DCE_X3_PAIR_MIN: windows per launch from which conv_x3p.hip runs
-    int x3_min_tiles = 192;                                 // DCE_X3_MIN_TILES: 256x128 tiles a launch needs for the split-bf16 fc.0 kernel
-    int conv4 = 0;                                          // DCE_CONV4=1: four row tiles per wave in the two-window conv kernel (A/B; slower)
+    // -- FC GEMMs at chip-filling sizes (fc_gemm_phased.hip)
+    bool gemm_tile = false;                                 // gemm_tile=1: round 1's tile kernels instead of the phased ones (bit-identical: the reference of test_phased_gemm_equals_tile_kernels)
+    int phased_min_tiles = 192, phased_min_tiles1 = 128;    // tiles a launch needs for the 256x128 / 128x64 phased tile
+    int phased_min = 1;                                     // 2: only the 256x128 tile
+    bool phased_cost = true;                                // 0: tile minimum only, no rounds model
+    int phased_sn = 3;                                      // log2 of the XCD super-tile's N extent
+    int fc23 = 0;                                           // 1: fc.3 never with the fused fc.6 chunk sums, 2: always
+    bool gemm_peel = true, conv_peel = true;                // 0: no row cuts of a batch past whole rounds of phased tiles / two-window conv workgroups
+    bool gemm_small_deep = true;                            // 0: 64x64 tile GEMM without the deep staging ring
+    // -- small and mid-size batches
+    bool gemv = true;                                       // 0: no weight-streaming GEMV for <= 8 windows
+    long long split_min = 9, split_max = 64;                // windows served by the four-range MFMA kernel (fc_gemm_split.hip)
+    long long chain_min = 9, chain_max = 640, chain_max3 = 2048, chain_bn16_max = 64;   // ... by the MFMA chain kernel (fc.0 / fc.3; 32x16 blocks up to)
+    long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // windows up to which the one-window / half-window / quarter-window conv kernels run (-1: kernel default 256 / 128 / 64)
+    bool wino1_w8 = true;                                   // 0: the four-wave predecessor of the one-window kernel
+    bool online_graph = false, online_direct = false;       // online pushes as ONE captured hipGraph launch / as plain launches with per-push parameters
+    // -- DCE_BF16_FC
+    bool bf16_stream = true;                                // 0: fc.0 / fc.3 at <= 256 windows on the 64x64 tile GEMM instead of fc_stream_bf16.hip
+    long long x3_bf16_min = 1;                              // windows from which the mode's conv stack runs on conv_x3.hip (below: the fp32 kernels, features rounded on the store)
+    int x3_bf16_terms = 2;                                  // 3: the mode's conv stack on three-term operands (six MFMAs per product) -- BASELINE configs[4] as written ("conv stays fp32"-grade)
+    // -- DCE_FP32_SPLIT
+    bool x3_conv = true;                                    // 0: keep the fp32 Winograd conv stack (three-plane feature store) instead of conv_x3.hip (both bf16-pipe precisions)
+    long long x3_conv_min = 128;                            // windows from which the conv stack runs on conv_x3.hip also below fc.0's threshold (fp32 features out)
+    int x3_min_tiles = 192;                                 // 256x128 tiles a launch needs for fc_gemm_x3.hip
+    bool x3_unfused = false;                                // 1: fp32 features + split3 kernel instead of the conv kernel's three-plane output
+    bool x3_permk = true;                                   // 0: conv_x3.hip's features through LDS in the reference's flatten order instead of straight out in the order t' * 128 + c
+    bool split_guard = true;                                // 0: no range guard (static bound at finalize, per-window exponent check + fp32 fallback): the round-4 behaviour, for the A/B and the audit
+    // -- experiments build only (ignored by the product library)
+    bool gemm_lockstep = false, gemm_pipe = false, gemm_ki = false;
+    int conv4 = 0;
+    bool x3_persist = false, x3_pair = false;
+    long long x3_persist_min = 1024, x3_pair_min = 1024;
+    bool conv_direct = false;                               // the direct-form conv stack of round 1 (conv_stack.hip)
+    bool one_per_cu = false, trace_wino1 = false;           // trace builds
 };
-Tuning tuning_from_env();
+// parses "key=value,..." over `t`; false + message on an unknown key or a malformed value
+bool tuning_parse(const char* spec, Tuning& t, char* err, int err_len);
 extern thread_local const Tuning* t_tuning;                  // the calling ctx's switches (nullptr: process defaults)
 const Tuning& tune();
 struct TuningScope {                                         // RAII: entry points bind their ctx's switches
@@ -59,6 +68,17 @@ struct TuningScope {                                         // RAII: entry poin
     explicit TuningScope(const Tuning* t) : prev(t_tuning) { t_tuning = t; }
     ~TuningScope() { t_tuning = prev; }
 };
+
+// ---- DCE_FP32_SPLIT's range guard.  A three-term split a = a1 + a2 + a3 is exact for |a| below bf16's largest finite number
+// (3.3895e38 < fp32's 3.4028e38: above it a1 rounds to Inf) and while a3 stays a normal number.  dce_finalize_weights bounds every
+// layer's activations for inputs |x| <= X (static: sums of |w|) and derives the largest safe X; z-scored windows are bounded by
+// construction (|z| <= 149 / sqrt(150)), pre-normalised windows are checked by the conv kernel's load stage, per window.  A launch that
+// saw a window outside [x_lo, x_hi] writes its generation to word[0]; the DCE_FP32 kernel sequence enqueued behind it is GATED on that
+// word: every workgroup of it reads the word first and returns unless it holds this launch's generation.
+struct GuardArgs { unsigned* word = nullptr; unsigned gen = 0; float x_hi = 0.f, x_lo = 0.f; };
+struct Gate { const unsigned* word = nullptr; unsigned gen = 0; unsigned* taken = nullptr; };
+extern thread_local Gate t_gate;                             // set around the gated fallback sequence; {} = no gate
+__device__ __forceinline__ bool gate_closed(const Gate& g) { return g.word != nullptr && *g.word != g.gen; }
 
 // ---- which kernels a call ran: every launcher notes the kernel family it picked; dce_last_plan returns the notes of
 // the ctx's most recent kernel sequence (tests assert that an A/B switch or a batch size really selected the kernel
@@ -164,9 +184,9 @@ void       conv_x3_pack_host(int layer, const float* w, unsigned short* out);
 hipError_t init_conv_x3();
 //   permk: the features leave straight from the accumulators in the K order k' = t' * 128 + c (no LDS staging, no barriers); fc.0
 //   behind it then takes weights whose K axis is permuted the same way (fc_perm_k_host)
-hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st, int permk = 0);
+hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st, int permk = 0, const GuardArgs& guard = GuardArgs{});
 hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat, hipStream_t st, int permk = 0, int terms = 3, const long long* src_row = nullptr);
-hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st);
+hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st, const GuardArgs& guard = GuardArgs{});
 hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3& pk, unsigned short* feat3, float* feat32,
                                const LayerTaps& taps, hipStream_t st);
 // The same stack for chip-filling batches (conv_x3p.hip): one persistent workgroup per CU, two windows a fixed three phases

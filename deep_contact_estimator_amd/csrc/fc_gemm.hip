@@ -64,9 +64,10 @@ template <int TM, int TN, bool BF16, bool OUT_BF16, int WGN = 2>
 __global__ __launch_bounds__(128 * WGN, WGN)
 void fc_gemm_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                     const float* __restrict__ bias, void* __restrict__ Cv,
-                    int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
+                    int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2, Gate gate = Gate{})
 {
     using Cfg = GemmCfg<TM, TN, WGN>;
+    if (gate_closed(gate)) return;                       // DCE_FP32_SPLIT's fallback sequence (dce_kernels.h Gate)
     constexpr int BM = Cfg::BM, BN = Cfg::BN, RPP = Cfg::RPP;
     constexpr int SA = BM / RPP, SB = BN / RPP;          // 16-B pieces staged per thread per K-tile
     constexpr int ES = BF16 ? 2 : 4;                     // element size
@@ -271,10 +272,11 @@ constexpr int GS_DEPTH = 4;
 __global__ __launch_bounds__(256, 2)
 void fc_gemm_small_kernel(const float* __restrict__ Af, const float* __restrict__ Wf,
                           const float* __restrict__ bias, float* __restrict__ C,
-                          int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
+                          int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2, Gate gate = Gate{})
 {
     using Cfg = GemmCfg<1, 1, 2>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, RPP = Cfg::RPP;
+    if (gate_closed(gate)) return;
     static_assert(BM / RPP == 2 && BN / RPP == 2 && KT_BYTES == 128, "two 16-byte pieces per operand per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
@@ -394,7 +396,7 @@ constexpr int TAIL_H2_LD = FC2 + 4;     // 516 floats: the 16 rows of a ds_read_
 constexpr int TAIL_PART_FLOATS = FC6_NCHUNK * TAIL_WINDOWS * NCLS;
 constexpr int TAIL_LDS_BYTES = (TAIL_WINDOWS * TAIL_H2_LD + TAIL_PART_FLOATS + TAIL_WINDOWS * NCLS) * (int)sizeof(float);
 __global__ void fc3_tail_kernel(const float*, const float*, const float*, int64_t, float*, int32_t*, uint8_t*,
-                                unsigned*, unsigned, unsigned*, uint8_t*);
+                                unsigned*, unsigned, unsigned*, uint8_t*, Gate);
 
 hipError_t init_fc_gemm()
 {
@@ -428,7 +430,7 @@ static hipError_t launch_gemm_cfg(const void* A, const void* W, const float* bia
     const int grid = ((nsuper + 7) / 8) * 8 * 64;
     plan_note(BF16 ? (TM == 2 ? "fc_tile128_bf16" : "fc_tile64_bf16") : (TM == 2 ? "fc_tile128" : "fc_tile64"));
     hipLaunchKernelGGL((fc_gemm_kernel<TM, TN, BF16, OUT_BF16, WGN>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st,
-                       A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+                       A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, t_gate);
     return hipGetLastError();
 }
 
@@ -490,7 +492,7 @@ static hipError_t launch_fc_gemm_one(const float* A, const float* W, const float
         const int grid = ((nsuper + 7) / 8) * 8 * 64;
         plan_note("fc_tile64_deep");
         hipLaunchKernelGGL(fc_gemm_small_kernel, dim3(grid), dim3(256), Cfg::LDS_BYTES, st,
-                           A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+                           A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, t_gate);
         return hipGetLastError();
     }
     return launch_gemm_cfg<1, 1, false, false>(A, W, bias, C, M, N, K, relu, st);
@@ -528,8 +530,10 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                      const float* __restrict__ b3, int64_t n, float* __restrict__ logits,
                      int32_t* __restrict__ pred, uint8_t* __restrict__ contacts,
                      unsigned* __restrict__ done_flag, unsigned done_seq, unsigned* __restrict__ seq_counter,
-                     uint8_t* __restrict__ packed)
+                     uint8_t* __restrict__ packed, Gate gate)
 {
+    if (gate_closed(gate)) return;                       // DCE_FP32_SPLIT's fallback sequence (dce_kernels.h Gate)
+    if (gate.taken && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(gate.taken, 1u);     // ... ran: counted (dce_split_guard_info)
     // dynamic LDS (43 KB): the 16 h2 rows of the current window tile [16][516] | chunk sums [8][16][16] | logits [16][16]
     extern __shared__ __attribute__((aligned(16))) float tsm[];
     float* h2s = tsm;
@@ -609,9 +613,11 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
 __global__ __launch_bounds__(256)
 void fc6_combine_kernel(const float* __restrict__ part, int64_t part_rows, const float* __restrict__ b3, int64_t n,
                         float* __restrict__ logits, int32_t* __restrict__ pred, uint8_t* __restrict__ contacts,
-                        uint8_t* __restrict__ packed)
+                        uint8_t* __restrict__ packed, Gate gate)
 {
     __shared__ float lg[16][NCLS];
+    if (gate_closed(gate)) return;                       // DCE_FP32_SPLIT's fallback sequence (dce_kernels.h Gate)
+    if (gate.taken && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(gate.taken, 1u);
     const int tid = threadIdx.x, cls = tid & 15, wl = tid >> 4;
     const int64_t base = (int64_t)blockIdx.x * 16, win = base + wl;
     const int64_t row = win < n ? win : n - 1;
@@ -641,7 +647,7 @@ hipError_t launch_fc6_combine(const float* part, int64_t part_rows, const float*
     if (n <= 0) return hipSuccess;
     plan_note("fc6_combine");
     hipLaunchKernelGGL(fc6_combine_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st,
-                       part, part_rows, b3, n, logits, pred, contacts, packed);
+                       part, part_rows, b3, n, logits, pred, contacts, packed, t_gate);
     return hipGetLastError();
 }
 
@@ -654,7 +660,7 @@ hipError_t launch_fc3_tail(const float* h2, const float* W3, const float* b3, in
     if (blocks > 1024) blocks = 1024;
     plan_note("fc3_tail");
     hipLaunchKernelGGL(fc3_tail_kernel, dim3((unsigned)blocks), dim3(256), TAIL_LDS_BYTES, st,
-                       h2, W3, b3, n, logits, pred, contacts, blocks == 1 ? done_flag : nullptr, done_seq, seq_counter, packed);
+                       h2, W3, b3, n, logits, pred, contacts, blocks == 1 ? done_flag : nullptr, done_seq, seq_counter, packed, t_gate);
     return hipGetLastError();
 }
 

@@ -143,9 +143,11 @@ __global__ __launch_bounds__(512, 2)
 void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                            const float* __restrict__ bias, void* __restrict__ Cv,
                            int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2,
-                           const float* __restrict__ W3 = nullptr, float* __restrict__ part = nullptr, long long part_rows = 0)
+                           const float* __restrict__ W3 = nullptr, float* __restrict__ part = nullptr, long long part_rows = 0,
+                           Gate gate = Gate{})
 {
     static_assert(!FUSE6 || (!OUT_BF16 && TM == 1 && TN == 1), "the fused fc.6 epilogue is fc.3's 128x64 tile with fp32 output");
+    if (gate_closed(gate)) return;                       // DCE_FP32_SPLIT's fallback sequence (dce_kernels.h Gate)
     using Cfg = PhCfg<TM, TN, ROWB>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NG = Cfg::NA + Cfg::NW, KQ = Cfg::KQ;
     constexpr int ES = BF16 ? 2 : 4;                     // operand element size
@@ -951,7 +953,7 @@ static hipError_t launch_phased_cfg(const void* A, const void* W, const float* b
     else
 #endif
         hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, false>), dim3(grid), dim3(512), Cfg::LDS, st,
-                           A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, nullptr, nullptr, 0ll);
+                           A, W, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, nullptr, nullptr, 0ll, t_gate);
     return hipGetLastError();
 }
 
@@ -975,7 +977,7 @@ bool fc23_fused_ok(int64_t M, int bf16)
     // take the 256 x 128 tile + the stand-alone tail: forcing the small tile there (DCE_FC23=always) measured 0.8 %
     // slower end to end on the 1e6-window sequence (3.849 vs 3.879 M windows/s) -- twice the phase hand-overs cost
     // more than h2's HBM round trip.  DCE_FC23=split: never fused (A/B).
-    const int mode = tune().fc23_mode;
+    const int mode = tune().fc23;
     if (mode == 1) return false;
     const int t = phased_tile(M, FC2, FC1, bf16 ? 2 : 4);
     if (t == 1) return true;
@@ -994,7 +996,7 @@ hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, co
     void* h2v = static_cast<void*>(h2_out);
     const long long pr = (long long)part_rows;
 #define FC23_LAUNCH(BF, LS) hipLaunchKernelGGL((fc_gemm_phased_kernel<BF, false, 1, 1, 256, true, LS>), dim3(grid), dim3(512), Cfg::LDS, st, \
-                                               h1, W2, b2, h2v, (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, pr)
+                                               h1, W2, b2, h2v, (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, pr, t_gate)
     plan_note(use_lockstep(false) ? "fc23_fused_lockstep128x64" : "fc23_fused_phased128x64");
 #if DCE_EXPERIMENTS
     if (use_lockstep(bf16)) { if (bf16) FC23_LAUNCH(true, true); else FC23_LAUNCH(false, true); }

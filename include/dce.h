@@ -65,11 +65,22 @@ typedef enum dce_precision {
                                   (8 significant bits).  The conv stack in front of that rounding runs on the bf16 matrix pipe with every
                                   operand as TWO bf16 terms (~17 significant bits, three MFMAs per product; csrc/conv_x3.hip, NT = 2) at
                                   every batch size: the mode's error against an fp64 evaluation is that of its bf16 FC operands, with
-                                  two terms as with three (DCE_X3_BF16_TERMS=3; profiles/r4h_bf16_terms_audit.json) */
+                                  two terms as with three (option x3_bf16_terms=3; profiles/r4h_bf16_terms_audit.json).  CONTRACT of the
+                                  mode: logits within 3e-3 of the largest logit of the CPU restatement of the mode
+                                  (oracle_forward_windows_bf16fc), argmax equal wherever the top-2 margin exceeds 1e-2 of it.
+                                  BASELINE configs[4] as written ("bf16 on the FC layers, conv stays fp32") is the option
+                                  x3_bf16_terms=3 -- fp32-grade conv results, band 2e-3; bench.py reports both figures */
     DCE_FP32_SPLIT      = 2    /* fp32 results with the conv stack and fc.0 of chip-filling batches on the bf16 matrix pipe: every fp32
                                   operand enters as three bf16 terms (a = a1 + a2 + a3 exactly), six bf16 MFMAs per product, fp32
                                   accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; the conv stack from 128
-                                  windows per call, fc.0 from 2817; below that the DCE_FP32 kernels.  Opt-in (csrc/conv_x3.hip, csrc/fc_gemm_x3.hip) */
+                                  windows per call, fc.0 from 2817; below that the DCE_FP32 kernels.  Opt-in (csrc/conv_x3.hip, csrc/fc_gemm_x3.hip).
+                                  RANGE GUARD (dce_split_guard_info): bf16's largest finite number is below fp32's and its subnormal range
+                                  starts 2^16 above where a value's third term lies, so the mode runs only where no operand can leave the
+                                  range in which a three-term split is exact -- decided statically from the checkpoint at
+                                  dce_finalize_weights (per-layer activation bounds; a checkpoint that fails runs the DCE_FP32 kernels) and,
+                                  for pre-normalised windows, per window in the conv kernel's load stage: a launch holding a window outside
+                                  [x_lo, x_hi] is recomputed by the DCE_FP32 kernel sequence queued behind it (gated on the device, no host
+                                  round trip).  z-scored windows (dce_infer_sequence) are inside the range by construction */
 } dce_precision;
 /* Batch-size regimes.  DCE_FP32 gives a window the same bits whatever the size of the call it arrives in (one fixed summation tree in
  * every kernel family).  The two other precisions pick kernels by the number of windows in a launch (a call of more than max_batch
@@ -102,6 +113,10 @@ int  dce_device_count(void);
  * windows per forward call (scratch for conv features / FC activations is sized from
  * it: 4736+2048+512 floats per window); calls with more windows are chunked inside. */
 int  dce_create(dce_ctx** out, int device_id, int64_t max_batch);
+/* ... with the A/B switches of DESIGN.md's appendix as an option string "key=value,key=value" (NULL: the environment variable
+ * DCE_TUNE; both over the built-in defaults).  ONE table names the keys (kTuneKeys, csrc/dce_api.hip); an unknown key or a malformed
+ * value is DCE_ERR_ARG; keys of variants that only the experiments build contains are accepted and ignored by the default library. */
+int  dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* options);
 void dce_destroy(dce_ctx* ctx);
 
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the
@@ -245,9 +260,24 @@ int  dce_comm_destroy(dce_ctx* ctx);
 int  dce_profile_enable(dce_ctx* ctx, int on);
 int  dce_profile_read(dce_ctx* ctx, double ms[DCE_PROFILE_SLOTS], int64_t launches[DCE_PROFILE_SLOTS], int reset);
 
+/* DCE_FP32_SPLIT's range guard as it stands for this context (synchronises the ctx stream to read the device-side counters). */
+typedef struct dce_split_guard {
+    int      precision;             /* dce_precision of the context */
+    int      enabled;               /* finalised with DCE_FP32_SPLIT and the guard not switched off (option split_guard=0) */
+    int      refused;               /* the checkpoint leaves the guarded range: every call runs the DCE_FP32 kernels (reason says why) */
+    float    x_hi, x_lo;            /* a pre-normalised window passes if max|x| <= x_hi and (max|x| >= x_lo or it is all zero) */
+    float    z_max;                 /* 149 / sqrt(150): what a z-scored window can reach */
+    double   gain[6], offs[6];      /* max|activation| of conv1..4, fc.0, fc.3 <= gain X + offs for inputs |x| <= X */
+    uint32_t guarded_launches;      /* launches that carried the per-window check */
+    uint32_t windows_out_of_range;  /* windows that failed it */
+    uint32_t fallbacks_run;         /* gated DCE_FP32 sequences that ran because of them */
+    char     reason[256];
+} dce_split_guard;
+int  dce_split_guard_info(dce_ctx* ctx, dce_split_guard* out);
+
 /* Which kernels the most recent kernel sequence of this ctx launched, as space-separated family names in launch order
  * (e.g. "conv_wino2 fc_phased256x128 fc23_fused_phased128x64 fc6_combine"): lets a test assert that a batch size or an
- * A/B switch (read from the environment once per dce_create) selected the kernel it means to check. */
+ * A/B switch (dce_create_ex's option string) selected the kernel it means to check. */
 int  dce_last_plan(dce_ctx* ctx, char* out, int out_len);
 
 /* Block until everything queued on the ctx stream has finished. */

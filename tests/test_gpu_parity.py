@@ -3,7 +3,7 @@ golden vectors of the reference, and size-independent properties at full size.""
 import numpy as np
 import pytest
 
-from conftest import tol_ok
+from conftest import needs_experiments, tol_ok
 
 pytestmark = pytest.mark.gpu
 
@@ -442,14 +442,10 @@ def test_online_mode_matches_sequence(models):
 @pytest.mark.parametrize("mode", ["default", "graph", "direct"])
 def test_online_mode_variants(mode, monkeypatch):
     """The three forms of a push -- constant-parameter kernels launched one by one (default), the same
-    sequence as one captured hipGraph (DCE_ONLINE_GRAPH=1), per-push parameters (DCE_ONLINE_DIRECT=1)
+    sequence as one captured hipGraph (option online_graph=1), per-push parameters (online_direct=1)
     -- give the same bits, across a reset and across the sample-buffer compaction."""
     from deep_contact_estimator_amd import contact_cnn, synth
-    if mode == "graph":
-        monkeypatch.setenv("DCE_ONLINE_GRAPH", "1")
-    if mode == "direct":
-        monkeypatch.setenv("DCE_ONLINE_DIRECT", "1")
-    m = contact_cnn(device=0, max_batch=64)
+    m = contact_cnn(device=0, max_batch=64, tune={"graph": {"online_graph": 1}, "direct": {"online_direct": 1}}.get(mode))
     m.load_state_dict(synth.make_state_dict(1, "uniform"))
     T = 150 + 4000                                        # crosses the compaction at 4096 rows
     seq = synth.make_sequence(T, 77).astype(np.float32)
@@ -566,17 +562,16 @@ def test_non_finite_windows_stay_contained(n, models, orc):
     tol_ok(got["logits"][~bad], ref["logits"][~bad], "clean pre-normalised windows")
 
 
+@needs_experiments
 def test_direct_form_conv_kernel(monkeypatch, golden, case_inputs, orc):
-    """DCE_CONV=direct selects the direct-form (implicit GEMM, 32x32x2 MFMA) conv stack kept for A/B
+    """conv_direct=1 (experiments build) selects the direct-form (implicit GEMM, 32x32x2 MFMA) conv stack kept for A/B
     against the Winograd kernels: same goldens, same tolerance, and the two agree with each other to
     fp32 round-off."""
     from deep_contact_estimator_amd import contact_cnn
     g = golden("seq_normal")
     sd, seq = case_inputs(g)
     wino = contact_cnn(device=0, max_batch=4096); wino.load_state_dict(sd)
-    monkeypatch.setenv("DCE_CONV", "direct")
-    direct = contact_cnn(device=0, max_batch=4096); direct.load_state_dict(sd)
-    monkeypatch.delenv("DCE_CONV")
+    direct = contact_cnn(device=0, max_batch=4096, tune={"conv_direct": 1}); direct.load_state_dict(sd)
     a, b = wino.infer_sequence(seq.astype(np.float32)), direct.infer_sequence(seq.astype(np.float32))
     tol_ok(b["logits"], g["logits"], "direct-form conv vs reference golden")
     tol_ok(b["logits"], a["logits"], "direct-form vs Winograd")
@@ -586,7 +581,7 @@ def test_direct_form_conv_kernel(monkeypatch, golden, case_inputs, orc):
     wino.close(); direct.close()
 
 
-@pytest.mark.parametrize("conv", ["winograd", "direct"])
+@pytest.mark.parametrize("conv", ["winograd", pytest.param("direct", marks=needs_experiments)])
 def test_forward_windows_bench_batch(conv, monkeypatch, orc):
     """BASELINE configs[1] exactly as bench.py runs it: the 4096 pre-normalised windows of the bench
     step (synthetic sequence seed 2, z-scored by the library, checkpoint seed 1) through
@@ -595,11 +590,8 @@ def test_forward_windows_bench_batch(conv, monkeypatch, orc):
     B = 4096
     sd = synth.make_state_dict(1, "uniform")
     seq = synth.make_sequence(B + 149, seed=2).astype(np.float32)
-    if conv == "direct":
-        monkeypatch.setenv("DCE_CONV", "direct")
-    m = contact_cnn(device=0, max_batch=B)
+    m = contact_cnn(device=0, max_batch=B, tune={"conv_direct": 1} if conv == "direct" else None)
     m.load_state_dict(sd).eval()
-    monkeypatch.delenv("DCE_CONV", raising=False)
     w = m.zscore_windows(seq, 0, B)                       # what bench.py materialises in HBM
     out = m.predict(w)
     m.close()
@@ -644,23 +636,20 @@ def test_inference_and_compute_acc_vs_reference_function(golden, case_inputs, mo
 def test_phased_gemm_equals_tile_kernels(n, precision, monkeypatch):
     """The phased GEMMs (one workgroup per CU, LDS-DMA staging, two wave groups one phase apart;
     fc_gemm_phased.hip) issue the same MFMA sequence per output as the tile kernels of fc_gemm.hip they
-    replace at chip-filling sizes (DCE_GEMM=tile keeps those): every FC activation and logit must be the
+    replace at chip-filling sizes (option gemm_tile=1 keeps those): every FC activation and logit must be the
     same BITS -- for a full grid, a partial last row tile and more than one round of tiles, in both
     precisions -- and over repeated runs (the phases order LDS-DMA against fragment reads only through
     counted waits and barriers, so a race would show up as a run-to-run difference)."""
     from deep_contact_estimator_amd import contact_cnn, synth
     sd = synth.make_state_dict(1, "uniform")
     x = np.random.default_rng(7 + n).standard_normal((n, 150, 54), dtype=np.float32)
-    monkeypatch.setenv("DCE_GEMM", "tile")
-    old = contact_cnn(device=0, max_batch=n, precision=precision); old.load_state_dict(sd)
+    old = contact_cnn(device=0, max_batch=n, precision=precision, tune={"gemm_tile": 1}); old.load_state_dict(sd)
     ref = old.predict(x)
     ref_taps = old.forward_taps(x[:4096]) if precision == "fp32" else None
     old.close()
-    monkeypatch.delenv("DCE_GEMM")
     from conftest import has_experiments
     for sched in ("phased", "lockstep") if has_experiments() else ("phased",):       # (phased ships; lockstep is the A/B variant of the experiments build)
-        monkeypatch.setenv("DCE_GEMM", sched)
-        new = contact_cnn(device=0, max_batch=n, precision=precision); new.load_state_dict(sd)
+        new = contact_cnn(device=0, max_batch=n, precision=precision, tune={"gemm_lockstep": int(sched == "lockstep")}); new.load_state_dict(sd)
         for rep in range(3):
             got = new.predict(x)
             assert np.array_equal(got["logits"], ref["logits"]), (n, sched, rep, np.abs(got["logits"] - ref["logits"]).max())
@@ -670,4 +659,3 @@ def test_phased_gemm_equals_tile_kernels(n, precision, monkeypatch):
             for k in ("h1", "h2", "logits"):
                 assert np.array_equal(taps[k], ref_taps[k]), (sched, k)
         new.close()
-    monkeypatch.delenv("DCE_GEMM")

@@ -138,7 +138,7 @@ def test_bf16_fc_vs_independent_restatement(n, model_of, orc):
     # other way -- rare, and never by more than that.
     want16 = orc.bf16_round(feat32)
     got16 = orc.bf16_from_bits(t16["feat"])
-    if not m16.last_plan()[0].startswith("conv_x"):              # (DCE_X3_CONV=0 / DCE_X3_BF16_MIN: the fp32 context's conv kernel, only the store differs)
+    if not m16.last_plan()[0].startswith("conv_x"):              # (x3_conv=0 / x3_bf16_min: the fp32 context's conv kernel, only the store differs)
         assert np.array_equal(t16["feat"], orc.bf16_bits(want16))
     else:
         # (... by default on TWO-term operands, conv_x2_*: ~17 significant bits, so about one value in 2^8 sits close enough to a
@@ -244,9 +244,10 @@ def test_packed_rows_equal_the_three_arrays(n, model_of):
 # the A/B switches are per context and select what they say
 # ------------------------------------------------------------------------------------------------
 def test_ab_switches_are_per_context(monkeypatch):
-    """DESIGN.md's A/B switches are read from the environment once per dce_create (round 2 latched them per process,
-    which made every in-process A/B comparison run one kernel twice): two live contexts created under different
-    settings run different kernels, as dce_last_plan reports, and still agree bit for bit."""
+    """DESIGN.md's A/B switches belong to a CONTEXT (dce_create_ex's option string; round 2 latched them per process, which made
+    every in-process A/B comparison run one kernel twice): live contexts created with different options run different kernels, as
+    dce_last_plan reports, and still agree bit for bit; DCE_TUNE in the environment is the default of contexts created without
+    options; an unknown key fails the creation."""
     from deep_contact_estimator_amd import contact_cnn, synth
     sd = synth.make_state_dict(1, "uniform")
     x = np.random.default_rng(1).standard_normal((4096, 150, 54), dtype=np.float32)
@@ -254,14 +255,17 @@ def test_ab_switches_are_per_context(monkeypatch):
     scheds = ("tile", "phased", "lockstep") if has_experiments() else ("tile", "phased")
     made = {}
     for sched in scheds:
-        monkeypatch.setenv("DCE_GEMM", sched)
-        made[sched] = contact_cnn(device=0, max_batch=4096); made[sched].load_state_dict(sd)
-        made[sched].predict(x[:2])                           # creates the ctx under this environment
-    monkeypatch.delenv("DCE_GEMM")
-    monkeypatch.setenv("DCE_CONV", "direct")
-    made["direct"] = contact_cnn(device=0, max_batch=4096); made["direct"].load_state_dict(sd)
-    made["direct"].predict(x[:2])
-    monkeypatch.delenv("DCE_CONV")
+        if sched == "tile":                                  # ... through the environment: the default of a context without options
+            monkeypatch.setenv("DCE_TUNE", "gemm_tile=1")
+            made[sched] = contact_cnn(device=0, max_batch=4096); made[sched].load_state_dict(sd)
+            made[sched].predict(x[:2])                       # creates the ctx under this environment
+            monkeypatch.delenv("DCE_TUNE")
+        else:
+            made[sched] = contact_cnn(device=0, max_batch=4096, tune={"gemm_lockstep": int(sched == "lockstep")}); made[sched].load_state_dict(sd)
+    if has_experiments():
+        made["direct"] = contact_cnn(device=0, max_batch=4096, tune="conv_direct=1"); made["direct"].load_state_dict(sd)
+    with pytest.raises(RuntimeError, match="unknown tuning option"):
+        contact_cnn(device=0, max_batch=64, tune={"no_such_switch": 1})._ensure_ctx()
     outs, plans = {}, {}
     for k, m in made.items():                                # all four contexts alive, environment back to defaults
         outs[k] = m.predict(x)
@@ -270,17 +274,19 @@ def test_ab_switches_are_per_context(monkeypatch):
     assert plans["tile"][1] == "fc_tile128" and "phased" not in " ".join(plans["tile"]), plans["tile"]
     if "lockstep" in plans:
         assert plans["lockstep"][1] == "fc_lockstep256x128" and plans["lockstep"][2] == "fc23_fused_lockstep128x64", plans["lockstep"]
-    assert plans["direct"][0] == "conv_direct" and plans["phased"][0] == "conv_wino2", (plans["direct"], plans["phased"])
+    assert plans["phased"][0] == "conv_wino2", plans["phased"]
     for k in scheds:
         assert np.array_equal(outs[k]["logits"], outs["phased"]["logits"]), k
-    tol_ok(outs["direct"]["logits"], outs["phased"]["logits"], "direct-form vs Winograd conv stack")
+    if "direct" in plans:
+        assert plans["direct"][0] == "conv_direct", plans["direct"]
+        tol_ok(outs["direct"]["logits"], outs["phased"]["logits"], "direct-form vs Winograd conv stack")
     for m in made.values():
         m.close()
 
 
 @pytest.mark.experiments
 def test_conv_rt4_equals_its_predecessor_bitwise(monkeypatch):
-    """The two-window conv workgroup with four row tiles per wave (DCE_CONV4=1, an A/B variant) against the shipped
+    """The two-window conv workgroup with four row tiles per wave (option conv4=1, an A/B variant) against the shipped
     two-row-tile kernel: same MFMAs per accumulator in the same K order -> the same feature bits, for pre-normalised windows
     and the z-score-fused sequence path, fp32 and bf16 features, odd window counts, NaN containment, repeated runs."""
     from deep_contact_estimator_amd import contact_cnn, synth
@@ -289,13 +295,11 @@ def test_conv_rt4_equals_its_predecessor_bitwise(monkeypatch):
     x = rng.standard_normal((2049, 150, 54), dtype=np.float32)
     x[7, 3, 5] = np.nan; x[1000, 100, 0] = np.inf
     seq = rng.standard_normal((1500 + 149, 54)).astype(np.float32) * 3 + 1
-    monkeypatch.setenv("DCE_X3_CONV", "0")                   # bf16_fc: the Winograd conv stack (its default is conv_x3.hip from 128 windows)
-    for precision in ("fp32", "bf16_fc"):
-        old = contact_cnn(device=0, max_batch=4096, precision=precision); old.load_state_dict(sd)
+    for precision in ("fp32", "bf16_fc"):                   # (x3_conv=0: bf16_fc on the Winograd conv stack -- its default is conv_x3.hip)
+        old = contact_cnn(device=0, max_batch=4096, precision=precision, tune={"x3_conv": 0}); old.load_state_dict(sd)
         ref_t = old.forward_taps(x); assert old.last_plan()[0] == "conv_wino2"
         ref_s = old.infer_sequence(seq)
-        monkeypatch.setenv("DCE_CONV4", "1")
-        new = contact_cnn(device=0, max_batch=4096, precision=precision); new.load_state_dict(sd)
+        new = contact_cnn(device=0, max_batch=4096, precision=precision, tune={"x3_conv": 0, "conv4": 1}); new.load_state_dict(sd)
         for rep in range(3):
             t = new.forward_taps(x); assert new.last_plan()[0] == "conv_wino2_rt4"
             for k in ("feat", "logits"):
@@ -304,7 +308,6 @@ def test_conv_rt4_equals_its_predecessor_bitwise(monkeypatch):
             s2 = new.infer_sequence(seq)
             assert np.array_equal(s2["logits"], ref_s["logits"]) and np.array_equal(s2["pred"], ref_s["pred"])
         assert np.isnan(t["logits"][7]).all() and np.isnan(t["logits"][1000]).all() and np.isfinite(t["logits"][8]).all()
-        monkeypatch.delenv("DCE_CONV4")
         old.close(); new.close()
 
 

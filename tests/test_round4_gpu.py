@@ -17,18 +17,9 @@ def orc():
     return oracle
 
 
-def _model(precision, max_batch=8192, env=None):
+def _model(precision, max_batch=8192, tune=None):
     from deep_contact_estimator_amd import contact_cnn
-    old = {k: os.environ.get(k) for k in (env or {})}
-    os.environ.update(env or {})
-    try:
-        m = contact_cnn(device=0, max_batch=max_batch, precision=precision)
-        m._ensure_ctx()                                   # the switches are read when the context is created
-    finally:
-        for k, v in old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
-    return m
+    return contact_cnn(device=0, max_batch=max_batch, precision=precision, tune=tune)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp32_split", "bf16_fc"])
@@ -65,14 +56,14 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs):
 def test_bf16_fc_conv_stack_on_two_term_operands(n, orc):
     """DCE_BF16_FC's conv stack by default: conv_x3.hip with NT = 2 -- operands as two bf16 terms, a1 b1 + a1 b2 + a2 b1 (three MFMAs per
     product, ~17 significant bits), two LDS planes, three workgroups per CU -- against the same kernel on three-term operands
-    (DCE_X3_BF16_TERMS=3, fp32-grade).  The features leave rounded to bf16 (8 bits), so the two may differ only where a value sits
+    (option x3_bf16_terms=3, fp32-grade).  The features leave rounded to bf16 (8 bits), so the two may differ only where a value sits
     within ~2^-17 of a rounding boundary: few values, one bf16 ulp each; the logits agree far inside the mode's band and the error
     against the fp64 oracle is the same.  Non-finite windows, odd sizes, both feature orders (a tap keeps the reference's flatten
     order), the z-score entry."""
     from deep_contact_estimator_amd import synth
     sd = synth.make_state_dict(1, "uniform")
     a = _model("bf16_fc"); a.load_state_dict(sd).eval()
-    b = _model("bf16_fc", env={"DCE_X3_BF16_TERMS": "3"}); b.load_state_dict(sd).eval()
+    b = _model("bf16_fc", tune={"x3_bf16_terms": 3}); b.load_state_dict(sd).eval()
     x = np.random.default_rng(50 + n).standard_normal((n, 150, 54), dtype=np.float32)
     x[n // 2, 3, 7] = np.inf
     ta, tb = a.forward_taps(x), b.forward_taps(x)
@@ -104,14 +95,14 @@ def test_bf16_fc_conv_stack_on_two_term_operands(n, orc):
 
 @pytest.mark.experiments
 def test_k_tiles_dealt_out_between_the_wave_groups():
-    """fc_gemm_ki_kernel (DCE_GEMM_KI=1, experiments build: group 0 multiplies the even K-tiles, group 1 the odd ones, partial sums meet
+    """fc_gemm_ki_kernel (option gemm_ki=1, experiments build: group 0 multiplies the even K-tiles, group 1 the odd ones, partial sums meet
     once through LDS; same launch time as the phased kernel at a lower clock, profiles/r4o_gemm_ki.txt): another fp32 summation order,
     so h1 may differ at bf16 rounding boundaries -- the logits stay within the mode's batch-size band of the phased kernel's, and every
     repeat gives the same bytes."""
     from deep_contact_estimator_amd import synth
     sd = synth.make_state_dict(1, "uniform")
-    a = _model("bf16_fc", env={"DCE_GEMM_KI": "1"}); a.load_state_dict(sd).eval()
-    b = _model("bf16_fc", env={"DCE_GEMM_KI": "0"}); b.load_state_dict(sd).eval()
+    a = _model("bf16_fc", tune={"gemm_ki": 1}); a.load_state_dict(sd).eval()
+    b = _model("bf16_fc", tune={"gemm_ki": 0}); b.load_state_dict(sd).eval()
     for n in (4096, 8192):
         x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
         ra, rb = a.predict(x), b.predict(x)
@@ -124,12 +115,12 @@ def test_k_tiles_dealt_out_between_the_wave_groups():
 
 @pytest.mark.experiments
 def test_barrier_free_bf16_gemm_equals_the_phased_kernel():
-    """fc_gemm_pipe_kernel (DCE_GEMM=pipe, experiments build: LDS counters instead of workgroup barriers in the K loop; measured
+    """fc_gemm_pipe_kernel (option gemm_pipe=1, experiments build: LDS counters instead of workgroup barriers in the K loop; measured
     slower, profiles/r4j_gemm_pipe.txt) walks K in the same 16-k blocks as the phased kernel: the same bytes, on every repeat."""
     from deep_contact_estimator_amd import synth
     sd = synth.make_state_dict(1, "uniform")
-    a = _model("bf16_fc", env={"DCE_GEMM": "pipe"}); a.load_state_dict(sd).eval()
-    b = _model("bf16_fc", env={"DCE_GEMM": "phased"}); b.load_state_dict(sd).eval()
+    a = _model("bf16_fc", tune={"gemm_pipe": 1}); a.load_state_dict(sd).eval()
+    b = _model("bf16_fc", tune={"gemm_pipe": 0}); b.load_state_dict(sd).eval()
     for n in (4096, 8192):
         x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
         ra, rb = a.predict(x), b.predict(x)
@@ -143,13 +134,13 @@ def test_barrier_free_bf16_gemm_equals_the_phased_kernel():
 @pytest.mark.experiments
 @pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
 def test_persistent_conv_stack_equals_one_workgroup_per_window(precision):
-    """conv_x3.hip's persistent form (DCE_X3_PERSIST=1, experiments build: two workgroups per CU walk the windows, the next window's
+    """conv_x3.hip's persistent form (option x3_persist=1, experiments build: two workgroups per CU walk the windows, the next window's
     samples requested a layer ahead) runs the same arithmetic in the same order: the same BYTES as one workgroup per window, at
     ragged sizes (workgroups with different window counts, fewer windows than workgroups), on both entries, with bad windows."""
     from deep_contact_estimator_amd import synth
     sd = synth.make_state_dict(1, "uniform")
-    a = _model(precision, env={"DCE_X3_PERSIST": "1", "DCE_X3_PERSIST_MIN": "128", "DCE_X3_BF16_TERMS": "3"}); a.load_state_dict(sd).eval()
-    b = _model(precision, env={"DCE_X3_PERSIST": "0", "DCE_X3_BF16_TERMS": "3"}); b.load_state_dict(sd).eval()
+    a = _model(precision, tune={"x3_persist": 1, "x3_persist_min": 128, "x3_bf16_terms": 3}); a.load_state_dict(sd).eval()
+    b = _model(precision, tune={"x3_persist": 0, "x3_bf16_terms": 3}); b.load_state_dict(sd).eval()
     for n in (300, 4096, 4097, 5001):
         if precision == "fp32_split" and n < 2817: continue
         x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
@@ -168,14 +159,14 @@ def test_persistent_conv_stack_equals_one_workgroup_per_window(precision):
 @pytest.mark.experiments
 @pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
 def test_paired_conv_stack_vs_one_window_kernel_and_oracle(precision, orc):
-    """conv_x3p.hip (DCE_X3_PAIR=1: one 8-wave workgroup per CU, two windows per wave, write-backs inside the other window's K
+    """conv_x3p.hip (option x3_pair=1: one 8-wave workgroup per CU, two windows per wave, write-backs inside the other window's K
     loops, features in the K order t' * 128 + c with fc.0's weights permuted alike) against conv_x3.hip on the same windows:
     ragged and odd batch sizes (a pair's second window missing, workgroups with different pair counts), the z-score entry,
     non-finite windows; fp32_split also against the oracle at the fp32 tolerance."""
     from deep_contact_estimator_amd import synth
     sd = synth.make_state_dict(1, "uniform")
-    a = _model(precision, env={"DCE_X3_PAIR": "1", "DCE_X3_PAIR_MIN": "256"}); a.load_state_dict(sd).eval()
-    b = _model(precision, env={"DCE_X3_PAIR": "0"}); b.load_state_dict(sd).eval()
+    a = _model(precision, tune={"x3_pair": 1, "x3_pair_min": 256}); a.load_state_dict(sd).eval()
+    b = _model(precision, tune={"x3_pair": 0}); b.load_state_dict(sd).eval()
     lim = 2e-5 if precision == "fp32_split" else 2e-2
     for n in (256, 511, 4096, 4097, 5001):
         if precision == "fp32_split" and n < 2817: continue                # (below the split fc.0's threshold the mode keeps fp32 features)
@@ -259,14 +250,14 @@ def test_layer_taps_refuse_a_bf16_fc_context():
 
 @pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
 def test_features_straight_from_the_accumulators_equal_the_staged_ones(precision):
-    """conv_x3.hip writes its features straight from the accumulators in the K order t' * 128 + c (DCE_X3_PERMK, default) with fc.0's
-    weights permuted alike, or through LDS in the reference's flatten order (DCE_X3_PERMK=0): the same products, another order of the
+    """conv_x3.hip writes its features straight from the accumulators in the K order t' * 128 + c (option x3_permk, default) with fc.0's
+    weights permuted alike, or through LDS in the reference's flatten order (x3_permk=0): the same products, another order of the
     fc.0 summation -- logits agree within the mode's noise, NaN windows are contained either way, a feature tap still hands out
     the reference's order."""
     from deep_contact_estimator_amd import synth
     sd = synth.make_state_dict(1, "uniform")
-    a = _model(precision, env={"DCE_X3_PERMK": "1"}); a.load_state_dict(sd).eval()
-    b = _model(precision, env={"DCE_X3_PERMK": "0"}); b.load_state_dict(sd).eval()
+    a = _model(precision, tune={"x3_permk": 1}); a.load_state_dict(sd).eval()
+    b = _model(precision, tune={"x3_permk": 0}); b.load_state_dict(sd).eval()
     for n in (4096, 4099, 3000 if precision == "fp32_split" else 129):
         x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
         x[3, 0, 0] = np.nan

@@ -161,17 +161,12 @@ def test_split_mode_nan_window_and_sequence_path(pair, orc):
 @pytest.mark.parametrize("n", [3072, 4099])
 def test_split_in_the_conv_kernel_equals_the_split_kernel(n, pair, monkeypatch):
     """By default the two-window conv kernel writes the features straight as three bf16 planes (plan conv_wino2_feat3);
-    DCE_X3_UNFUSED=1 (read per context) keeps fp32 features and splits them with split3_kernel.  Same terms, same layout:
+    the option x3_unfused=1 keeps fp32 features and splits them with split3_kernel.  Same terms, same layout:
     the same bits downstream.  (4099: an odd number of rows -- the planes' stride is rounded up to even.)"""
     from deep_contact_estimator_amd import contact_cnn
     sd, a, _ = pair
-    monkeypatch.setenv("DCE_X3_CONV", "0")                   # both contexts: the fp32 Winograd conv stack
-    b = contact_cnn(device=0, max_batch=8192, precision="fp32_split"); b.load_state_dict(sd).eval()
-    b.predict(np.zeros((1, 150, 54), np.float32))            # the context (and its switches) exist from the first call on
-    monkeypatch.setenv("DCE_X3_UNFUSED", "1")
-    u = contact_cnn(device=0, max_batch=8192, precision="fp32_split"); u.load_state_dict(sd).eval()
-    u.predict(np.zeros((1, 150, 54), np.float32))
-    monkeypatch.delenv("DCE_X3_UNFUSED"); monkeypatch.delenv("DCE_X3_CONV")
+    b = contact_cnn(device=0, max_batch=8192, precision="fp32_split", tune={"x3_conv": 0}); b.load_state_dict(sd).eval()     # both contexts: the fp32 Winograd conv stack
+    u = contact_cnn(device=0, max_batch=8192, precision="fp32_split", tune={"x3_conv": 0, "x3_unfused": 1}); u.load_state_dict(sd).eval()
     x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
     x[5, 3, 2] = np.inf                                     # a non-finite window goes through both routes as NaN features
     rb, ru = b.predict(x), u.predict(x)

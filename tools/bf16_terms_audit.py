@@ -19,13 +19,7 @@ N = 8192 if QUICK else 65536
 
 
 def model(terms):
-    os.environ["DCE_X3_BF16_TERMS"] = str(terms)
-    try:
-        m = contact_cnn(device=0, max_batch=32768, precision="bf16_fc")
-        m._ensure_ctx()
-    finally:
-        os.environ.pop("DCE_X3_BF16_TERMS", None)
-    return m
+    return contact_cnn(device=0, max_batch=32768, precision="bf16_fc", tune={"x3_bf16_terms": terms})
 
 
 def report(got, ref):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev check of conv_x3p.hip (two windows per workgroup, a phase apart) against conv_x3.hip (DCE_X3_PAIR=0) and the oracle,
+"""Dev check of conv_x3p.hip (two windows per workgroup, a phase apart) against conv_x3.hip (x3_pair=0) and the oracle,
 then event-timed A/B of the two; run on the GPU box.  Usage: python tools/dev_x3p.py [--no-oracle] [--time]"""
 import os
 import sys
@@ -14,11 +14,8 @@ from deep_contact_estimator_amd import contact_cnn, synth
 
 
 def make(precision, pair, max_batch=8192):
-    os.environ["DCE_X3_PAIR"] = "1" if pair else "0"
-    m = contact_cnn(device=0, max_batch=max_batch, precision=precision)
-    m._ensure_ctx()                                   # (the switches are read when the context is created)
+    m = contact_cnn(device=0, max_batch=max_batch, precision=precision, tune={"x3_pair": int(pair)})
     m.load_state_dict(synth.make_state_dict(1, "uniform")).eval()
-    os.environ.pop("DCE_X3_PAIR", None)
     return m
 
 

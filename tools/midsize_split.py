@@ -4,9 +4,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 from deep_contact_estimator_amd import contact_cnn, synth
 def run(envmin):
-    if envmin is None: os.environ.pop("DCE_X3_CONV_MIN", None)
-    else: os.environ["DCE_X3_CONV_MIN"] = str(envmin)
-    m = contact_cnn(device=0, max_batch=4096, precision="fp32_split"); m.load_state_dict(synth.make_state_dict(1))
+    m = contact_cnn(device=0, max_batch=4096, precision="fp32_split", tune=None if envmin is None else {"x3_conv_min": envmin}); m.load_state_dict(synth.make_state_dict(1))
     seq = torch.from_numpy(synth.make_sequence(4096 + 149, 2).astype(np.float32)).cuda()
     x = m.zscore_windows(seq)
     res = {}

@@ -22,7 +22,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         child(); sys.exit(0)
     out = {}
-    for tag, env in (("launches", {}), ("graph", {"DCE_ONLINE_GRAPH": "1"})):
+    for tag, env in (("launches", {}), ("graph", {"DCE_TUNE": "online_graph=1"})):
         p = subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, **env), capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
         out[tag] = json.loads(line[-1][7:]) if line else p.stderr[-500:]

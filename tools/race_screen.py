@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Race screen for the phased GEMMs (LDS-DMA ordered against fragment reads only by counted waits + barriers): many
 repeated runs at several batch sizes, in both precisions and both schedules, must return the bits of the tile kernels
-(DCE_GEMM=tile; the switch is read per context, and dce_last_plan is recorded to prove which kernels each context ran), also while a second stream keeps the memory system busy (uneven load shifts LDS-DMA landing times)."""
+(option gemm_tile=1; the switches belong to a context, and dce_last_plan is recorded to prove which kernels each context ran), also while a second stream keeps the memory system busy (uneven load shifts LDS-DMA landing times)."""
 import json, os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,11 +17,9 @@ def child(precision, sched, sizes, reps):
     side = torch.cuda.Stream()
     for n in sizes:
         x = torch.randn((n, 150, 54), generator=torch.Generator(device="cuda").manual_seed(n), device="cuda")
-        os.environ["DCE_GEMM"] = "tile"
-        ref_m = contact_cnn(device=0, max_batch=n, precision=precision); ref_m.load_state_dict(sd)
+        ref_m = contact_cnn(device=0, max_batch=n, precision=precision, tune={"gemm_tile": 1}); ref_m.load_state_dict(sd)
         ref = ref_m.predict(x)["logits"].clone(); ref_plan = ref_m.last_plan(); ref_m.close()
-        os.environ["DCE_GEMM"] = sched
-        m = contact_cnn(device=0, max_batch=n, precision=precision); m.load_state_dict(sd)
+        m = contact_cnn(device=0, max_batch=n, precision=precision, tune={"gemm_lockstep": int(sched == "lockstep")}); m.load_state_dict(sd)
         bad = 0
         for r in range(reps):
             if r % 2:                                   # every other run under a concurrent copy stream

@@ -3,7 +3,7 @@
 MFMA kernel (fc_gemm_split.hip, 9..64 windows; wave-private images, one barrier at the end) and the MFMA chain kernel
 (fc_gemm_chain.hip: a register ring of asm loads, a double-buffered LDS image, one barrier per chunk): repeated runs at the
 window counts they serve must return the same bits every time -- and the bits of a run with all three switched off
-(DCE_CHAIN_MAX=0, DCE_CHAIN_MAX3=0, DCE_SPLIT_MAX=0, DCE_SMALL_BATCH=gemm: tile kernels only) -- also while a second stream
+(DCE_TUNE=chain_max=0,chain_max3=0,split_max=0,gemv=0: tile kernels only) -- also while a second stream
 keeps the memory system busy (uneven load shifts the landing times of the loads)."""
 import json, os, subprocess, sys
 import numpy as np
@@ -38,7 +38,7 @@ if __name__ == "__main__":
         child(int(sys.argv[2])); sys.exit(0)
     reps = int(os.environ.get("REPS", 300))
     res = {}
-    for tag, env in (("chain", {}), ("off", {"DCE_CHAIN_MAX": "0", "DCE_CHAIN_MAX3": "0", "DCE_SPLIT_MAX": "0", "DCE_SMALL_BATCH": "gemm"})):
+    for tag, env in (("chain", {}), ("off", {"DCE_TUNE": "chain_max=0,chain_max3=0,split_max=0,gemv=0"})):
         p = subprocess.run([sys.executable, __file__, "child", str(reps if tag == "chain" else 2)], env=dict(os.environ, **env),
                            capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Debug: phase timeline of the one-window conv kernel (conv_wino1_kernel; needs the trace variant:
-build_variant('trace', ['-DDCE_TRACE=1']), DCE_LIB pointing at it, DCE_TRACE_WINO1=1, and DCE_WINOH_MAX=0 DCE_WINOQ_MAX=0
+build_variant('trace', ['-DDCE_TRACE=1']), DCE_LIB pointing at it, DCE_TUNE=trace_wino1=1,winoh_max=0,winoq_max=0
 so that the one-window kernel runs instead of its half- / quarter-window forms, which carry no marks)."""
 import ctypes as C, os, sys
 import numpy as np

@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deep_contact_estimator_amd import contact_cnn, synth, _lib
-# DCE_TRACE_PRECISION=bf16_fc traces the bf16 GEMM; DCE_PHASED_MIN_TILES1=100000 keeps fc.3 off the phased kernel so that the
+# DCE_TRACE_PRECISION=bf16_fc traces the bf16 GEMM; DCE_TUNE=phased_min_tiles1=100000 keeps fc.3 off the phased kernel so that the
 # trace left behind is fc.0's
 m = contact_cnn(device=0, max_batch=4096, precision=os.environ.get("DCE_TRACE_PRECISION", "fp32")); m.load_state_dict(synth.make_state_dict(1))
 x = torch.randn((4096, 150, 54), device="cuda")

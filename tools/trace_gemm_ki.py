@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Debug: phase timeline of fc_gemm_ki_kernel (needs build_variant('phtrace', ['-DPH_TRACE=1']), DCE_LIB, DCE_GEMM_KI=1)."""
+"""Debug: phase timeline of fc_gemm_ki_kernel (needs build_variant('phtrace', ['-DPH_TRACE=1']), DCE_LIB)."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deep_contact_estimator_amd import contact_cnn, synth, _lib
-os.environ.setdefault("DCE_PHASED_MIN_TILES1", "100000")       # keeps fc.3 off the phased kernels: the trace left behind is fc.0's
+os.environ.setdefault("DCE_TUNE", "phased_min_tiles1=100000,gemm_ki=1")       # keeps fc.3 off the phased kernels: the trace left behind is fc.0's
 m = contact_cnn(device=0, max_batch=4096, precision="bf16_fc"); m.load_state_dict(synth.make_state_dict(1))
 x = torch.randn((4096, 150, 54), device="cuda")
 for _ in range(3): m.predict(x)
