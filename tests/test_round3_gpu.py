@@ -50,8 +50,8 @@ def test_conv_layer_taps_vs_reference_hooks(kernel, name, golden, case_inputs, m
     block2[1], block2[3]) for EVERY conv kernel family, and the oracle's taps for the other windows of the launch
     (so that both windows of a two-window workgroup and every segment of a cut window are covered)."""
     from conftest import has_experiments
-    if kernel == "wino2rt4" and not has_experiments():
-        pytest.skip("the four-row-tile workgroup lives in the experiments build (tests/test_experiments_gpu.py runs it there)")
+    if kernel in ("wino2rt4", "direct") and not has_experiments():
+        pytest.skip("the four-row-tile workgroup and the direct-form kernel live in the experiments build (tests/test_experiments_gpu.py runs them there)")
     g = golden(name)
     sd, _ = case_inputs(g)
     m = model_of(int(g["wseed"]), str(g["bias"]))
