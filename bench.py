@@ -464,7 +464,9 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
     m.load_state_dict(sd).eval()
     if backend == "nccl" and use_rccl:
         use_rccl = comm_bootstrap_checked(m, rank, world, dev, key="dce_comm_id_sharded") is None
-    n_total = world * n_per_rank
+    # DCE_SHARDED_TOTAL: another total (a rehearsal of the 8-rank flow on one GPU; a count that does not divide by the world gives ragged shards)
+    n_total = int(os.environ.get("DCE_SHARDED_TOTAL", world * n_per_rank))
+    n_per_rank = n_total / world
     r0, r1, _, _ = shard_rows(n_total + 149, rank, world)
     g = torch.Generator(device=dev)
     chunk = 1 << 20                                          # row r is a pure function of r: chunk-aligned streams
@@ -474,7 +476,7 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
         blk = torch.randn((chunk, 54), generator=g, device=dev, dtype=torch.float32)
         parts.append(blk[max(r0 - a, 0): min(r1 - a, chunk)])
     rows = torch.cat(parts)
-    m.infer_sequence(rows[:32768 + 149])
+    m.infer_sequence(rows[:min(32768 + 149, rows.shape[0])])
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
@@ -487,9 +489,9 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
     if rank != 0:
         return None
     assert res["logits"].shape == (n_total, 16) and res["contacts"].shape == (n_total, 4)
-    return {"workload": f"BASELINE configs[3]: {world} x {n_per_rank} windows, halo-sharded, one gather of the packed "
+    return {"workload": f"BASELINE configs[3]: {world} x {n_per_rank:g} windows, halo-sharded, one gather of the packed "
                         "logits+contacts (68 B/window) to rank 0",
-            "windows_per_s_incl_gather": n_total / float(t.item()), "ms": float(t.item()) * 1e3,
+            "windows": n_total, "windows_per_s_incl_gather": n_total / float(t.item()), "ms": float(t.item()) * 1e3,
             "gathered_MB": n_total * 68 / 1e6,
             "transport": "dce_gather_results (ncclGather issued by libdce.so)" if backend == "nccl" and use_rccl else f"torch.distributed {backend}"}
 

@@ -48,6 +48,7 @@ SYMBOLS = {
     "dce_sync": (C.c_int, [C.c_void_p]),
     "dce_last_error": (C.c_char_p, [C.c_void_p]),
     "dce_debug_split3": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dce_debug_latency_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 BUILD_EXPERIMENTS, BUILD_TRACE, BUILD_ASAN = 1, 2, 4

@@ -80,6 +80,7 @@ class contact_cnn:
         return self._ctx
 
     def close(self):
+        self._online_stream_own = False
         if getattr(self, "_ctx", None):
             self._lib.dce_destroy(self._ctx)
             self._ctx = C.c_void_p()
@@ -171,6 +172,7 @@ class contact_cnn:
             if "contacts" in want: out["contacts"] = torch.empty((n, 4), dtype=torch.uint8, device=x.device)
             ptr = lambda k: C.c_void_p(out[k].data_ptr()) if k in out and n > 0 else None
             _lib.check(lib.dce_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), 0), ctx)
+            self._online_stream_own = False
             if raw_sequence:
                 rc = lib.dce_infer_sequence(ctx, C.c_void_p(x.data_ptr()), x.shape[0], WINDOW, 1,
                                             ptr("logits"), ptr("pred"), ptr("contacts"))
@@ -232,6 +234,7 @@ class contact_cnn:
     def _torch_stream(self, t):
         import torch
         _lib.check(self._lib.dce_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream), 0), self._ctx)
+        self._online_stream_own = False
 
     def _run_packed(self, x, raw_sequence: bool, out=None):
         """-> (n,68) uint8 rows: 16 fp32 logits + 4 contact bits per window, written by the last kernel of the path.
@@ -417,6 +420,7 @@ class contact_cnn:
             seq = seq.contiguous()
             out = torch.empty((n, WINDOW, CHANNELS), dtype=torch.float32, device=seq.device)
             _lib.check(self._lib.dce_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(seq.device).cuda_stream), 0), ctx)
+            self._online_stream_own = False
             _lib.check(self._lib.dce_zscore_windows(ctx, C.c_void_p(seq.data_ptr()), T, first, n, 1,
                                                     C.c_void_p(out.data_ptr()) if n > 0 else None), ctx)
             return out
@@ -433,18 +437,26 @@ class contact_cnn:
 
     def online_push(self, sample):
         """Online mode: append one (54,) sample; once 150 samples are in, returns
-        (logits (16,), pred int, contacts (4,) u8) for the newest window, else None."""
+        (logits (16,), pred int, contacts (4,) u8) for the newest window, else None.
+        (The call is on the latency path of a robot's control loop: buffers and their ctypes pointers are made once.)"""
         self._finalize()
-        s = np.ascontiguousarray(np.asarray(sample), dtype=np.float32).reshape(-1)
-        if s.shape[0] != CHANNELS:
-            raise RuntimeError(f"expected a ({CHANNELS},) sample, got {s.shape}")
-        logits = np.empty(CLASSES, np.float32); pred = np.empty(1, np.int32); contacts = np.empty(4, np.uint8)
-        _lib.check(self._lib.dce_set_stream(self._ctx, None, 1), self._ctx)
-        rc = self._lib.dce_online_push(self._ctx, s.ctypes.data_as(C.c_void_p), logits.ctypes.data_as(C.c_void_p),
-                                       pred.ctypes.data_as(C.c_void_p), contacts.ctypes.data_as(C.c_void_p))
+        ob = getattr(self, "_online_bufs", None)
+        if ob is None:
+            s = np.empty(CHANNELS, np.float32); lg = np.empty(CLASSES, np.float32); pr = np.empty(1, np.int32); ct = np.empty(4, np.uint8)
+            ob = self._online_bufs = (s, lg, pr, ct, s.ctypes.data_as(C.c_void_p), lg.ctypes.data_as(C.c_void_p),
+                                      pr.ctypes.data_as(C.c_void_p), ct.ctypes.data_as(C.c_void_p))
+        s, lg, pr, ct, ps, pl, pp, pc = ob
+        a = np.asarray(sample)
+        if a.size != CHANNELS:
+            raise RuntimeError(f"expected a ({CHANNELS},) sample, got {a.shape}")
+        s[:] = a.reshape(-1)
+        if not getattr(self, "_online_stream_own", False):
+            _lib.check(self._lib.dce_set_stream(self._ctx, None, 1), self._ctx)
+            self._online_stream_own = True
+        rc = self._lib.dce_online_push(self._ctx, ps, pl, pp, pc)
         if rc < 0:
             _lib.check(rc, self._ctx)
-        return (logits, int(pred[0]), contacts) if rc == 1 else None
+        return (lg.copy(), int(pr[0]), ct.copy()) if rc == 1 else None
 
     def confusion_counts(self, pred, labels, counts=None):
         """Accumulate the 16x16 confusion counts C[gt][pred] on the device (dce_confusion_counts).
@@ -458,6 +470,7 @@ class contact_cnn:
             if counts is None:
                 counts = torch.zeros((16, 16), dtype=torch.int64, device=pred.device)
             _lib.check(self._lib.dce_set_stream(ctx, C.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream), 0), ctx)
+            self._online_stream_own = False
             _lib.check(self._lib.dce_confusion_counts(ctx, C.c_void_p(pred.data_ptr()), C.c_void_p(labels.data_ptr()),
                                                       pred.shape[0], 1, C.c_void_p(counts.data_ptr())), ctx)
             return counts

@@ -19,6 +19,16 @@
 
 using namespace dce;
 
+#if defined(__x86_64__) || defined(__i386__)
+#define DCE_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define DCE_CPU_RELAX() asm volatile("yield" ::: "memory")
+#else
+#define DCE_CPU_RELAX() do {} while (0)
+#endif
+
+namespace { int lat_service_stop(dce_ctx* c); }
+
 namespace {
 
 struct KeyInfo { const char* name; int ndim; int64_t shape[3]; };
@@ -52,7 +62,7 @@ const TuneKey kTuneKeys[] = {
     TK(split_min, 'l'), TK(split_max, 'l'), TK(chain_min, 'l'), TK(chain_max, 'l'), TK(chain_max3, 'l'), TK(chain_bn16_max, 'l'),
     TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
     TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'),
-    TK(online_graph, 'b'), TK(online_direct, 'b'),
+    TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
     TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(split_guard, 'b'),
     TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
     TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
@@ -223,6 +233,82 @@ void compute_split_guard(dce_ctx* c)
     g.reason = "ok";
 }
 
+// ---- latency mode (latency.hip): kernel arguments, and the resident service behind dce_online_push
+// exchange memory (fine-grained): features (4736 floats) | h1, h2 as (value, tag) words | LatSync
+constexpr size_t LAT_X_BYTES = FEAT * sizeof(float) + (FC1 + FC2) * sizeof(unsigned long long) + sizeof(LatSync);
+LatArgs lat_args(dce_ctx* c)
+{
+    LatArgs a{};
+    a.pk = c->pk;
+    a.w1 = c->fc1w; a.b1 = c->fc1b; a.w2 = c->fc2w; a.b2 = c->fc2b; a.w3 = c->fc3w; a.b3 = c->fc3b;
+    a.feat = c->lat_x; a.h1 = reinterpret_cast<unsigned long long*>(c->lat_x + FEAT); a.h2 = a.h1 + FC1;
+    a.sync = c->lat_sync; a.mbox = c->lat_mbox; a.trace = c->lat_trace;
+    a.fc_delay_ticks = (unsigned long long)(c->tuning.latency_fc_delay > 0 ? c->tuning.latency_fc_delay : 0);
+    a.deadline_ticks = 5000000ull;                                    // 50 ms of the 100 MHz wall clock: far beyond any hand-over of a healthy launch
+    a.idle_ticks = (unsigned long long)(c->tuning.latency_idle_ms > 0 ? c->tuning.latency_idle_ms : 1) * 100000ull;
+    return a;
+}
+
+// a wait of the one-shot kernel or of the service ran into its deadline: the arrival counters are out of step -> start over from zero
+int lat_check_error(dce_ctx* c)
+{
+    if (!c->lat_mbox || !__atomic_load_n(&c->lat_mbox->error, __ATOMIC_ACQUIRE)) return DCE_OK;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->lat_stream) (void)hipStreamSynchronize(c->lat_stream);
+    c->lat_running = false;
+    c->lat_mbox->error = 0;
+    (void)hipMemset(c->lat_x, 0, LAT_X_BYTES);
+    c->lat_seq = 0;
+    return fail(c, DCE_ERR_HIP, "latency mode: a hand-over between the kernel's workgroups ran into its 50 ms deadline (is another kernel holding CUs? the mode needs all %d)", latency_grid());
+}
+
+int lat_service_stop(dce_ctx* c)
+{
+    if (!c || !c->lat_running) return DCE_OK;
+    LatMailbox* mb = c->lat_mbox;
+    mb->kind = 2;
+    __atomic_store_n(&mb->req, ++c->lat_req, __ATOMIC_RELEASE);
+    HIP_TRY(c, hipStreamSynchronize(c->lat_stream));                  // (if it had left by itself already: returns at once)
+    c->lat_running = false;
+    HIP_TRY(c, hipMemsetAsync(c->lat_x, 0, LAT_X_BYTES, c->lat_stream));          // the one-shot launches count their requests from one again
+    HIP_TRY(c, hipStreamSynchronize(c->lat_stream));
+    c->lat_seq = 0;
+    return DCE_OK;
+}
+
+int lat_service_start(dce_ctx* c)
+{
+    LatMailbox* mb = c->lat_mbox;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                      // the scratch rows and the device must be ours
+    HIP_TRY(c, hipStreamSynchronize(c->lat_stream));
+    HIP_TRY(c, hipMemsetAsync(c->lat_x, 0, LAT_X_BYTES, c->lat_stream));
+    c->lat_seq = 0;
+    LatArgs a = lat_args(c);
+    a.seq = 1;
+    a.hist = c->lat_hist; a.hist_state = c->lat_hist_state;
+    a.req_base = c->lat_req; a.done_base = c->online_seq;
+    mb->a.tag = mb->b.tag = c->online_seq;
+    __atomic_store_n(&mb->alive, 0u, __ATOMIC_RELEASE);
+    { TuningScope ts(&c->tuning);
+      HIP_TRY(c, launch_latency(2, a, c->lat_stream)); }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE)) {          // the kernel is up (its weights may still be on their way)
+        DCE_CPU_RELAX();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5))
+            return fail(c, DCE_ERR_HIP, "latency mode: the service kernel did not start within 5 s");
+    }
+    c->lat_running = true;
+    return DCE_OK;
+}
+
+// every entry point other than dce_online_push: the resident kernel holds every CU's LDS -- it leaves first
+int lat_quiesce(dce_ctx* c)
+{
+    int rc = lat_check_error(c);
+    if (rc) return rc;
+    return lat_service_stop(c);
+}
+
 // The gated DCE_FP32 fallback behind a guarded DCE_FP32_SPLIT launch: binds the gate for the launchers and a tuning without the
 // small-batch kernel families and row cuts (the gated kernels: conv_wino2, tile / phased GEMMs, fused fc.3, combine, tail).
 struct GateScope {
@@ -254,6 +340,7 @@ struct Plan {
     Fc0 fc0; bool split3;                 // split3: fp32 features split by a kernel of their own in front of fc_gemm_x3 (taps, x3_unfused)
     Fc3 fc3; int64_t fused_rows;          // rows the fused fc.3 + fc.6 kernel takes (whole rounds); the rest goes to the chain kernel + tail
     bool guarded;                         // DCE_FP32_SPLIT on pre-normalised windows: the conv kernel checks every window's range (SplitGuard)
+    bool latency;                         // latency mode, one window: the whole path in ONE kernel of 256 co-resident workgroups (latency.hip)
 };
 
 Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
@@ -261,7 +348,8 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
     const Tuning& tu = tune();                                        // (bound by run_chunk: the context's switches, or their gated form)
     const bool wino = !(DCE_EXPERIMENTS && tu.conv_direct);
     const bool online = c->src_row_dev != nullptr;                    // the online graph: the window start lives in device memory
-    Plan p{Conv::WinoF32, 0, Fc0::F32, false, Fc3::F32, 0, false};
+    Plan p{Conv::WinoF32, 0, Fc0::F32, false, Fc3::F32, 0, false, false};
+    if (tu.latency && c->precision == DCE_FP32 && n == 1 && !online && !c->done_flag && !c->want_feat && !c->want_h2 && !c->gate_on) { p.latency = true; return p; }
     if (c->precision == DCE_BF16_FC) {
         const bool x3c = tu.x3_conv && wino && n >= tu.x3_bf16_min && (!online || zscore);
         const bool pair = DCE_EXPERIMENTS && tu.x3_conv && tu.x3_pair && wino && !online && !c->want_feat && n >= tu.x3_pair_min;
@@ -323,6 +411,14 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
              float* logits, int32_t* pred, uint8_t* contacts, uint8_t* packed)
 {
     const hipStream_t st = c->stream;
+    if (p.latency) {
+        Timer t(c, 0);
+        LatArgs a = lat_args(c);
+        a.seq = ++c->lat_seq;
+        a.src = src; a.logits = logits; a.pred = pred; a.contacts = contacts; a.packed = packed;
+        HIP_TRY(c, launch_latency(zscore ? 1 : 0, a, st));
+        return DCE_OK;
+    }
     unsigned short* featb = reinterpret_cast<unsigned short*>(c->feat);
     const bool wino = !(DCE_EXPERIMENTS && c->tuning.conv_direct);
     auto conv_f32 = wino ? launch_conv_wino : launch_conv_stack;
@@ -425,6 +521,11 @@ int check_ready(dce_ctx* c)
     if (!c) return DCE_ERR_ARG;
     if (!c->finalized) return fail(c, DCE_ERR_STATE, "weights not finalized: call dce_finalize_weights first");
     return DCE_OK;
+}
+int check_ready_quiet(dce_ctx* c)                         // ... and the latency mode's resident kernel, if any, has left
+{
+    const int rc = check_ready(c);
+    return rc ? rc : lat_quiesce(c);
 }
 
 // Shared driver for forward_windows / infer_sequence: chunk over max_batch.
@@ -597,6 +698,32 @@ int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* o
     CREATE_TRY(hipMalloc(&c->part, (size_t)max_batch * 8 * NCLS * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->d_guard, 4 * sizeof(unsigned)));
     CREATE_TRY(hipMemset(c->d_guard, 0, 4 * sizeof(unsigned)));
+    if (c->tuning.latency) {
+        // the latency mode's kernel is ONE grid of co-resident workgroups, one per CU: it needs a device with that many CUs to itself
+        int cus = 0;
+        CREATE_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id));
+        if (cus < latency_grid()) {
+            fail(nullptr, DCE_ERR_STATE, "latency=1 needs %d CUs (one workgroup each, all resident at once); device %d has %d", latency_grid(), device_id, cus);
+            dce_destroy(c); return DCE_ERR_STATE;
+        }
+        CREATE_TRY(init_latency());
+        // what crosses workgroups inside the kernel -- one row of features, h1, h2 and the arrival counters -- lives in FINE-GRAINED device
+        // memory (uncached in the XCDs' L2s): the hand-overs then need no cache write-back / invalidate (latency.hip)
+        CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->lat_x), LAT_X_BYTES, hipDeviceMallocFinegrained));
+        c->lat_sync = reinterpret_cast<LatSync*>(c->lat_x + FEAT + 2 * (FC1 + FC2));
+        CREATE_TRY(hipMemset(c->lat_x, 0, LAT_X_BYTES));
+        if (getenv("DCE_LAT_TRACE")) {                    // debug: wall-clock stamps of the last request's phases, readable by the host (dce_debug_latency_trace)
+            CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->lat_trace), 16 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+            memset(c->lat_trace, 0, 16 * sizeof(unsigned long long));
+        }
+        CREATE_TRY(hipMalloc(&c->lat_hist, WIN * CH * sizeof(float)));
+        CREATE_TRY(hipMalloc(&c->lat_hist_state, 2 * sizeof(int)));
+        CREATE_TRY(hipMemset(c->lat_hist_state, 0, 2 * sizeof(int)));
+        CREATE_TRY(hipMemset(c->lat_hist, 0, WIN * CH * sizeof(float)));
+        CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->lat_mbox), sizeof(LatMailbox), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->lat_mbox, 0, sizeof(LatMailbox));
+        CREATE_TRY(hipStreamCreateWithFlags(&c->lat_stream, hipStreamNonBlocking));
+    }
 #undef CREATE_TRY
     *out = c;
     return DCE_OK;
@@ -606,6 +733,11 @@ void dce_destroy(dce_ctx* c)
 {
     if (!c) return;
     DeviceGuard guard(c->device);
+    (void)lat_service_stop(c);
+    if (c->lat_stream) hipStreamDestroy(c->lat_stream);
+    if (c->lat_mbox) hipHostFree(c->lat_mbox);
+    hipFree(c->lat_x); hipFree(c->lat_hist); hipFree(c->lat_hist_state);
+    if (c->lat_trace) hipHostFree(c->lat_trace);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     if (c->stream != c->own_stream) hipStreamSynchronize(c->stream);   // scratch may still be in use there
     for (auto& s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
@@ -672,6 +804,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     for (int k = 0; k < 14; ++k)
         if (!c->have[k]) return fail(c, DCE_ERR_STATE, "missing state_dict key '%s'", kKeys[k].name);
     DEVICE_GUARD(c);
+    { const int rc = lat_quiesce(c); if (rc) return rc; }
     // a captured online graph holds the old weight pointers / precision: drop it, the next push re-captures
     if (c->online_exec) { hipGraphExecDestroy(c->online_exec); c->online_exec = nullptr; }
     if (c->online_graph) { hipGraphDestroy(c->online_graph); c->online_graph = nullptr; }
@@ -772,7 +905,7 @@ int dce_forward_windows(dce_ctx* c, const float* windows, int64_t n, int on_devi
                         float* logits, int32_t* pred, uint8_t* contacts)
 {
     RoctxRange range_("dce_forward_windows");
-    int rc = check_ready(c);
+    int rc = check_ready_quiet(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
     if (n < 0 || (n > 0 && !windows)) return fail(c, DCE_ERR_ARG, "dce_forward_windows: bad argument");
@@ -784,7 +917,7 @@ int dce_infer_sequence(dce_ctx* c, const float* seq, int64_t T, int window, int 
                        float* logits, int32_t* pred, uint8_t* contacts)
 {
     RoctxRange range_("dce_infer_sequence");
-    int rc = check_ready(c);
+    int rc = check_ready_quiet(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
     if (window != WIN) return fail(c, DCE_ERR_ARG, "window_size must be %d (the model hard-codes 4736 = 128*37), got %d", WIN, window);
@@ -797,7 +930,7 @@ int dce_infer_sequence(dce_ctx* c, const float* seq, int64_t T, int window, int 
 int dce_forward_windows_packed(dce_ctx* c, const float* windows, int64_t n, int on_device, uint8_t* packed)
 {
     RoctxRange range_("dce_forward_windows_packed");
-    int rc = check_ready(c);
+    int rc = check_ready_quiet(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
     if (n < 0 || (n > 0 && (!windows || !packed))) return fail(c, DCE_ERR_ARG, "dce_forward_windows_packed: bad argument");
@@ -809,7 +942,7 @@ int dce_forward_windows_packed(dce_ctx* c, const float* windows, int64_t n, int 
 int dce_infer_sequence_packed(dce_ctx* c, const float* seq, int64_t T, int window, int on_device, uint8_t* packed)
 {
     RoctxRange range_("dce_infer_sequence_packed");
-    int rc = check_ready(c);
+    int rc = check_ready_quiet(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
     if (window != WIN) return fail(c, DCE_ERR_ARG, "window_size must be %d (the model hard-codes 4736 = 128*37), got %d", WIN, window);
@@ -868,7 +1001,7 @@ int dce_zscore_windows(dce_ctx* c, const float* seq, int64_t T, int64_t first, i
 int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
                      void* feat, void* h1, float* h2, float* logits)
 {
-    int rc = check_ready(c);
+    int rc = check_ready_quiet(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
     if (n <= 0 || n > c->max_batch || !windows)
@@ -905,7 +1038,7 @@ int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
 int dce_conv_layer_taps(dce_ctx* c, const float* windows, int64_t n, int kernel,
                         float* conv1, float* conv2, float* pool1, float* conv3, float* conv4, float* feat)
 {
-    int rc = check_ready(c);
+    int rc = check_ready_quiet(c);
     if (rc) return rc;
     DEVICE_GUARD(c);
     if (n <= 0 || n > c->max_batch || n > 64 || !windows || !conv1 || !conv2 || !pool1 || !conv3 || !conv4 || !feat)
@@ -967,6 +1100,14 @@ int dce_confusion_counts(dce_ctx* c, const int32_t* pred, const int64_t* labels,
 int dce_online_reset(dce_ctx* c)
 {
     if (!c) return DCE_ERR_ARG;
+    if (c->lat_mbox) {
+        DEVICE_GUARD(c);
+        const int rc = lat_quiesce(c);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemset(c->lat_hist_state, 0, 2 * sizeof(int)));
+        c->lat_count = 0;
+        c->lat_mbox->a.tag = c->lat_mbox->b.tag = 0;
+    }
     c->ring_rows = 0;
     c->online_seq = 0;
     c->online_state_dirty = true;
@@ -979,13 +1120,6 @@ namespace {
 // pinned block: [0,16) logits | [16] pred | [17] contacts | [32] completion flag | [40,94) the incoming sample
 constexpr int PIN_FLAG = 32, PIN_SAMPLE = 40, PIN_FLOATS = 96;
 
-#if defined(__x86_64__) || defined(__i386__)
-#define DCE_CPU_RELAX() __builtin_ia32_pause()
-#elif defined(__aarch64__)
-#define DCE_CPU_RELAX() asm volatile("yield" ::: "memory")
-#else
-#define DCE_CPU_RELAX() do {} while (0)
-#endif
 
 int online_wait(dce_ctx* c, unsigned expect)
 {
@@ -1040,6 +1174,54 @@ void online_build_graph(dce_ctx* c)
     c->online_exec = x;
 }
 
+// dce_online_push in the latency mode: the sample goes to the mailbox of the resident kernel (started on the first push, and again
+// after it left for want of samples), the estimate comes back through the same mailbox: no launch, no copy, no stream operation.
+int lat_push(dce_ctx* c, const float* sample, float* logits, int32_t* pred, uint8_t* contacts)
+{
+    int rc = lat_check_error(c);
+    if (rc) return rc;
+    LatMailbox* mb = c->lat_mbox;
+    const bool estimate = c->lat_count + 1 >= WIN;
+    for (int attempt = 0;; ++attempt) {
+        if (c->lat_running && !__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE)) {      // it left for want of samples (latency_idle_ms): start it again
+            HIP_TRY(c, hipStreamSynchronize(c->lat_stream));
+            c->lat_running = false;
+        }
+        if (!c->lat_running && (rc = lat_service_start(c))) return rc;
+        memcpy(mb->sample, sample, CH * sizeof(float));
+        mb->kind = estimate ? 1u : 0u;
+        const unsigned req = ++c->lat_req;
+        __atomic_store_n(&mb->req, req, __ATOMIC_RELEASE);
+        const unsigned want_done = c->online_seq + 1;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool dead = false;
+        for (unsigned spins = 0;; ++spins) {
+            if (estimate ? (__atomic_load_n(&mb->a.tag, __ATOMIC_ACQUIRE) == want_done && __atomic_load_n(&mb->b.tag, __ATOMIC_ACQUIRE) == want_done)
+                         : (__atomic_load_n(&mb->ack[0], __ATOMIC_ACQUIRE) == req && __atomic_load_n(&mb->ack[1], __ATOMIC_ACQUIRE) == req &&
+                            __atomic_load_n(&mb->ack[2], __ATOMIC_ACQUIRE) == req && __atomic_load_n(&mb->ack[3], __ATOMIC_ACQUIRE) == req)) break;
+            DCE_CPU_RELAX();
+            if ((spins & 0x3ff) != 0x3ff) continue;
+            if (__atomic_load_n(&mb->error, __ATOMIC_ACQUIRE)) return lat_check_error(c);
+            if (!__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) && __atomic_load_n(&mb->ack[0], __ATOMIC_ACQUIRE) != req) { dead = true; break; }   // it left before it saw this request
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                (void)lat_service_stop(c);
+                return fail(c, DCE_ERR_HIP, "dce_online_push (latency mode): no answer from the service kernel within 200 ms");
+            }
+        }
+        if (!dead) break;
+        HIP_TRY(c, hipStreamSynchronize(c->lat_stream));
+        c->lat_running = false;
+        if (attempt >= 2) return fail(c, DCE_ERR_HIP, "dce_online_push (latency mode): the service kernel keeps leaving before it takes a request");
+    }
+    if (c->lat_count < WIN) c->lat_count += 1;
+    if (!estimate) return 0;
+    c->online_seq += 1;
+    if (logits) { memcpy(logits, mb->a.logits, 15 * sizeof(float)); logits[15] = mb->b.logit15; }
+    if (pred) *pred = mb->b.pred;
+    if (contacts) memcpy(contacts, mb->b.contacts, 4);
+    return 1;
+}
+
 }  // namespace
 
 int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pred, uint8_t* contacts)
@@ -1049,6 +1231,7 @@ int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pre
     if (rc) return rc;
     DEVICE_GUARD(c);
     if (!sample) return fail(c, DCE_ERR_ARG, "dce_online_push: NULL sample");
+    if (c->tuning.latency && c->precision == DCE_FP32) return lat_push(c, sample, logits, pred, contacts);
     if (!c->d_ring) {
         HIP_TRY(c, hipMalloc(&c->d_ring, (size_t)ONLINE_ROWS * CH * sizeof(float)));
         HIP_TRY(c, hipMalloc(&c->d_online_state, sizeof(OnlineState)));
@@ -1166,6 +1349,14 @@ int dce_sync(dce_ctx* c)
     if (!c) return DCE_ERR_ARG;
     DEVICE_GUARD(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->lat_mbox && !c->lat_running) return lat_check_error(c);
+    return DCE_OK;
+}
+
+int dce_debug_latency_trace(dce_ctx* c, unsigned long long out[16])
+{
+    if (!c || !out || !c->lat_trace) return DCE_ERR_STATE;
+    for (int i = 0; i < 16; ++i) out[i] = __atomic_load_n(&c->lat_trace[i], __ATOMIC_RELAXED);
     return DCE_OK;
 }
 

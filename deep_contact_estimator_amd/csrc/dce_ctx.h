@@ -80,6 +80,18 @@ struct dce_ctx {
     int online_mode = -1;                  // -1 undecided, 0 direct launches, 1 graph
     bool online_state_dirty = true;        // device state must be zeroed before the next push
 
+    // latency mode (latency.hip; option latency=1)
+    float* lat_x = nullptr;                // fine-grained device memory: one row of features | h1 | h2 | the arrival counters
+    dce::LatSync* lat_sync = nullptr;      // (inside lat_x)
+    unsigned long long* lat_trace = nullptr;   // DCE_LAT_TRACE: pinned, phase stamps of the last request
+    dce::LatMailbox* lat_mbox = nullptr;   // pinned host
+    float* lat_hist = nullptr; int* lat_hist_state = nullptr;    // device: the service's sample history
+    hipStream_t lat_stream = nullptr;      // the resident service kernel runs here
+    bool lat_running = false;
+    unsigned long long lat_seq = 0;        // estimates requested since the counters were last zeroed
+    unsigned lat_req = 0;                  // mailbox request number
+    int lat_count = 0;                     // samples in the history (host mirror)
+
     // multi-GPU (dce_comm.hip): one RCCL communicator per ctx, collectives on comm_stream behind the ctx stream
     void* comm = nullptr;                  // ncclComm_t
     int comm_rank = 0, comm_world = 0;

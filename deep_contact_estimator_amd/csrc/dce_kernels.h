@@ -40,6 +40,9 @@ struct Tuning {
     long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // windows up to which the one-window / half-window / quarter-window conv kernels run (-1: kernel default 256 / 128 / 64)
     bool wino1_w8 = true;                                   // 0: the four-wave predecessor of the one-window kernel
     bool online_graph = false, online_direct = false;       // online pushes as ONE captured hipGraph launch / as plain launches with per-push parameters
+    bool latency = false;                                   // 1: the LATENCY MODE (latency.hip; DCE_FP32 only): one-window calls as one kernel of 256 co-resident workgroups, online pushes served by a resident kernel that polls a mailbox in pinned memory.  Inside the fp32 tolerance, NOT the batch path's bits
+    int latency_fc_delay = 100;                             // 10 ns ticks by which the fc.0 role starts its 38.8 MB weight stream behind the conv role (one-window calls: 30.1 us with 0, 28.0 with 1 us, 28.6 / 28.9 with 3 / 6 us -- the conv role's first weight fragments would queue behind the stream; profiles/r5h_latency_ab.txt)
+    int latency_idle_ms = 250;                              // ... how long the resident kernel waits for the next sample before it leaves by itself
     // -- DCE_BF16_FC
     bool bf16_stream = true;                                // 0: fc.0 / fc.3 at <= 256 windows on the 64x64 tile GEMM instead of fc_stream_bf16.hip
     long long x3_bf16_min = 1;                              // windows from which the mode's conv stack runs on conv_x3.hip (below: the fp32 kernels, features rounded on the store)
@@ -244,6 +247,43 @@ hipError_t launch_online_append(float* row, const OnlineSample& s, hipStream_t s
 struct OnlineState { long long src_row; int cursor; unsigned seq; };
 constexpr int ONLINE_ROWS = 4096;     // rows of the sample buffer; the last 149 move to the front when it is full
 hipError_t launch_online_append_state(float* ring, OnlineState* state, const float* sample_host, hipStream_t st);
+
+// ---- latency mode (latency.hip; option latency=1): one window through the whole net in ONE kernel of 256 co-resident workgroups
+struct LatSync { unsigned long long feat; unsigned quit, pad; };               // fine-grained device memory: arrivals of the conv segments (monotonic: request s waits for 4 s), the service's quit word
+struct LatMailbox {                                                            // pinned host memory, device-visible, coherent
+    unsigned req;              // host -> device: number of the newest request (written LAST, release)
+    unsigned kind;             //   0 append the sample, 1 append + estimate, 2 quit
+    float    sample[54];
+    unsigned ack[4];           // device -> host: conv workgroup i has taken request ack[i] (the sample slot is free)
+    unsigned alive;            //   1 while the service kernel runs
+    unsigned error;            //   a wait ran into its deadline (one shot or service)
+    // The estimate: TWO 64-byte lines, each written by ONE 16-lane store and each carrying the estimate's number in its last word.  The
+    // device's writes to host memory may arrive line by line in any order (PCIe relaxed ordering: a separate "done" word was seen by the
+    // host ahead of the logits' line); a line, though, arrives whole: the host waits until BOTH lines carry the number it expects.
+    struct alignas(64) LineA { float logits[15]; unsigned tag; } a;
+    struct alignas(64) LineB { float logit15; int pred; unsigned char contacts[4]; unsigned pad[12]; unsigned tag; } b;
+};
+static_assert(sizeof(LatMailbox::LineA) == 64 && sizeof(LatMailbox::LineB) == 64, "one line each");
+struct LatArgs {
+    ConvPack pk;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;                                  // fc.0 / fc.3 / fc.6 in PyTorch layout
+    float* feat;                                                               // fine-grained device memory: one row of features,
+    unsigned long long *h1, *h2;                                               // ... h1 / h2 as (value, tag) words: tag = the number of the request that wrote them
+    LatSync* sync;
+    LatMailbox* mbox;
+    unsigned long long seq;                                                    // number of this (first) request (>= 1; counted from the last zeroing of the exchange memory)
+    unsigned long long deadline_ticks, idle_ticks;                             // 100 MHz ticks: every wait's deadline; service: how long to wait for a request
+    // one shot
+    const float* src; float* logits; int32_t* pred; uint8_t* contacts; uint8_t* packed;
+    // service
+    float* hist; int* hist_state;                                              // device copy of the last 150 samples [150][54] and {head, count}
+    unsigned req_base, done_base;                                              // mailbox numbers at launch (requests posted / estimates delivered so far)
+    unsigned long long fc_delay_ticks;                                         // (A/B) the fc.0 role starts its weight stream this much later
+    unsigned long long* trace;                                                 // NULL, or 16 wall-clock stamps of the last request (tools/latency_mode.py)
+};
+hipError_t init_latency();
+int        latency_grid();                                                     // workgroups = CUs the mode needs
+hipError_t launch_latency(int mode /* 0 one window, pre-normalised; 1 raw rows (z-score fused); 2 service */, const LatArgs& a, hipStream_t st);
 
 // counts[gt*16 + pred] += 1 over n (pred, label) pairs; out-of-range classes are skipped
 hipError_t launch_confusion16(const int32_t* pred, const int64_t* label, int64_t n,

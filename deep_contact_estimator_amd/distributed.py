@@ -55,6 +55,8 @@ def pack_results(out):
     lg = out["logits"].contiguous()
     n = lg.shape[0]
     buf = torch.empty((n, PACK_COLS), dtype=torch.uint8, device=lg.device)
+    if n == 0:                                           # a rank without windows (fewer windows than ranks): an empty block
+        return buf                                       # (a zero-row tensor from numpy has stride 0 and cannot be re-viewed)
     buf[:, :64] = lg.view(torch.uint8).reshape(n, 64)
     buf[:, 64:] = out["contacts"]
     return buf

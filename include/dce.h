@@ -291,6 +291,11 @@ const char* dce_last_error(dce_ctx* ctx);
  * (tests/test_x3_gpu.py::test_split_terms_are_exact).  No device involved. */
 void dce_debug_split3(const float* x, size_t n, unsigned short* planes);
 
+/* Debug hook of the latency mode (option latency=1, contexts created with DCE_LAT_TRACE set): 16 stamps of the device's 100 MHz wall
+ * clock taken by the last request -- [0] request seen, [1] window ready, [2] conv segment 0 done, [3] its arrival posted, [4] features
+ * seen by fc workgroup 0, [5] its fc.0 rows done, [6] h1 complete, [7] its fc.3 rows done, [8] h2 complete, [9]/[10] results written. */
+int  dce_debug_latency_trace(dce_ctx* ctx, unsigned long long stamps[16]);
+
 #ifdef __cplusplus
 }
 #endif

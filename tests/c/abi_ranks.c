@@ -3,7 +3,7 @@
  * ncclUniqueId of rank 0 carried to the others through a file, libdce.so's own communicator, one gather of the packed rows
  * (reference src/inference_one_seq.py:137-156 is single-device; this is the boundary a C / C++ host would use for 8 GPUs).
  *
- *   abi_ranks --rank R --world W --id-file F [--device D] [--windows N] [--nonce S] [--dry-run]
+ *   abi_ranks --rank R --world W --id-file F [--device D] [--windows N] [--nonce S] [--dry-run] [--delay-ms MS]
  *
  * Rendezvous: rank 0 removes a left-over F, draws the id and writes <16-byte nonce><128-byte id> to F.tmp, renames it to F;
  * the other ranks poll F and accept it only if its nonce is theirs (a file left by an earlier job is ignored, not trusted);
@@ -90,7 +90,7 @@ static int rendezvous(const char* path, int rank, const uint8_t nonce[NONCE], ui
 
 int main(int argc, char** argv)
 {
-    int rank = -1, world = -1, device = -1, dry = 0;
+    int rank = -1, world = -1, device = -1, dry = 0, delay_ms = 0;
     long nwin = 1000;
     const char* path = NULL;
     const char* nonce_s = getenv("DCE_COMM_NONCE");
@@ -102,9 +102,11 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[a], "--id-file") && a + 1 < argc) path = argv[++a];
         else if (!strcmp(argv[a], "--nonce") && a + 1 < argc) nonce_s = argv[++a];
         else if (!strcmp(argv[a], "--dry-run")) dry = 1;
+        else if (!strcmp(argv[a], "--delay-ms") && a + 1 < argc) delay_ms = atoi(argv[++a]);    /* a rank that comes late (rehearsals) */
         else { fprintf(stderr, "usage: abi_ranks --rank R --world W --id-file F [--device D] [--windows N] [--nonce S] [--dry-run]\n"); return 64; }
     }
     g_rank = rank;
+    if (delay_ms > 0) { struct timespec nap = {delay_ms / 1000, (long)(delay_ms % 1000) * 1000000L}; nanosleep(&nap, NULL); }
     CHECK(rank >= 0 && world >= 1 && rank < world && path && nwin >= 1, "need --rank R --world W (R < W) --id-file F");
     uint8_t nonce[NONCE] = {0};
     if (nonce_s) { const size_t l = strlen(nonce_s); memcpy(nonce, nonce_s, l < NONCE ? l : NONCE); }
@@ -116,6 +118,11 @@ int main(int argc, char** argv)
         const int rc = rendezvous(path, rank, nonce, id, timeout_s);
         CHECK(rc == 0, "rendezvous failed (%d): %s", rc, rc == 2 ? "no id with this job's nonce appeared" : "cannot write the id file");
         for (int k = 0; k < DCE_COMM_ID_BYTES; ++k) CHECK(id[k] == (uint8_t)(3 * k + 1), "id byte %d differs", k);
+        {   /* the partition every rank derives by itself: contiguous ranges, sizes differ by at most one (deep_contact_estimator_amd/distributed.py shard_range) */
+            const long q = nwin / world, rem = nwin % world;
+            const long lo = rank * q + (rank < rem ? rank : rem), hi = lo + q + (rank < rem ? 1 : 0);
+            printf("abi_ranks[%d]: shard [%ld, %ld) of %ld windows\n", rank, lo, hi, nwin);
+        }
         printf("abi_ranks[%d]: OK (dry run: rendezvous of %d ranks through %s)\n", rank, world, path);
         return 0;
     }

@@ -71,6 +71,33 @@ def test_n_rank_client_rendezvous_without_a_gpu(tmp_path):
     assert r.returncode != 0 and "no id with this job's nonce" in r.stderr
 
 
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+def test_eight_rank_rendezvous_rehearsal_without_a_gpu(tmp_path):
+    """The first contact with an 8-GPU node, rehearsed as far as a box without one allows: EIGHT torch-free ranks (tests/c/abi_ranks.c
+    --dry-run under tools/launch_ranks.sh) meet through the id file with a stale file of another job in place and one rank 1.5 s
+    late; every rank derives its shard of 1,000,003 windows by itself and the eight shards tile the range with sizes one apart; a ninth
+    process with another job's nonce is refused."""
+    import re
+    exe = _build_ranks(str(tmp_path / "abi_ranks"))
+    idf = tmp_path / "id"
+    idf.write_bytes(b"s" * 144)                                  # left behind by an earlier job
+    env = dict(os.environ, DCE_COMM_ID_FILE=str(idf), DCE_COMM_TIMEOUT="30", DCE_LAUNCH_LATE="5:1500")
+    r = subprocess.run([os.path.join(ROOT, "tools", "launch_ranks.sh"), "8", exe, "--dry-run", "--windows", "1000003"], env=env,
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("OK (dry run") == 8 and "all 8 ranks OK" in r.stdout
+    shards = sorted((int(m.group(1)), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"abi_ranks\[(\d)\]: shard \[(\d+), (\d+)\) of 1000003", r.stdout))
+    assert [s[0] for s in shards] == list(range(8)) and shards[0][1] == 0 and shards[-1][2] == 1000003
+    assert all(a[2] == b[1] for a, b in zip(shards, shards[1:]))
+    sizes = [s[2] - s[1] for s in shards]
+    from deep_contact_estimator_amd.distributed import shard_sizes
+    assert sizes == shard_sizes(1000003, 8) and max(sizes) - min(sizes) == 1
+    env = dict(os.environ, DCE_COMM_TIMEOUT="1")
+    r = subprocess.run([exe, "--rank", "7", "--world", "8", "--id-file", str(idf), "--nonce", "another-job", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no id with this job's nonce" in r.stderr
+
+
 def test_python_id_file_rendezvous_rejects_a_stale_id(tmp_path, monkeypatch):
     """distributed.id_file_rendezvous (DCE_COMM_ID_FILE without a torch.distributed group): same file format, same rules."""
     import threading

@@ -53,7 +53,8 @@ def test_entry_scripts_on_synthetic_config(tmp_path):
     assert len(lines) - i0 == 78 + 6                       # the reference's report: 46 labelled lines (6 matrices of 2 rows), 32 raw
 
 
-def test_entry_scripts_sharded_over_two_processes(tmp_path):
+@pytest.mark.parametrize("nproc", [2, 8])
+def test_entry_scripts_sharded_over_two_processes(nproc, tmp_path):
     """The multi-GPU launch of the entry scripts (one process per rank under torch.distributed.run),
     on ONE GPU: two ranks share it and exchange over gloo (RCCL refuses two ranks per device), which
     exercises everything but the transport -- halo sharding, per-rank fused pass, gather of the (N,4)
@@ -77,8 +78,8 @@ def test_entry_scripts_sharded_over_two_processes(tmp_path):
     tpath = tmp_path / "test_params.yaml"
     yaml.safe_dump(tcfg, open(tpath, "w"))
     env = dict(os.environ, PYTHONPATH=ROOT, DCE_DIST_BACKEND="gloo")
-    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-              "--master-addr", "127.0.0.1", "--master-port", "29571"]
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+              "--master-addr", "127.0.0.1", "--master-port", str(29571 + nproc)]      # (8: the ranks of an 8-GPU node, here sharing the one GPU over gloo; 301 windows = 38 / 37 per rank)
 
     r = subprocess.run(launch + ["-m", "deep_contact_estimator_amd.inference_one_seq", "--config_name", str(cfg_path)],
                        env=env, capture_output=True, text=True, timeout=600)
@@ -119,6 +120,29 @@ def test_bench_two_rank_flow():
     sh = j["extra"]["sharded_1e6"]                       # BASELINE configs[3] literally, measured in the same run
     assert sh["windows_per_s_incl_gather"] > 0 and abs(sh["gathered_MB"] - 2 * 1_000_000 * 68 / 1e6) < 1e-9
     assert abs(j["value"] - 2 * 4096 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
+
+
+def test_bench_eight_rank_flow_rehearsal():
+    """The driver's `bench.py --gpus 8` command line, rehearsed with the eight ranks sharing this box's one GPU over gloo
+    (RCCL refuses two ranks on one device): eight per-rank records, the weak-scaling arithmetic of the line, and configs[3]'s
+    sharded pass on 1,000,003 windows -- ragged shards of 125,001 / 125,000 -- gathered to rank 0."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, DCE_DIST_BACKEND="gloo", DCE_SHARDED_TOTAL="1000003", DCE_EXTRA_TIMEOUT="600")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29591", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--steps", "3", "--warmup", "1", "--settle-s", "0.2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["config"]["global_batch"] == 8 * j["config"]["batch_per_gpu"]
+    assert abs(j["value"] - 8 * 4096 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6
+    pr = j["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and 0 <= pr["rank_of_max"] < 8 and abs(pr["ms_per_step_max"] - j["ms_per_step"]) / j["ms_per_step"] < 0.05
+    sh = j["extra"]["sharded_1e6"]
+    assert sh["windows"] == 1000003 and sh["windows_per_s_incl_gather"] > 0 and abs(sh["gathered_MB"] - 1000003 * 68 / 1e6) < 1e-9, sh
+    assert not j.get("partial")
 
 
 def test_bench_self_launch_from_the_plain_command_line():

@@ -44,6 +44,38 @@ def test_pack_unpack_is_bit_exact():
     assert shard_sizes(10, 4) == [3, 3, 2, 2] and shard_sizes(0, 3) == [0, 0, 0] and sum(shard_sizes(8_000_000, 8)) == 8_000_000
 
 
+def test_shards_pack_and_unpack_for_every_world_size_up_to_eight():
+    """SURVEY 8(e)'s partition for every world size 1..8 and window counts around the multiples of 8 (and configs[3]'s 8e6, and a
+    count that leaves a remainder on an 8-GPU node): contiguous cover, sizes within one of each other, halo rows exactly 149 past
+    the last window, empty shards when there are fewer windows than ranks; and the gather's wire format through those very sizes --
+    per-rank blocks packed, concatenated in rank order, unpacked -- reproduces the single-process arrays bit for bit."""
+    import torch
+    from deep_contact_estimator_amd.distributed import shard_range, shard_rows, shard_sizes, pack_results, unpack_results
+    rng = np.random.default_rng(8)
+    counts = sorted({0, 1, 2, 7, 8, 9, 15, 16, 17, 23, 24, 25, 63, 64, 65, 1000, 1_000_003, 8_000_000} | {8 * k + d for k in (1, 5, 13) for d in (-1, 0, 1)})
+    for world in range(1, 9):
+        for n in counts:
+            sizes = shard_sizes(n, world)
+            assert len(sizes) == world and sum(sizes) == n and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+            lo = 0
+            for r in range(world):
+                a, b = shard_range(n, r, world)
+                assert (a, b) == (lo, lo + sizes[r]) if n else (a, b) == (0, 0)
+                r0, r1, w0, w1 = shard_rows(n + 149, r, world)
+                assert (w0, w1) == (a, b) and ((r0, r1) == (a, b + 149) if b > a else (r0, r1) == (0, 0))
+                lo += sizes[r]
+        n = 8 * 13 + world - 3                                  # the wire format through these sizes
+        lg = rng.standard_normal((n, 16)).astype(np.float32)
+        pred = lg.argmax(1).astype(np.int32)
+        contacts = ((pred[:, None] & np.array([8, 4, 2, 1])) != 0).astype(np.uint8)
+        blocks, lo = [], 0
+        for sz in shard_sizes(n, world):
+            blocks.append(pack_results({"logits": torch.from_numpy(lg[lo:lo + sz]), "contacts": torch.from_numpy(contacts[lo:lo + sz])}))
+            lo += sz
+        back = unpack_results(torch.cat(blocks))
+        assert np.array_equal(back["logits"].numpy(), lg) and np.array_equal(back["pred"].numpy(), pred) and np.array_equal(back["contacts"].numpy(), contacts)
+
+
 def _worker(rank, world, port, T, out_path, local_slices=False):
     sys.path.insert(0, ROOT)
     import torch
@@ -74,9 +106,10 @@ def _worker(rank, world, port, T, out_path, local_slices=False):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("T,local_slices", [(150 + 60, False), (150 + 2, False), (151, False),   # even split, tiny, one rank empty
                                             (150 + 61, True), (151, True)])                         # ranks hold only their rows
-def test_two_rank_gather_matches_single_process(T, local_slices, tmp_path):
+def test_two_rank_gather_matches_single_process(T, local_slices, world, tmp_path):
     import torch.multiprocessing as mp
     from deep_contact_estimator_amd import synth
     from oracle import oracle as orc
@@ -84,7 +117,9 @@ def test_two_rank_gather_matches_single_process(T, local_slices, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "gathered.npz")
-    mp.spawn(_worker, args=(2, port, T, out, local_slices), nprocs=2, join=True)
+    if world == 8 and (T, local_slices) not in ((150 + 60, False), (150 + 61, True), (150 + 2, False)):
+        pytest.skip("the 8-rank rehearsal runs the ragged, the rank-local and the mostly-empty case")
+    mp.spawn(_worker, args=(world, port, T, out, local_slices), nprocs=world, join=True)
     got = np.load(out)
     ref = orc.Oracle(synth.make_state_dict(1, "uniform")).infer_sequence(
         synth.make_sequence(T, 17).astype(np.float32))

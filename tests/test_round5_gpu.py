@@ -169,3 +169,89 @@ def test_split_guard_leaves_the_zscore_entry_alone_and_can_be_switched_off(orc):
     assert not off.split_guard()["enabled"]
     assert np.array_equal(r_off["logits"], r_on["logits"])        # in range: the guard changes nothing
     a.close(); off.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# latency mode (csrc/latency.hip): one window in one kernel; online pushes through a resident kernel and a mailbox
+# ------------------------------------------------------------------------------------------------
+def test_latency_mode_one_window_calls_vs_oracle(orc):
+    """option latency=1: a one-window call (the reference's shipped batch_size 1, config/inference_one_seq_params.yaml:10) is ONE
+    kernel -- four conv-segment workgroups and 252 fc workgroups that hold their neurons' weights in registers, meeting through
+    arrival counters.  Not the batch path's bits (K is folded over the lanes by a tree), but inside the fp32 contract of the ORACLE:
+    pre-normalised and raw (z-score fused) windows, host and device pointers, packed rows, a non-finite window; two windows and
+    more take the batch path's kernels."""
+    import torch
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    m, b = _model("fp32", sd, max_batch=64, tune={"latency": 1}), _model("fp32", sd, max_batch=64)
+    seq = synth.make_sequence(150 + 95, seed=21, kind="ar1").astype(np.float32)
+    zw = orc.zscore_windows(seq)
+    ref = orc.Oracle(sd).forward_windows(zw)
+    n = zw.shape[0]
+    got = np.stack([m.predict(zw[i:i + 1])["logits"][0] for i in range(n)])
+    assert m.last_plan() == ["latency_one"], m.last_plan()
+    tol_ok(got, ref["logits"], "latency mode, one pre-normalised window per call")
+    pred = np.array([int(m.predict(zw[i:i + 1])["pred"][0]) for i in range(n)])
+    _argmax_contract(pred, ref)
+    # raw rows: dce_infer_sequence with T = 150
+    got_z = np.stack([m.infer_sequence(seq[i:i + 150])["logits"][0] for i in range(n)])
+    assert m.last_plan() == ["latency_one_zs"], m.last_plan()
+    tol_ok(got_z, ref["logits"], "latency mode, one raw window per call")
+    # device pointers (asynchronous on torch's stream), contacts, packed rows; repeated calls are bit-stable
+    xt = torch.from_numpy(zw).cuda()
+    outs = [m.predict(xt[i:i + 1]) for i in range(n)]
+    torch.cuda.synchronize()
+    dev = np.stack([o["logits"][0].cpu().numpy() for o in outs])
+    assert np.array_equal(dev, got)
+    assert np.array_equal(np.stack([o["contacts"][0].cpu().numpy() for o in outs]), orc.decimal2binary(pred))
+    pk = m.predict_packed(xt[3:4]).cpu().numpy()
+    assert np.array_equal(pk[0, :64].view(np.float32), got[3]) and np.array_equal(pk[0, 64:], orc.decimal2binary(pred[3:4])[0])
+    # the batch path is within the tolerance of it too, and is what two or more windows run
+    tol_ok(got, b.predict(zw)["logits"], "latency mode vs the batch path")
+    two = m.predict(zw[:2])
+    assert "latency_one" not in m.last_plan() and np.array_equal(two["logits"], b.predict(zw[:2])["logits"])
+    bad = zw[5:6].copy(); bad[0, 17, 3] = np.nan
+    r = m.predict(bad)
+    assert np.isnan(r["logits"]).all() and r["pred"][0] == 0
+    tol_ok(m.predict(zw[6:7])["logits"], ref["logits"][6:7], "after a non-finite window")
+    m.close(); b.close()
+
+
+def test_latency_mode_online_pushes_vs_oracle(orc):
+    """dce_online_push in the latency mode: a resident kernel takes each sample from a mailbox in pinned memory (no launch, no copy
+    per push), keeps the last 150 in LDS and answers through the mailbox.  4,350 pushes -- beyond the 4096-row compaction of the
+    batch path's sample buffer -- every estimate against the ORACLE on the same rows (fp32 contract + argmax), then: the kernel leaves
+    by itself when no sample comes (latency_idle_ms) and the next push restarts it with the history intact; another call on the model
+    (predict) makes it leave and pushes continue; a reset starts a new sequence."""
+    import time
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    T = 150 + 4200
+    seq = synth.make_sequence(T, seed=33).astype(np.float32)
+    ref = orc.Oracle(sd).infer_sequence(seq)
+    m = _model("fp32", sd, max_batch=64, tune={"latency": 1, "latency_idle_ms": 30})
+    m.online_reset()
+    rows = []
+    for t in range(T):
+        if t == 2000:
+            time.sleep(0.2)                                        # the service leaves (30 ms without a sample) ...
+        if t == 3000:
+            m.predict(seq[:150][None] * 0 + 1)                     # ... or is told to: another call needs the device
+        r = m.online_push(seq[t])
+        assert (r is None) == (t < 149), t
+        if r is not None:
+            rows.append((r[0].copy(), r[1], r[2].copy()))
+    logits = np.stack([r[0] for r in rows]); pred = np.array([r[1] for r in rows]); contacts = np.stack([r[2] for r in rows])
+    assert logits.shape == ref["logits"].shape
+    tol_ok(logits, ref["logits"], "latency mode, online pushes vs the oracle")
+    _argmax_contract(pred, ref)
+    assert np.array_equal(contacts, orc.decimal2binary(pred))
+    assert np.array_equal(pred, logits.argmax(1))
+    # a reset starts over: the first 149 pushes answer nothing, the 150th is window 0 of the new sequence
+    m.online_reset()
+    seq2 = synth.make_sequence(150 + 20, seed=34, kind="ar1").astype(np.float32)
+    ref2 = orc.Oracle(sd).infer_sequence(seq2)
+    got2 = [m.online_push(s) for s in seq2]
+    assert all(g is None for g in got2[:149])
+    tol_ok(np.stack([g[0] for g in got2[149:]]), ref2["logits"], "after a reset")
+    m.close()
