@@ -56,6 +56,7 @@ struct Tuning {
     bool split_guard = true;                                // 0: no range guard (static bound at finalize, per-window exponent check + fp32 fallback): the round-4 behaviour, for the A/B and the audit
     // -- experiments build only (ignored by the product library)
     bool gemm_lockstep = false, gemm_pipe = false, gemm_ki = false;
+    bool bf16_k32 = false;                                  // fc.0's 256x128 bf16 tile with 32-k K-tiles, two workgroups per CU, from 512 tiles per launch (fc_gemm_phased.hip PhTile<3>; round 5: measured 22 % slower)
     int conv4 = 0;
     bool x3_persist = false, x3_pair = false;
     long long x3_persist_min = 1024, x3_pair_min = 1024;

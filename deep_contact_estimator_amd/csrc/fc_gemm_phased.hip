@@ -69,12 +69,13 @@ template <int TM, int TN, int ROWB> struct PhCfg {
     static constexpr int SLOTS = ROWB / 16, CROWS = 64 / SLOTS;    // 16-byte slots per row; rows per 1 KB chunk
     static constexpr int NA = BM / CROWS / 8, NW = BN / CROWS / 8; // 1 KB chunks per wave per K-tile: of A, of W
     static constexpr int KQ = ROWB / 32;                           // 32-byte column pairs (fragment loads per row per tile)
-    static_assert(ROWB == 128 || ROWB == 256, "");
+    static_assert(ROWB == 64 || ROWB == 128 || ROWB == 256, "");
     static_assert((NA == 4 && NW == 2) || (NA == 2 && NW == 1), "issue_tile is written for 4+2 and 2+1 chunks");
     static_assert(LDS <= 160 * 1024, "three K-tiles in LDS");
     // bank swizzle: 16-byte column c of row r is stored at slot c ^ swz(r); conflict-free for ds_read_b128's
     // lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (lane = row): 8 slots need (r>>1)&7, 16 slots r&15
-    __device__ static constexpr int swz(int r) { return SLOTS == 8 ? (r >> 1) & 7 : r & 15; }
+    // (4 slots -- 64-byte rows, the 32-k K-tiles of round 5's two-workgroups-per-CU experiment: (r >> 2) & 3, as fc_gemm_x3.hip found for its 64-byte rows)
+    __device__ static constexpr int swz(int r) { return SLOTS == 4 ? (r >> 2) & 3 : SLOTS == 8 ? (r >> 1) & 7 : r & 15; }
 };
 
 __device__ __forceinline__ unsigned short f32_to_bf16(float f)
@@ -139,7 +140,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p)
 // summation tree (fc6_chain.h), so the epilogue finishes that chunk -- h2 tile -> LDS -> 16 MFMAs per 16 rows
 // -> chunk sums to `part` ([8][part_rows][16]) -- and h2 itself goes to HBM only when Cv != NULL (taps).
 template <bool BF16, bool OUT_BF16, int TM, int TN, int ROWB, bool FUSE6, bool LOCKSTEP>
-__global__ __launch_bounds__(512, 2)
+__global__ __launch_bounds__(512, ROWB == 64 ? 4 : 2)       // (64-byte K-tiles: 3 x 24 KB of LDS and <= 128 VGPRs -> TWO workgroups per CU)
 void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                            const float* __restrict__ bias, void* __restrict__ Cv,
                            int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2,
@@ -254,9 +255,13 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
     // LDS byte offsets of this lane's fragment columns, one set per buffer, made opaque so that they STAY in
     // registers: recomputed inside the loop they are VALU instructions of the load phase, and a VALU instruction
     // of the wave that shares a SIMD with a wave streaming MFMAs waits for that wave's next MFMA to issue
-    unsigned pa[PH_NBUF][KQ], pb[PH_NBUF][KQ];
+    // (64-byte K-tiles run under a 128-register budget: one address per kq, the buffer -- 24 KB apart, inside ds_read_b128's 16-bit
+    //  offset field -- folded into the instruction as an immediate)
+    constexpr int PAB = ROWB == 64 ? 1 : PH_NBUF;
+    static_assert(ROWB != 64 || 2 * Cfg::TILE + 32 * ROWB * (TM > TN ? TM : TN) < 65536, "buffer + block offsets fit the LDS instructions' immediate");
+    unsigned pa[PAB][KQ], pb[PAB][KQ];
 #pragma unroll
-    for (int b = 0; b < PH_NBUF; ++b)
+    for (int b = 0; b < PAB; ++b)
 #pragma unroll
         for (int kq = 0; kq < KQ; ++kq) {
             pa[b][kq] = b * Cfg::TILE + arow + fo[kq];
@@ -268,9 +273,9 @@ void fc_gemm_phased_kernel(const void* __restrict__ Av, const void* __restrict__
 #pragma unroll
         for (int kq = 0; kq < KQ; ++kq) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[kq][a] = *reinterpret_cast<const float4*>(smem + pa[b][kq] + a * 32 * ROWB);
+            for (int a = 0; a < TM; ++a) af[kq][a] = *reinterpret_cast<const float4*>(smem + pa[PAB == 1 ? 0 : b][kq] + (PAB == 1 ? b * Cfg::TILE : 0) + a * 32 * ROWB);
 #pragma unroll
-            for (int c = 0; c < TN; ++c) bf[kq][c] = *reinterpret_cast<const float4*>(smem + pb[b][kq] + c * 32 * ROWB);
+            for (int c = 0; c < TN; ++c) bf[kq][c] = *reinterpret_cast<const float4*>(smem + pb[PAB == 1 ? 0 : b][kq] + (PAB == 1 ? b * Cfg::TILE : 0) + c * 32 * ROWB);
         }
     };
     auto math = [&](const float4 (&af)[KQ][TM], const float4 (&bf)[KQ][TN]) {
@@ -825,6 +830,15 @@ void fc_gemm_pipe_kernel(const void* __restrict__ Av, const void* __restrict__ W
 template <int T> struct PhTile;
 template <> struct PhTile<2> { static constexpr int TM = 2, TN = 2, ROWB = 128; };
 template <> struct PhTile<1> { static constexpr int TM = 1, TN = 1, ROWB = 256; };
+// tile 3 (bf16 only, option bf16_k32=1, EXPERIMENTS BUILD; round 5's one experiment on this GEMM): the 256 x 128 tile with 32-k K-tiles --
+// 3 x 24 KB of LDS and 128 registers, so that TWO workgroups share a CU and each one's phase hand-overs are covered by the other's MFMA
+// phase (what took conv_x3 from 308 to 171 us); it needs >= 512 tiles per launch (8192 windows of fc.0).  MEASURED (profiles/r5i_gemm_k32.txt):
+// bit-identical and SLOWER -- fc.0 at 8192 windows 164-166 us against 134 (0.385 against 0.474 of 2.5 PF), at 32768 windows 677-679 against
+// 567-568.  The counters say why: twice the waves are resident (SQ_WAVE_CYCLES 2.84e8 against 1.12e8) for the same MFMA cycles in 1.47x
+// the time; the 64-byte row pieces of a 32-k K-tile double the L2 requests (TCC_REQ 2.95e7 against 1.51e7) through a per-CU address path
+// that the 64-k kernel already keeps busy 768 of 1024 cycles; waves wait 2.2x as long (SQ_WAIT_INST_ANY).  Two workgroups do not cover each
+// other here because what they wait for is the same LDS-DMA path.  With this the bf16 GEMM is closed.
+template <> struct PhTile<3> { static constexpr int TM = 2, TN = 2, ROWB = 64; };
 
 // Schedule: the two-groups-one-phase-apart loop ships for both precisions; DCE_GEMM=lockstep selects the other loop
 // (kept as a tested A/B variant).  Measured (r2q, interleaved rounds of the bench step):
@@ -877,6 +891,9 @@ hipError_t init_fc_gemm_phased()
     if ((e = grant_phased<true, true, 2>()) != hipSuccess) return e;
     if ((e = grant_phased<true, false, 2>()) != hipSuccess) return e;
     if ((e = grant_phased<true, true, 1>()) != hipSuccess) return e;
+#if DCE_EXPERIMENTS
+    if ((e = grant_phased<true, true, 3>()) != hipSuccess) return e;
+#endif
     return grant_phased<true, false, 1>();
 }
 
@@ -945,7 +962,7 @@ static hipError_t launch_phased_cfg(const void* A, const void* W, const float* b
         }
     }
 #endif
-    plan_note(use_lockstep(BF16) ? (T == 2 ? "fc_lockstep256x128" : "fc_lockstep128x64") : (T == 2 ? "fc_phased256x128" : "fc_phased128x64"));
+    plan_note(use_lockstep(BF16) ? (T == 2 ? "fc_lockstep256x128" : "fc_lockstep128x64") : (T == 3 ? "fc_phased256x128_k32" : T == 2 ? "fc_phased256x128" : "fc_phased128x64"));
 #if DCE_EXPERIMENTS
     if (use_lockstep(BF16))
         hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, true>), dim3(grid), dim3(512), Cfg::LDS, st,
@@ -964,6 +981,11 @@ hipError_t launch_fc_gemm_phased(const void* A, const void* W, const float* bias
     if (t == 0 || (!bf16 && out_bf16)) return hipErrorInvalidValue;
     if (!bf16) return t == 2 ? launch_phased_cfg<false, false, 2>(A, W, bias, C, M, N, K, relu, st)
                              : launch_phased_cfg<false, false, 1>(A, W, bias, C, M, N, K, relu, st);
+#if DCE_EXPERIMENTS
+    // (A/B, bf16_k32=1) the large tile with 32-k K-tiles, two workgroups per CU: needs two tiles per CU
+    if (t == 2 && out_bf16 && tune().bf16_k32 && !use_lockstep(true) && ((M + 255) / 256) * (N / 128) >= 512 && K % 32 == 0 && K >= 128)
+        return launch_phased_cfg<true, true, 3>(A, W, bias, C, M, N, K, relu, st);
+#endif
     if (out_bf16) return t == 2 ? launch_phased_cfg<true, true, 2>(A, W, bias, C, M, N, K, relu, st)
                                 : launch_phased_cfg<true, true, 1>(A, W, bias, C, M, N, K, relu, st);
     return t == 2 ? launch_phased_cfg<true, false, 2>(A, W, bias, C, M, N, K, relu, st)

@@ -171,6 +171,26 @@ def test_split_guard_leaves_the_zscore_entry_alone_and_can_be_switched_off(orc):
     a.close(); off.close()
 
 
+@pytest.mark.experiments
+def test_bf16_gemm_k32_two_workgroups_per_cu_bit_identical():
+    """Round 5's one experiment on the bf16 fc.0 GEMM (option bf16_k32=1, experiments build): the 256 x 128 tile with 32-k K-tiles, two
+    workgroups per CU.  Same MFMA sequence per output as the shipped 64-k kernel: the same bits, a partial last row tile and repeated
+    runs included (measured 22 % slower: profiles/r5i_gemm_k32.txt -- it stays an experiment)."""
+    import torch
+    from deep_contact_estimator_amd import contact_cnn, synth
+    sd = synth.make_state_dict(1, "uniform")
+    for n in (8192, 8192 + 300):
+        x = torch.randn((n, 150, 54), generator=torch.Generator(device="cuda").manual_seed(n), device="cuda")
+        a = contact_cnn(device=0, max_batch=n, precision="bf16_fc", tune={"bf16_k32": 1}); a.load_state_dict(sd).eval()
+        b = contact_cnn(device=0, max_batch=n, precision="bf16_fc", tune={"bf16_k32": 0}); b.load_state_dict(sd).eval()
+        rb = b.predict(x)["logits"].clone()
+        for rep in range(3):
+            ra = a.predict(x)["logits"]
+            assert "fc_phased256x128_k32" in a.last_plan() and "fc_phased256x128_k32" not in b.last_plan(), (a.last_plan(), b.last_plan())
+            assert torch.equal(ra, rb), (n, rep)
+        a.close(); b.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # latency mode (csrc/latency.hip): one window in one kernel; online pushes through a resident kernel and a mailbox
 # ------------------------------------------------------------------------------------------------
