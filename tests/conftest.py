@@ -43,6 +43,11 @@ def tol_ok(got, ref, what="", factor=1.0):
                           f"(bound at worst {bound.reshape(-1)[np.nanargmax(err - bound)]:.3e})"
 
 
+# tests/golden/chip_ar1.npz: the (window, class) logits of the REFERENCE that its own fp32 z-score (utils/data_handler.py:55-56) leaves
+# just outside the fp32 contract of an fp64-statistics evaluation (1.001 .. 1.146 bounds; tests/test_oracle.py pins the list)
+CHIP_AR1_REFERENCE_ZSCORE_OUTLIERS = [(384, 9), (386, 9), (580, 9), (2885, 7), (3584, 5)]
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

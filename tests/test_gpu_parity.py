@@ -272,6 +272,30 @@ def test_full_size_properties(models, orc):
     ref = o.forward_windows(zs)
     tol_ok(logits[idx], ref["logits"], "1e6-run rows vs oracle")
     _argmax_contract(pred[idx], contacts[idx], ref["logits"], ref["pred"], ref["contacts"])
+    # (3) a CONTIGUOUS 65,536-window slice of the run -- two whole 32768-window launches -- against the oracle on the same rows:
+    #     every logit inside the fp32 contract, argmax and contact bits exact outside the noise margin
+    lo, span = 393_216, 65_536
+    rows_np = seq[lo:lo + span + 149].cpu().numpy()
+    ref = o.infer_sequence(rows_np)
+    tol_ok(logits[lo:lo + span], ref["logits"], "1e6-run, 65,536 contiguous windows vs oracle (fp32)")
+    _argmax_contract(pred[lo:lo + span], contacts[lo:lo + span], ref["logits"], ref["pred"], ref["contacts"])
+    # ... and the same slice in the bf16_fc precision (BASELINE configs[4]) against the CPU restatement of the MODE: the mode's band
+    # (3e-3 of the largest logit, include/dce.h), argmax exact wherever the top-2 margin exceeds 1e-2 of it
+    from deep_contact_estimator_amd import contact_cnn
+    mb = contact_cnn(device=0, max_batch=32768, precision="bf16_fc"); mb.load_state_dict(synth.make_state_dict(1, "uniform")).eval()
+    ob = mb.infer_sequence(seq)
+    torch.cuda.synchronize()
+    lb = ob["logits"].cpu().numpy(); pb = ob["pred"].cpu().numpy()
+    assert lb.shape == (N, 16) and np.isfinite(lb).all() and np.array_equal(pb, lb.argmax(axis=1))
+    refb = orc.Oracle(synth.make_state_dict(1, "uniform"), bf16_fc=True).infer_sequence(rows_np)
+    scale = np.abs(refb["logits"]).max()
+    err = np.abs(lb[lo:lo + span] - refb["logits"]).max()
+    assert err <= 3e-3 * scale, (err, scale)
+    srt = np.sort(refb["logits"], axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 1e-2 * scale
+    assert np.array_equal(pb[lo:lo + span][safe], refb["pred"][safe])
+    assert (pb[lo:lo + span] != refb["pred"]).mean() < 5e-3
+    mb.close()
 
 
 def test_bf16_fc_precision(models, orc):
@@ -393,9 +417,10 @@ def test_context_lifecycle_and_isolation(models):
         m.close()                                        # idempotent
 
 
-def test_online_mode_matches_sequence(models):
+def test_online_mode_matches_sequence(models, orc):
     """pushing a sequence one sample at a time reproduces dce_infer_sequence
-    row for row, bit for bit -- including across the ring compaction (every 3947 pushes)."""
+    row for row, bit for bit -- including across the ring compaction (every 3947 pushes) -- and the pushes'
+    estimates are held to the ORACLE directly (fp32 contract, argmax), not only through the sequence path."""
     import time
     from deep_contact_estimator_amd import synth
     m = models()
@@ -415,6 +440,9 @@ def test_online_mode_matches_sequence(models):
     assert np.array_equal(np.stack([r[0] for r in rows]), ref["logits"])
     assert np.array_equal(np.array([r[1] for r in rows], np.int32), ref["pred"])
     assert np.array_equal(np.stack([r[2] for r in rows]), ref["contacts"])
+    oref = orc.Oracle(synth.make_state_dict(1, "uniform")).infer_sequence(seq)
+    tol_ok(np.stack([r[0] for r in rows]), oref["logits"], "online pushes vs the oracle")
+    _argmax_contract(np.array([r[1] for r in rows], np.int32), np.stack([r[2] for r in rows]), oref["logits"], oref["pred"], oref["contacts"])
     m.online_reset()
     assert m.online_push(seq[0]) is None
     print(f"online mode: {dt * 1e6:.0f} us per sample end to end (host sample in, result out)")
@@ -581,19 +609,25 @@ def test_direct_form_conv_kernel(monkeypatch, golden, case_inputs, orc):
     wino.close(); direct.close()
 
 
-@pytest.mark.parametrize("conv", ["winograd", pytest.param("direct", marks=needs_experiments)])
+@pytest.mark.parametrize("conv", ["winograd", pytest.param("direct", marks=needs_experiments), "fp32_split_guarded"])
 def test_forward_windows_bench_batch(conv, monkeypatch, orc):
     """BASELINE configs[1] exactly as bench.py runs it: the 4096 pre-normalised windows of the bench
     step (synthetic sequence seed 2, z-scored by the library, checkpoint seed 1) through
-    dce_forward_windows -- EVERY row against the oracle, on both conv kernels."""
+    dce_forward_windows -- EVERY row against the oracle, on both conv kernels and in the guarded fp32_split
+    precision (three-term bf16 operands behind the range guard: same contract)."""
     from deep_contact_estimator_amd import contact_cnn, synth
     B = 4096
     sd = synth.make_state_dict(1, "uniform")
     seq = synth.make_sequence(B + 149, seed=2).astype(np.float32)
-    m = contact_cnn(device=0, max_batch=B, tune={"conv_direct": 1} if conv == "direct" else None)
+    m = contact_cnn(device=0, max_batch=B, tune={"conv_direct": 1} if conv == "direct" else None,
+                    precision="fp32_split" if conv == "fp32_split_guarded" else "fp32")
     m.load_state_dict(sd).eval()
     w = m.zscore_windows(seq, 0, B)                       # what bench.py materialises in HBM
     out = m.predict(w)
+    if conv == "fp32_split_guarded":
+        g = m.split_guard()
+        assert m.last_plan()[0].startswith("conv_x3") and "fc_x3_256x128" in m.last_plan() and m.last_plan()[-1] == "gated_fp32_fallback", m.last_plan()
+        assert g["enabled"] and not g["refused"] and g["guarded_launches"] == 1 and g["windows_out_of_range"] == 0 and g["fallbacks_run"] == 0, g
     m.close()
     ref = orc.Oracle(sd).forward_windows(w)
     assert out["logits"].shape == (B, 16)

@@ -170,9 +170,15 @@ def test_chip_filling_golden_pins_the_oracle(golden, case_inputs):
     out = orc.Oracle(sd).infer_sequence(seq)
     assert out["logits"].shape == (4096, 16)
     # The reference z-scores in fp32 (utils/data_handler.py:55-56); on this sequence -- offsets up to 5 on spreads down to 0.01 --
-    # its fp32 mean alone is off by up to 5e-5 standard deviations, and 5 of its 65,536 logits sit 1.9 bounds away from the
-    # fp64-statistics evaluation (the 128-window AR(1) fixture stays inside one): three bounds here, argmax exact below.
-    tol_ok(out["logits"], g["logits"], "4096 AR(1) windows vs the reference", factor=3.0)
+    # its fp32 mean alone is off by up to 5e-5 standard deviations.  Against the fp64-statistics evaluation that leaves FIVE of its
+    # 65,536 logits just outside the contract (1.001 .. 1.146 bounds; 41 windows come within 0.7 of it, the 128-window AR(1) fixture
+    # stays inside): those five are named, every other logit is held to the contract as stated.
+    from conftest import CHIP_AR1_REFERENCE_ZSCORE_OUTLIERS as named
+    ref = g["logits"].astype(np.float64)
+    ratio = np.abs(out["logits"].astype(np.float64) - ref) / (1e-5 * np.abs(ref).max() + 1e-4 * np.abs(ref))
+    outside = sorted((int(a), int(b)) for a, b in np.argwhere(ratio > 1.0))
+    assert outside == sorted(named), outside
+    assert max(ratio[a, b] for a, b in named) < 1.2
     safe = g["margin"] > 1e-3 * np.abs(g["logits"]).max()
     assert safe.sum() >= 0.95 * safe.size
     assert np.array_equal(out["pred"][safe], g["pred"][safe])

@@ -23,7 +23,7 @@ def _model(precision, max_batch=8192, tune=None):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp32_split", "bf16_fc"])
-def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs):
+def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs, orc):
     """One 4096-window launch per precision against logits the reference itself produced: fp32 and fp32_split within the fp32
     tolerance and argmax-exact outside the noise margin, bf16_fc within its band (bf16 operands of fc.0 / fc.3)."""
     g = golden("chip_ar1")
@@ -41,9 +41,16 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs):
         assert flips.mean() < 0.02 and (g["margin"][flips] < 4 * err + 1e-6).all()
         assert plan[0].startswith("conv_x2_bf16") and "fc_phased256x128" in plan, plan      # two-term operands: three MFMAs per product
     else:
-        # (three bounds: on this sequence the reference's own fp32 z-score puts 5 of its 65,536 logits 1.9 bounds away from the
-        #  fp64-statistics evaluation -- tests/test_oracle.py::test_chip_filling_golden_pins_the_oracle)
-        tol_ok(out["logits"], ref, f"{precision}: 4096 AR(1) windows vs the reference", factor=3.0)
+        # Against the fp64-statistics evaluation (the oracle) on the same rows: the contract as stated, every logit.  Against the
+        # reference's own numbers: the reference z-scores in fp32 and on this sequence sits up to 1.15 bounds from that evaluation
+        # itself (five named logits outside the contract, tests/conftest.py CHIP_AR1_REFERENCE_ZSCORE_OUTLIERS), so a logit may be
+        # as far from the reference as the contract plus the reference's own distance from the fp64 evaluation -- no blanket factor.
+        o = orc.Oracle(sd).infer_sequence(seq)
+        tol_ok(out["logits"], o["logits"], f"{precision}: 4096 AR(1) windows vs the fp64-statistics evaluation")
+        r64 = ref.astype(np.float64)
+        bound = 1e-5 * np.abs(r64).max() + 1e-4 * np.abs(r64)
+        over = np.abs(out["logits"].astype(np.float64) - r64) - (bound + np.abs(o["logits"].astype(np.float64) - r64))
+        assert (over <= 0).all(), f"{precision}: {(over > 0).sum()} logits further from the reference than the contract + the reference's own z-score noise"
         assert np.array_equal(out["pred"][safe], g["pred"][safe])
         assert (out["pred"] != g["pred"]).sum() <= 2
         if precision == "fp32": assert "fc_phased256x128" in plan and "fc23_fused_phased128x64" in plan, plan
