@@ -63,7 +63,7 @@ const TuneKey kTuneKeys[] = {
     TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
     TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'),
     TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
-    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(split_guard, 'b'),
+    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'),
     TKX(bf16_k32, 'b'), TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
     TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
 };
@@ -181,7 +181,7 @@ int drain_spans(dce_ctx* c)
 // DCE_FP32_SPLIT's range guard, static half (dce_kernels.h GuardArgs has the why).  For inputs |x| <= X every activation of layer l is
 // bounded by  gain[l] X + offs[l]  with  gain[l] = gain[l-1] S_l,  offs[l] = offs[l-1] S_l + max|b_l|,  S_l = max over outputs of the
 // sum of |w| (ReLU and MaxPool do not raise a bound).  The operands the kernels split are the input, the four conv layers' outputs
-// (the last one = the features) and the weights of conv1..4 and fc.0: all must stay below LIM = 2^126 (bf16's largest finite number
+// (the last one = the features), fc.0's output h1 (fc.3 takes three-term operands too) and the weights of conv1..4, fc.0, fc.3: all must stay below LIM = 2^126 (bf16's largest finite number
 // is 2^128 - 2^120; the margin covers the accumulators' rounding), so x_hi = min_l (LIM - offs[l]) / gain[l].  A z-scored window
 // reaches |z| <= (n-1)/sqrt(n) = 12.166 at n = 150 (one sample against 149 equal ones), so a checkpoint whose x_hi is below that is
 // REFUSED: the mode then runs the DCE_FP32 kernels for every call and says so (dce_last_plan, dce_split_guard_info).  The small side:
@@ -214,11 +214,11 @@ void compute_split_guard(dce_ctx* c)
         }
         gain *= smax; offs = offs * smax + bmax;
         g.gain[l] = gain; g.offs[l] = offs;
-        if (l > 4) continue;                                          // fc.3 runs on fp32 operands: its row is information only
+        if (l > 4 && !c->tuning.x3_fc3) continue;                     // fc.3 on fp32 operands (x3_fc3=0): its row is information only
         if (!finite || !std::isfinite(gain) || !std::isfinite(offs)) { snprintf(msg, sizeof msg, "%s holds a non-finite weight or its bound overflows", names[l]); g.refused = true; g.reason = msg; break; }
         if (wmax >= LIM) { snprintf(msg, sizeof msg, "%s: largest |w| %.3g reaches bf16's range limit", names[l], wmax); g.refused = true; g.reason = msg; break; }
         if (wmax < SMALL) { snprintf(msg, sizeof msg, "%s: largest |w| %.3g is below 2^-40 (third terms of the split near the subnormal range)", names[l], wmax); g.refused = true; g.reason = msg; break; }
-        if (l == 4) continue;                                         // fc.0's OUTPUT is not split
+        if (l == 5 || (l == 4 && !c->tuning.x3_fc3)) continue;        // fc.3's output is never split; fc.0's (h1) only when fc.3 takes three-term operands
         if (offs >= LIM) { snprintf(msg, sizeof msg, "%s: activation bound %.3g reaches bf16's range limit whatever the input", names[l], offs); g.refused = true; g.reason = msg; break; }
         if (gain > 0.0 && (LIM - offs) / gain < x_hi) x_hi = (LIM - offs) / gain;
     }
@@ -334,7 +334,7 @@ struct GateScope {
 //                  range: the DCE_FP32 row, gated on the device word the conv kernel raised)
 enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16 };
 enum class Fc0 { F32, Gemv, X3, Bf16 };
-enum class Fc3 { F32, Gemv, Fused, Bf16, FusedBf16 };
+enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16 };
 struct Plan {
     Conv conv; int permk;                 // permk: features (and fc.0's weights) in the K order t' * 128 + c; 2: from persistent workgroups (experiments)
     Fc0 fc0; bool split3;                 // split3: fp32 features split by a kernel of their own in front of fc_gemm_x3 (taps, x3_unfused)
@@ -385,8 +385,9 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
         // tiles = 4096 windows: a batch that ends up to 2048 windows past a round gives that remainder to the chain kernel + tail
         // (same bits, rows are independent) instead of paying a full round for it.
         const int64_t rest = n % 4096;
-        p.fc3 = Fc3::Fused;
-        p.fused_rows = (tu.gemm_peel && !c->gate_on && n > 4096 && rest && (rest <= 8 || fc_split_ok(rest, FC2, FC1) || fc_gemm_chain_ok(rest, FC2, FC1))) ? n - rest : n;
+        p.fc3 = (x3 && !c->want_h1 && c->fc2w_x3 && c->h1p && fc23_x3_ok(n)) ? Fc3::FusedX3 : Fc3::Fused;      // fc.3 on three-term operands too (h1 then leaves fc.0 as three planes)
+        const bool cut = p.fc3 == Fc3::Fused && tu.gemm_peel && !c->gate_on && n > 4096 && rest && (rest <= 8 || fc_split_ok(rest, FC2, FC1) || fc_gemm_chain_ok(rest, FC2, FC1));
+        p.fused_rows = cut ? n - rest : n;
     }
     return p;
 }
@@ -441,7 +442,9 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
       case Fc0::X3:   // fc.0 on the bf16 matrix pipe with three-term operands (fc_gemm_x3.hip); everything behind it as in DCE_FP32
           if (!p.permk) { const int rc = ensure_fc1w_x3(c); if (rc) return rc; }
           if (p.split3) HIP_TRY(c, launch_split3(c->feat, c->feat3, n, FEAT, st));
-          HIP_TRY(c, launch_fc_gemm_x3(c->feat3, p.permk ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, st)); break;
+          if (p.fc3 == Fc3::FusedX3) HIP_TRY(c, launch_fc_gemm_x3(c->feat3, p.permk ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1p, n, FC1, FEAT, 1, st, 1));
+          else HIP_TRY(c, launch_fc_gemm_x3(c->feat3, p.permk ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, st));
+          break;
       case Fc0::Bf16: HIP_TRY(c, launch_fc_gemm_bf16(c->feat, p.permk ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, st)); break;
       } }
     const int64_t nf = p.fused_rows;
@@ -450,6 +453,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
       case Fc3::F32:  HIP_TRY(c, launch_fc_gemm(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, st)); break;
       case Fc3::Gemv: HIP_TRY(c, launch_fc_gemv(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, st)); break;
       case Fc3::Bf16: HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, st)); break;
+      case Fc3::FusedX3: HIP_TRY(c, launch_fc23_fused_x3(c->h1p, c->fc2w_x3, c->fc2b, c->fc3w, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
       case Fc3::FusedBf16: HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
       case Fc3::Fused:
           HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, nf, st));
@@ -457,7 +461,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
           break;
       } }
     { Timer t(c, 3);
-      if (p.fc3 == Fc3::Fused || p.fc3 == Fc3::FusedBf16) {
+      if (p.fc3 == Fc3::Fused || p.fc3 == Fc3::FusedX3 || p.fc3 == Fc3::FusedBf16) {
           HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, st, packed));
           if (nf < n) HIP_TRY(c, launch_fc3_tail(c->h2 + nf * FC2, c->fc3w, c->fc3b, n - nf, logits ? logits + nf * NCLS : nullptr, pred ? pred + nf : nullptr,
                                                  contacts ? contacts + nf * 4 : nullptr, st, nullptr, 0, nullptr, packed ? packed + nf * PACKED_ROW : nullptr));
@@ -750,7 +754,7 @@ void dce_destroy(dce_ctx* c)
     if (c->xfer_stream) { hipStreamSynchronize(c->xfer_stream); hipStreamDestroy(c->xfer_stream); }
     for (auto& slot : c->ring_ev) for (auto e : slot) if (e) hipEventDestroy(e);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->feat3); hipFree(c->h1); hipFree(c->h2); hipFree(c->part);
-    hipFree(c->d_guard); hipFree(c->fc1w_x3_own); hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
+    hipFree(c->d_guard); hipFree(c->fc1w_x3_own); hipFree(c->h1p); hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
     if (c->online_exec) hipGraphExecDestroy(c->online_exec);
     if (c->online_graph) hipGraphDestroy(c->online_graph);
     hipFree(c->d_ring); hipFree(c->d_online_state);
@@ -855,7 +859,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
             to_bf16(w1p.data(), w1p.size(), reinterpret_cast<unsigned short*>(img.data() + off_bfp));
         }
     }
-    size_t off_x3 = 0, off_x3p = 0, off_cx[4] = {0, 0, 0, 0};
+    size_t off_x3 = 0, off_x3p = 0, off_x3b = 0, off_cx[4] = {0, 0, 0, 0};
     if (want_cx)
         for (int l = 0; l < 4; ++l) {                     // conv weights as three-term planes, packed per lane (conv_x3.hip)
             off_cx[l] = reserve((conv_x3_pack_halfs(l) + 1) / 2);
@@ -873,6 +877,12 @@ int dce_finalize_weights(dce_ctx* c, int precision)
             split3_host(w1p.data(), FC1, FEAT, reinterpret_cast<unsigned short*>(img.data() + off_x3p));
         }
         if (!c->feat3) HIP_TRY(c, hipMalloc(&c->feat3, (size_t)(c->max_batch + 1) * FEAT * 3 * sizeof(unsigned short)));
+        if (c->tuning.x3_fc3) {                           // fc.3 on three-term operands: its weights as three row-major planes, h1 as three planes out of fc.0
+            const auto& v2 = c->host_w[10];
+            off_x3b = reserve((3 * v2.size() + 1) / 2);
+            split3_rows_host(v2.data(), FC2, FC1, reinterpret_cast<unsigned short*>(img.data() + off_x3b));
+            if (!c->h1p) HIP_TRY(c, hipMalloc(&c->h1p, (size_t)(c->max_batch + 1) * FC1 * 3 * sizeof(unsigned short)));
+        }
     }
     if (c->d_weights) { HIP_TRY(c, hipFree(c->d_weights)); c->d_weights = nullptr; }
     HIP_TRY(c, hipMalloc(&c->d_weights, img.size() * sizeof(float)));
@@ -893,6 +903,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     }
     if (c->fc1w_x3_own) { HIP_TRY(c, hipFree(c->fc1w_x3_own)); c->fc1w_x3_own = nullptr; }
     c->fc1w_x3 = precision == DCE_FP32_SPLIT && !want_pair ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3) : nullptr;
+    c->fc2w_x3 = precision == DCE_FP32_SPLIT && c->tuning.x3_fc3 ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3b) : nullptr;
     c->fc1w_x3p = precision == DCE_FP32_SPLIT && want_pair ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3p) : nullptr;
     c->precision = precision;
     c->guard = dce_ctx::SplitGuard{};
@@ -1018,8 +1029,9 @@ int dce_forward_taps(dce_ctx* c, const float* windows, int64_t n, int on_device,
     }
     c->want_h2 = h2 != nullptr;
     c->want_feat = feat != nullptr;
+    c->want_h1 = h1 != nullptr;
     rc = run_chunk(c, dsrc, 0, n, dl, nullptr, nullptr);
-    c->want_h2 = c->want_feat = false;
+    c->want_h2 = c->want_feat = c->want_h1 = false;
     if (rc) return rc;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     // DCE_BF16_FC: the features and ReLU(fc.0) ARE bf16 in that mode -- the taps hand out the (n,4736) / (n,2048)

@@ -53,9 +53,12 @@ struct dce_ctx {
     dce::ConvPackX3 pkx3{};                                      // ... and the conv weights, packed per lane (conv_x3.hip)
     const unsigned short* fc1w_x3 = nullptr;                // ... and fc.0's weights, [3][2048][4736] (inside d_weights, or fc1w_x3_own: made on first use when the permuted copy is the one in use)
     unsigned short* fc1w_x3_own = nullptr;
+    const unsigned short* fc2w_x3 = nullptr;                // ... fc.3's weights, three row-major planes [3][512][2048] (inside d_weights)
+    unsigned short* h1p = nullptr;                          // ... h1 as three row-major bf16 planes [3][max_batch + 1][2048] (fc.0's epilogue writes them, fc.3 reads them)
     const unsigned short* fc1w_x3p = nullptr;               // ... and the same with the K axis in conv_x3p.hip's feature order
     float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
     bool want_feat = false;                                // dce_forward_taps: DCE_FP32_SPLIT keeps the fp32 features (split by a kernel of its own)
+    bool want_h1 = false;                                  // dce_forward_taps: h1 is wanted in fp32 (DCE_FP32_SPLIT then keeps fc.3 on the fp32 kernels)
     bool want_h2 = false;                                  // dce_forward_taps: the fused epilogue also writes h2
 
     // staging for host-pointer callers: a ring of RING_SLOTS chunk-sized slots (run_all), so that

@@ -53,6 +53,7 @@ struct Tuning {
     int x3_min_tiles = 192;                                 // 256x128 tiles a launch needs for fc_gemm_x3.hip
     bool x3_unfused = false;                                // 1: fp32 features + split3 kernel instead of the conv kernel's three-plane output
     bool x3_permk = true;                                   // 0: conv_x3.hip's features through LDS in the reference's flatten order instead of straight out in the order t' * 128 + c
+    bool x3_fc3 = false;                                    // 1: fc.3 on three-term operands too (fc_gemm_x3.hip's 128 x 64 tile with the fused fc.6 epilogue; h1 leaves fc.0 as three planes).  Built and parity-green in round 5, and NOT faster: 64.3 us against 71 for the fp32 MFMA kernel, +9.5 us on fc.0's epilogue (profiles/r5j_split_fc3.txt) -- with 32 x 32 wave tiles a K-tile's LDS traffic is fc.0's for half its MFMAs
     bool split_guard = true;                                // 0: no range guard (static bound at finalize, per-window exponent check + fp32 fallback): the round-4 behaviour, for the A/B and the audit
     // -- experiments build only (ignored by the product library)
     bool gemm_lockstep = false, gemm_pipe = false, gemm_ki = false;
@@ -177,8 +178,14 @@ hipError_t init_fc_gemm_x3();
 bool       fc_gemm_x3_ok(int64_t M, int N, int K);
 void       split3_host(const float* x, size_t rows, size_t cols, unsigned short* planes);
 hipError_t launch_split3(const float* x, unsigned short* planes, int64_t rows, int cols, hipStream_t st);
-hipError_t launch_fc_gemm_x3(const unsigned short* A3, const unsigned short* W3, const float* bias, float* C,
-                             int64_t M, int N, int K, int relu, hipStream_t st);
+//   out_planes: C leaves as three ROW-MAJOR bf16 planes [3][M rounded up to even][N] (unsigned short), the next layer's three-term operand
+hipError_t launch_fc_gemm_x3(const unsigned short* A3, const unsigned short* W3, const float* bias, void* C,
+                             int64_t M, int N, int K, int relu, hipStream_t st, int out_planes = 0);
+// fc.3 + fc.6 chunk sums on three-term operands (round 5): the 128 x 64 tile of the same kernel with the fused fc.6 epilogue
+bool       fc23_x3_ok(int64_t M);
+void       split3_rows_host(const float* x, size_t rows, size_t cols, unsigned short* planes);
+hipError_t launch_fc23_fused_x3(const unsigned short* h1p, const unsigned short* W2p, const float* b2, const float* W3, float* part, int64_t part_rows,
+                                float* h2_out, int64_t M, hipStream_t st);
 
 // The conv stack with three-term bf16 operands (conv_x3.hip, precision DCE_FP32_SPLIT): direct-form implicit GEMM on
 // v_mfma_f32_16x16x32_bf16, one window per workgroup; features leave as the three planes fc_gemm_x3.hip reads.

@@ -27,7 +27,9 @@
 // Operands in HBM: A3 = three bf16 planes of the (M, K) features written by split3_kernel, W3 = three planes of the (N, K)
 // weights split on the host when the weights are finalised; both pair-interleaved (x3_off).
 #include "dce_kernels.h"
+#include "fc6_chain.h"
 #include <cstring>
+#include <type_traits>
 
 namespace dce {
 
@@ -60,14 +62,25 @@ __device__ unsigned long long g_x3_trace[8 * 32 * 4];
 
 namespace {
 
-constexpr int X3_BM = 256, X3_BN = 128, X3_ROWS = X3_BM + X3_BN;
-constexpr int X3_KT = 32;                                 // k per K-tile
-constexpr int X3_ROWB = 2 * X3_KT;                        // 64 bytes of K per row per plane
-constexpr int X3_PLANE = X3_ROWS * X3_ROWB;               // 24,576 B
-constexpr int X3_TILE = 3 * X3_PLANE;                     // 73,728 B = 72 chunks of 1 KB
-constexpr int X3_LDS = 2 * X3_TILE;                       // 147,456 B
-constexpr int X3_NCH = 18;                                // 1 KB chunks per ISSUING wave (the four of group 0) per K-tile
-static_assert(X3_TILE == 4 * X3_NCH * 1024 && X3_LDS <= 160 * 1024, "four waves x eighteen chunks; two K-tiles in LDS");
+// Tile configuration.  fc.0: 256 x 128 with 32-k K-tiles (64-byte rows, planes PAIR-INTERLEAVED in HBM, x3_off); fc.3 (round 5): 128 x 64
+// with 64-k K-tiles (128-byte rows = whole lines, planes row-major) -- 256 tiles at 4096 windows, the same 72 KB per K-tile and the
+// same eighteen 1 KB pieces per issuing wave.
+template <int BM_, int BN_, int KT_> struct X3Cfg {
+    static constexpr int BM = BM_, BN = BN_, KT = KT_, ROWS = BM + BN;
+    static constexpr int ROWB = 2 * KT;                          // bytes of K per row per plane
+    static constexpr int PLANE = ROWS * ROWB, TILE = 3 * PLANE, LDS = 2 * TILE;
+    static constexpr int SL = ROWB / 16, CR = 64 / SL;            // 16-byte slots per row; rows per 1 KB chunk
+    static constexpr int NCH = TILE / 1024 / 4;                   // 1 KB chunks per ISSUING wave (the four of group 0) per K-tile
+    static constexpr int NQ = NCH / 3, NQA = BM / CR / 4;         // chunks per plane per wave; of which from the A panel
+    static constexpr int WTM = BM / 4, WTN = BN / 2, AB = WTM / 32, BB = WTN / 32, KQ = KT / 16;
+    static constexpr bool ILV = ROWB == 64;                       // pair-interleaved operand planes (x3_off)
+    static_assert(TILE == 4 * NCH * 1024 && NCH == 18 && LDS <= 160 * 1024, "four waves x eighteen chunks; two K-tiles in LDS");
+    static_assert(NQA * 4 * CR == BM && (NQ - NQA) * 4 * CR == BN, "chunk deal");
+    __device__ static constexpr int swz(int r) { return SL == 4 ? (r >> 2) & 3 : (r >> 1) & 7; }
+};
+using X3Fc0 = X3Cfg<256, 128, 32>;
+using X3Fc3 = X3Cfg<128, 64, 64>;
+constexpr int X3_BM = X3Fc0::BM, X3_BN = X3Fc0::BN, X3_KT = X3Fc0::KT, X3_LDS = X3Fc0::LDS;
 
 __device__ __forceinline__ unsigned x3_lds_addr(const void* p)
 {
@@ -155,11 +168,20 @@ void split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ pla
     }
 }
 
+// Cfg: tile configuration (X3Fc0 / X3Fc3).  OUT3: C leaves as three bf16 planes, row-major [3][M rounded up to even][N] (fc.0 in front of an
+// fc.3 that takes three-term operands) instead of fp32.  FUSE6 (X3Fc3 only): the block's 64 output columns are one chunk of fc.6's
+// summation tree (fc6_chain.h), finished in the epilogue exactly as fc_gemm_phased.hip's FUSE6 does -- chunk sums to `part`, h2 itself to
+// C only when C != NULL (taps).
+template <class Cfg, bool OUT3, bool FUSE6>
 __global__ __launch_bounds__(512, 2)
 void fc_gemm_x3_kernel(const unsigned short* __restrict__ A3, const unsigned short* __restrict__ W3,
                        const float* __restrict__ bias, float* __restrict__ C,
-                       int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
+                       int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2,
+                       const float* __restrict__ W6 = nullptr, float* __restrict__ part = nullptr, long long part_rows = 0)
 {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, TILE = Cfg::TILE, NCH = Cfg::NCH, NQ = Cfg::NQ, NQA = Cfg::NQA;
+    constexpr int AB = Cfg::AB, BB = Cfg::BB, KQ = Cfg::KQ;
+    static_assert(!FUSE6 || (BM == 128 && BN == FC6_CHUNK && AB == 1 && BB == 1 && !OUT3), "the fused fc.6 epilogue is fc.3's 128 x 64 tile");
     extern __shared__ __attribute__((aligned(16))) char x3_smem[];
     // ---- XCD-aware tile assignment, as fc_gemm_phased.hip: the 32 blocks of one XCD form an sm x sn super-tile
     const int bid = blockIdx.x;
@@ -171,79 +193,82 @@ void fc_gemm_x3_kernel(const unsigned short* __restrict__ A3, const unsigned sho
     const int tm = (sid / nsn) * sm + (within >> sn_log2);
     const int tn = (sid % nsn) * sn + (within & (sn - 1));
     if (tm >= mtiles) return;
-    const int m0 = tm * X3_BM, n0 = tn * X3_BN;
+    const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wid >> 2;                                // phase group; waves w and w+4 share a SIMD
-    const int wm = (wid & 3) * 64, wn = grp * 64;            // this wave's corner of the block tile
+    const int wm = (wid & 3) * Cfg::WTM, wn = grp * Cfg::WTN;    // this wave's corner of the block tile
     const int i = lane & 31, h = lane >> 5;
 
     // ---- global -> LDS, issued by the four waves of group 0 only (at the start of their load phase, see below).  Wave w' =
-    //      wid & 3 brings chunks c = w' + 4 j, j = 0..17: plane j / 6; q = j % 6 < 4: A rows 16 (w' + 4 q) .., else W rows
-    //      16 (w' + 4 (q - 4)) ..; lane (lr = lane / 4, slot = lane % 4) fills slot `slot` of row lr of the chunk with the
+    //      wid & 3 brings chunks c = w' + 4 j, j = 0..17: plane j / 6; q = j % 6 < 4: A rows CR (w' + 4 q) .., else W rows
+    //      CR (w' + 4 (q - 4)) ..; lane (lr = lane / SL, slot = lane % SL) fills slot `slot` of row lr of the chunk with the
     //      logical column slot ^ swz(row).
-    const size_t rowb = (size_t)K * 2;                                   // bytes of one row; a row PAIR spans 2 rowb (x3_off)
+    const size_t rowb = (size_t)K * 2;                                   // bytes of one row; (ILV) a row PAIR spans 2 rowb (x3_off)
     const size_t planeA = (size_t)((M + 1) & ~1) * rowb, planeW = (size_t)N * rowb;
-    unsigned voff[X3_NCH];
+    unsigned voff[NCH];
     {
-        const int lr = lane >> 2, slot = lane & 3, w4 = wid & 3;
+        const int lr = lane / Cfg::SL, slot = lane % Cfg::SL, w4 = wid & 3;
 #pragma unroll
-        for (int j = 0; j < X3_NCH; ++j) {
-            const int p = j / 6, q = j % 6;
-            const int r = 16 * (w4 + 4 * (q < 4 ? q : q - 4)) + lr;       // row inside the A panel (0..255) / the W panel (0..127)
-            const int col = slot ^ ((r >> 2) & 3);                        // panels start at multiples of 16 rows: swz(r) = swz of the tile row
-            if (q < 4) {
+        for (int j = 0; j < NCH; ++j) {
+            const int p = j / NQ, q = j % NQ;
+            const int r = Cfg::CR * (w4 + 4 * (q < NQA ? q : q - NQA)) + lr;   // row inside the A panel / the W panel
+            const int col = slot ^ Cfg::swz(r);                           // panels start at multiples of 32 rows: swz(r) = swz of the tile row
+            if (q < NQA) {
                 int grow = r;
                 if (m0 + grow >= M) grow = M - 1 - m0;                    // rows past M re-read the last one (never stored); m0 is even
-                voff[j] = (unsigned)(p * planeA + (size_t)(grow >> 1) * 2 * rowb + (grow & 1) * 64 + 16 * col);
+                voff[j] = Cfg::ILV ? (unsigned)(p * planeA + (size_t)(grow >> 1) * 2 * rowb + (grow & 1) * 64 + 16 * col)
+                                   : (unsigned)(p * planeA + (size_t)grow * rowb + 16 * col);
             } else {
-                voff[j] = (unsigned)(p * planeW + (size_t)(r >> 1) * 2 * rowb + (r & 1) * 64 + 16 * col);
+                voff[j] = Cfg::ILV ? (unsigned)(p * planeW + (size_t)(r >> 1) * 2 * rowb + (r & 1) * 64 + 16 * col)
+                                   : (unsigned)(p * planeW + (size_t)r * rowb + 16 * col);
             }
         }
     }
     const char* sA = reinterpret_cast<const char*>(A3) + (size_t)m0 * rowb;
     const char* sW = reinterpret_cast<const char*>(W3) + (size_t)n0 * rowb;
+    constexpr size_t KSTEP = Cfg::ILV ? 2 * ROWB : ROWB;                  // bytes from one K-tile to the next in HBM
     const unsigned lds_wave = x3_lds_addr(x3_smem) + (wid & 3) * 1024;    // chunk w' of buffer 0; piece j lands 4 j KB behind it
     auto piece = [&](int j, size_t ko) {                                  // j is a compile-time constant at every call; pieces go in order
-        x3_piece((j % 6 < 4 ? sA : sW) + ko, voff[j]);
+        x3_piece((j % NQ < NQA ? sA : sW) + ko, voff[j]);
     };
 
     // ---- fragment reads: lane (i, h) reads row (corner + 32 blk + i), logical column 2 kq + h  (k = 16 kq + 8 h + 0..7)
-    const int sw = (i >> 2) & 3;
-    unsigned fa[2][2], fb[2][2];                                          // [buffer][kq]: byte offsets of plane 0, block 0
+    const int sw = Cfg::swz(i);
+    unsigned fa[2][KQ], fb[2][KQ];                                        // [buffer][kq]: byte offsets of plane 0, block 0
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int kq = 0; kq < 2; ++kq) {
+        for (int kq = 0; kq < KQ; ++kq) {
             const int o = 16 * ((2 * kq + h) ^ sw);
-            fa[b][kq] = b * X3_TILE + (wm + i) * X3_ROWB + o;
-            fb[b][kq] = b * X3_TILE + (X3_BM + wn + i) * X3_ROWB + o;
+            fa[b][kq] = b * TILE + (wm + i) * ROWB + o;
+            fb[b][kq] = b * TILE + (BM + wn + i) * ROWB + o;
             asm volatile("" : "+v"(fa[b][kq]), "+v"(fb[b][kq]));          // stay in registers (see fc_gemm_phased.hip)
         }
 
-    x3_f32x16 acc[2][2];
+    x3_f32x16 acc[AB][BB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < BB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // fragments of one K-tile: [kq][plane][block] x 16 bytes per lane, A and W: 24 float4
-    float4 af[2][3][2], bf[2][3][2];
+    // fragments of one K-tile: [kq][plane][block] x 16 bytes per lane, A and W
+    float4 af[KQ][3][AB], bf[KQ][3][BB];
     auto load_frags = [&](int buf) {                                      // buf is a compile-time constant at every call
 #pragma unroll
-        for (int kq = 0; kq < 2; ++kq)
+        for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < 3; ++p) {
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    af[kq][p][blk] = *reinterpret_cast<const float4*>(x3_smem + fa[buf][kq] + p * X3_PLANE + blk * 32 * X3_ROWB);
-                    bf[kq][p][blk] = *reinterpret_cast<const float4*>(x3_smem + fb[buf][kq] + p * X3_PLANE + blk * 32 * X3_ROWB);
-                }
+                for (int blk = 0; blk < AB; ++blk) af[kq][p][blk] = *reinterpret_cast<const float4*>(x3_smem + fa[buf][kq] + p * PLANE + blk * 32 * ROWB);
+#pragma unroll
+                for (int blk = 0; blk < BB; ++blk) bf[kq][p][blk] = *reinterpret_cast<const float4*>(x3_smem + fb[buf][kq] + p * PLANE + blk * 32 * ROWB);
+            }
     };
-    // the 48 MFMAs of a K-tile.  X3_ISSUE == 1: with `deal` (wave-uniform) the eighteen pieces of a later K-tile go out one
+    // the MFMAs of a K-tile.  X3_ISSUE == 1: with `deal` (wave-uniform) the eighteen pieces of a later K-tile go out one
     // behind each of MFMAs 1 .. 18 -- ONE instruction stream for both cases (two copies of the MFMA chain behind a branch
     // made hipcc shuttle the 64 accumulator registers between them with v_mov_b64 every K-tile).
     auto math = [&](bool deal, unsigned lds0, size_t ko) {
@@ -255,41 +280,42 @@ void fc_gemm_x3_kernel(const unsigned short* __restrict__ A3, const unsigned sho
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-        for (int kq = 0; kq < 2; ++kq)
+        for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < AB; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
+                    for (int b = 0; b < BB; ++b) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(x3_bf16x8, af[kq][TA[t]][a]), __builtin_bit_cast(x3_bf16x8, bf[kq][TB[t]][b]), acc[a][b], 0, 0, 0);
 #if X3_ISSUE == 1
-                        const int n = ((kq * 6 + t) * 2 + a) * 2 + b;
-                        if (n < X3_NCH) {
+                        const int n = ((kq * 6 + t) * AB + a) * BB + b;
+                        if (n < NCH) {
                             __builtin_amdgcn_sched_barrier(0);
                             if (deal && !(X3_EXP & 1)) piece(n, ko);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (n == X3_NCH) {
+                        if (n == NCH) {
                             if (deal) x3_m0_end(keep);
                             __builtin_amdgcn_sched_barrier(0);
                         }
 #endif
                     }
+        (void)deal; (void)lds0; (void)ko;
     };
     // the eighteen pieces of one K-tile, in a bunch
     auto issue = [&](unsigned lds0, size_t ko) {
         const unsigned keep = x3_m0_begin(lds0);
 #pragma unroll
-        for (int j = 0; j < X3_NCH; ++j) if (!(X3_EXP & 1) || ko < 4 * X3_ROWB) piece(j, ko);
+        for (int j = 0; j < NCH; ++j) if (!(X3_EXP & 1) || ko < 2 * KSTEP) piece(j, ko);
         x3_m0_end(keep);
     };
 
 #if X3_TRACE
-    unsigned long long* x3_marks = reinterpret_cast<unsigned long long*>(x3_smem + X3_LDS);      // 8 KB behind the two tiles
+    unsigned long long* x3_marks = reinterpret_cast<unsigned long long*>(x3_smem + Cfg::LDS);      // 8 KB behind the two tiles
 #endif
-    const int KT = K / X3_KT;                                             // >= 2 (checked by the launcher)
+    const int KT = K / Cfg::KT;                                           // >= 2 (checked by the launcher)
     // Phases p = 0, 1, 2, ...; a workgroup barrier ends each.
     //   group 0: load(u) in phase 2u, math(u) in 2u+1            group 1: load(u) in 2u+1, math(u) in 2u+2
     // Tile u lives in buffer u & 1 and is read in phases 2u and 2u+1.  Group 0 issues ALL of tile u+1 at the start of its
@@ -303,7 +329,7 @@ void fc_gemm_x3_kernel(const unsigned short* __restrict__ A3, const unsigned sho
     // behind wave-uniform branches.
     if (grp == (X3_ISSUE == 1 ? 1 : 0)) {
         issue(lds_wave, 0);
-        issue(lds_wave + X3_TILE, 2 * X3_ROWB);
+        issue(lds_wave + TILE, KSTEP);
         asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                 // tile 0 landed
     }
     asm volatile("s_barrier" ::: "memory");
@@ -319,12 +345,12 @@ void fc_gemm_x3_kernel(const unsigned short* __restrict__ A3, const unsigned sho
         X3_MARK(1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         X3_MARK(2);
-        math(grp == 1 && u + 2 < KT, lds_wave + buf * X3_TILE, (size_t)(u + 2) * 2 * X3_ROWB);
+        math(grp == 1 && u + 2 < KT, lds_wave + buf * TILE, (size_t)(u + 2) * KSTEP);
         X3_MARK(3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
         // ---- load phase
-        if (grp == 0 && u >= 1 && u + 1 < KT) issue(lds_wave + (buf ^ 1) * X3_TILE, (size_t)(u + 1) * 2 * X3_ROWB);
+        if (grp == 0 && u >= 1 && u + 1 < KT) issue(lds_wave + (buf ^ 1) * TILE, (size_t)(u + 1) * KSTEP);
         X3_MARK(0);
         if (!(X3_EXP & 2) || u == 0) load_frags(buf);
         X3_MARK(1);
@@ -348,30 +374,70 @@ void fc_gemm_x3_kernel(const unsigned short* __restrict__ A3, const unsigned sho
         for (int q = 0; q < 32 * 4; ++q) g_x3_trace[wid * 128 + q] = x3_marks[wid * 128 + q];
 #endif
 
+    if constexpr (FUSE6) {
+        // ---- fused epilogue (fc.3): bias + ReLU, h2 tile -> LDS, this block's chunk of fc.6's summation tree -> `part`.  Every wave is
+        //      past its last fragment read (the barrier above), LDS is free.
+        constexpr int HLD = 68;                          // h2 tile [128][68] floats
+        float* ht = reinterpret_cast<float*>(x3_smem);
+        float4 bw6[4];
+        fc6_load_w3(W6, tn, lane, bw6);
+        const int col_l = wn + i;
+        const float bv = bias[n0 + col_l];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row_l = wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = acc[0][0][r] + bv;
+            v = v < 0.f ? 0.f : v;                       // fc.3's ReLU; keeps NaN like torch
+            ht[row_l * HLD + col_l] = v;
+            if (C && m0 + row_l < M) C[(size_t)(m0 + row_l) * N + n0 + col_l] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const fc6_f32x4 p = fc6_chunk_mfma(ht + 16 * wid * HLD, HLD, 0, lane, bw6);   // wave w: rows 16w .. 16w+15
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * wid + 4 * (lane >> 4) + r;
+            if (row < M) part[((size_t)tn * part_rows + row) * NCLS + (lane & 15)] = p[r];
+        }
+        return;
+    }
+
     // ---- epilogue: bias + (ReLU); D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     auto store_tile = [&](auto full) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < BB; ++b) {
             const int col = n0 + wn + 32 * b + i;
             const float bv = bias[col];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < AB; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
                     float v = acc[a][b][r] + bv;
                     if (relu) v = v < 0.f ? 0.f : v;                      // keeps NaN like torch
-                    if (decltype(full)::value || row < M) C[(size_t)row * N + col] = v;
+                    if (decltype(full)::value || row < M) {
+                        if constexpr (OUT3) {                             // three bf16 planes, row-major: the next layer's three-term operand
+                            unsigned short t1, t2, t3;
+                            x3_split(v, t1, t2, t3);
+                            unsigned short* const p0 = reinterpret_cast<unsigned short*>(C);        // (wave-uniform base + 32-bit element offsets: one address register per store)
+                            const unsigned pl = (unsigned)((M + 1) & ~1) * (unsigned)N, idx = (unsigned)row * (unsigned)N + (unsigned)col;
+                            p0[idx] = t1; p0[pl + idx] = t2; p0[2 * pl + idx] = t3;
+                        } else C[(size_t)row * N + col] = v;
+                    }
+                    if constexpr (OUT3) __builtin_amdgcn_sched_barrier(0);  // (one value at a time: left alone hipcc splits all 64 at once and spills)
                 }
         }
     };
-    if (m0 + X3_BM <= M) store_tile(std::true_type{});
+    if (m0 + BM <= M) store_tile(std::true_type{});
     else store_tile(std::false_type{});
 }
 
 hipError_t init_fc_gemm_x3()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS + (X3_TRACE ? 8192 : 0));
+    hipError_t e;
+    for (const void* k : {reinterpret_cast<const void*>(&fc_gemm_x3_kernel<X3Fc0, false, false>), reinterpret_cast<const void*>(&fc_gemm_x3_kernel<X3Fc0, true, false>),
+                          reinterpret_cast<const void*>(&fc_gemm_x3_kernel<X3Fc3, false, true>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS + (X3_TRACE ? 8192 : 0))) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 // 256 x 128 tiles must fill the chip (as the phased fp32 kernel asks of its large tile)
@@ -382,6 +448,19 @@ bool fc_gemm_x3_ok(int64_t M, int N, int K)
     if ((nt & (nt - 1)) != 0) return false;
     if (3ull * (size_t)(M > N ? M : N) * K * 2 >= (1ull << 32)) return false;       // per-lane offsets are 32-bit, planes included
     return ((M + X3_BM - 1) / X3_BM) * nt >= tune().x3_min_tiles;
+}
+
+// fc.3 + fc.6 chunk sums on three-term operands: where the fp32 path fuses them (one round of 128 x 64 tiles) and the planes' offsets fit
+bool fc23_x3_ok(int64_t M)
+{
+    return tune().x3_fc3 && fc23_fused_ok(M, 0) && 3ull * (size_t)((M + 1) & ~(int64_t)1) * FC1 * 2 < (1ull << 32);
+}
+
+// rows x cols fp32 -> three ROW-MAJOR planes [3][rows][cols] (fc.3's weights: its 64-k K-tiles are whole 128-byte lines as they are)
+void split3_rows_host(const float* x, size_t rows, size_t cols, unsigned short* planes)
+{
+    const size_t n = rows * cols;
+    for (size_t e = 0; e < n; ++e) x3_split(x[e], planes[e], planes[n + e], planes[2 * n + e]);
 }
 
 // rows x cols fp32 -> three pair-interleaved planes (x3_off); rows even.  cols = 0: flat (planes[p][k], the test hook)
@@ -407,8 +486,8 @@ hipError_t launch_split3(const float* x, unsigned short* planes, int64_t rows, i
     return hipGetLastError();
 }
 
-hipError_t launch_fc_gemm_x3(const unsigned short* A3, const unsigned short* W3, const float* bias, float* C,
-                             int64_t M, int N, int K, int relu, hipStream_t st)
+hipError_t launch_fc_gemm_x3(const unsigned short* A3, const unsigned short* W3, const float* bias, void* C,
+                             int64_t M, int N, int K, int relu, hipStream_t st, int out_planes)
 {
     if (!fc_gemm_x3_ok(M, N, K)) return hipErrorInvalidValue;
     const int mtiles = (int)((M + X3_BM - 1) / X3_BM), ntiles = N / X3_BN;
@@ -418,7 +497,26 @@ hipError_t launch_fc_gemm_x3(const unsigned short* A3, const unsigned short* W3,
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
     plan_note("fc_x3_256x128");
-    hipLaunchKernelGGL(fc_gemm_x3_kernel, dim3(grid), dim3(512), X3_LDS + (X3_TRACE ? 8192 : 0), st, A3, W3, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+    float* Cf = static_cast<float*>(C);
+    if (out_planes) hipLaunchKernelGGL((fc_gemm_x3_kernel<X3Fc0, true, false>), dim3(grid), dim3(512), X3_LDS + (X3_TRACE ? 8192 : 0), st, A3, W3, bias, Cf, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+    else            hipLaunchKernelGGL((fc_gemm_x3_kernel<X3Fc0, false, false>), dim3(grid), dim3(512), X3_LDS + (X3_TRACE ? 8192 : 0), st, A3, W3, bias, Cf, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+    return hipGetLastError();
+}
+
+// fc.3 (+ReLU) on three-term operands with fc.6's chunk sums finished in the epilogue: h1p = three row-major bf16 planes [3][M even][2048]
+// (fc_gemm_x3's OUT3 epilogue), W2p = three planes [3][512][2048] (split3_rows_host); part: [8][part_rows][16] chunk sums; h2_out: NULL or (M,512) fp32
+hipError_t launch_fc23_fused_x3(const unsigned short* h1p, const unsigned short* W2p, const float* b2, const float* W3, float* part, int64_t part_rows,
+                                float* h2_out, int64_t M, hipStream_t st)
+{
+    static_assert(X3Fc3::BN == FC6_CHUNK && FC2 / X3Fc3::BN == FC6_NCHUNK && FC1 % X3Fc3::KT == 0, "one column tile of fc.3 = one chunk of fc.6");
+    if (M <= 0) return hipSuccess;
+    const int mtiles = (int)((M + X3Fc3::BM - 1) / X3Fc3::BM), ntiles = FC2 / X3Fc3::BN;
+    const int sn_log2 = 2, sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
+    const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
+    const int grid = ((nsuper + 7) / 8) * 8 * 32;
+    plan_note("fc23_fused_x3_128x64");
+    hipLaunchKernelGGL((fc_gemm_x3_kernel<X3Fc3, false, true>), dim3(grid), dim3(512), X3Fc3::LDS + (X3_TRACE ? 8192 : 0), st, h1p, W2p, b2, h2_out,
+                       (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
     return hipGetLastError();
 }
 

@@ -49,7 +49,7 @@ def test_split_guard_static_bounds_of_a_checkpoint():
         s, b = w.sum(1).max(), np.abs(sd[bk].astype(np.float64)).max()
         gain, offs = gain * s, offs * s + b
         assert np.isclose(g["gain"][l], gain, rtol=1e-9) and np.isclose(g["offs"][l], offs, rtol=1e-9), (l, g["gain"][l], gain)
-    x_hi = min((2.0 ** 126 - g["offs"][l]) / g["gain"][l] for l in range(4))
+    x_hi = min((2.0 ** 126 - g["offs"][l]) / g["gain"][l] for l in range(4))      # conv1..4 outputs: the activations that are split (h1 too with x3_fc3=1)
     assert g["x_hi"] <= x_hi and g["x_hi"] >= x_hi * (1 - 1e-6) and g["x_hi"] > 1e20 and g["x_lo"] == 2.0 ** -40, g
     # a model of another precision reports the guard as not applicable
     f = _model("fp32", sd); gf = f.split_guard()
@@ -275,3 +275,38 @@ def test_latency_mode_online_pushes_vs_oracle(orc):
     assert all(g is None for g in got2[:149])
     tol_ok(np.stack([g[0] for g in got2[149:]]), ref2["logits"], "after a reset")
     m.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32_split: fc.3 on three-term operands (csrc/fc_gemm_x3.hip, the 128 x 64 tile with the fused fc.6 epilogue)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [4096, 4100, 8192])
+def test_split_mode_fc3_on_three_term_operands(n, orc):
+    """Option x3_fc3=1: fp32_split at chip-filling batches with fc.3 on the bf16 matrix pipe too -- fc.0's epilogue writes h1 as three bf16
+    planes, the 128 x 64 tile of fc_gemm_x3 multiplies them with fc.3's three-plane weights and finishes fc.6's chunk sums in its epilogue
+    (plan fc23_fused_x3_128x64).  Same contract as the fp32 path against the oracle -- every row --, within 2e-5 of the largest logit of
+    the default form of the mode (fc.3 on fp32 MFMA), h2 taps within the tolerance, a non-finite window contained, repeatable.  (Measured
+    no faster than the fp32 kernel -- profiles/r5j_split_fc3.txt -- hence an option, not the default.)"""
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    a = _model("fp32_split", sd, max_batch=8192, tune={"x3_fc3": 1})
+    b = _model("fp32_split", sd, max_batch=8192)
+    x = np.random.default_rng(40 + n).standard_normal((n, 150, 54), dtype=np.float32)
+    x[11, 5, 7] = np.inf
+    ra, rb = a.predict(x), b.predict(x)
+    assert "fc23_fused_x3_128x64" in a.last_plan() and "fc_x3_256x128" in a.last_plan(), a.last_plan()
+    assert "fc23_fused_x3_128x64" not in b.last_plan() and "fc23_fused_phased128x64" in b.last_plan(), b.last_plan()
+    assert np.array_equal(a.predict(x)["logits"].view(np.uint32), ra["logits"].view(np.uint32))
+    ok = np.ones(n, bool); ok[11] = False
+    assert np.isnan(ra["logits"][11]).all() and ra["pred"][11] == 0 and np.isfinite(ra["logits"][ok]).all()
+    ref = orc.Oracle(sd).forward_windows(x[ok])
+    tol_ok(ra["logits"][ok], ref["logits"], f"fp32_split with fc.3 on three-term operands, {n} windows")
+    _argmax_contract(ra["pred"][ok], ref)
+    scale = np.abs(ref["logits"]).max()
+    assert np.abs(ra["logits"][ok] - rb["logits"][ok]).max() <= 2e-5 * scale
+    if n == 4096:
+        t = a.forward_taps(x[:4096])                                   # h1 wanted in fp32: that call keeps fc.3 on the fp32 kernels
+        assert "fc23_fused_x3_128x64" not in a.last_plan()
+        rt = orc.Oracle(sd).forward_windows(x[ok][:64], taps=True)
+        tol_ok(t["h2"][ok[:4096]][:64], rt["h2"], "h2 tap")
+    a.close(); b.close()
