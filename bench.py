@@ -335,11 +335,11 @@ def extra_small_batches(torch, model, windows, sizes=(1, 30, 64, 256, 512, 1024)
                         "per workgroup <= 256)", "batches": res}
 
 
-def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000, precision="fp32"):
+def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000, precision="fp32", tune=None):
     """SURVEY 8(f) rank 4 / the reference's README.md:67-83: push one (54,) host sample, get one estimate back (dce_online_push:
     sample in the kernel arguments / pinned memory, the newest window through the small-batch kernels, result polled from pinned
     memory).  Per-sample latency through the Python binding, plain launches."""
-    m = contact_cnn(device=dev.index, max_batch=64, precision=precision)
+    m = contact_cnn(device=dev.index, max_batch=64, precision=precision, tune=tune)
     m.load_state_dict(sd).eval()
     m.online_reset()
     pushes = max(min(pushes, seq_np.shape[0] - 350), 0)
@@ -354,6 +354,32 @@ def extra_online(contact_cnn, sd, dev, seq_np, pushes=2000, precision="fp32"):
     m.close()
     return {"workload": "dce_online_push: one host sample in -> logits, class, 4 contact bits out, per push (Python binding, plain launches)",
             "us_per_push": dt * 1e6, "pushes": k, "samples_per_s": 1.0 / dt}
+
+
+def extra_latency_mode(torch, contact_cnn, sd, dev, windows, seq_np, ref_logits):
+    """The reference's shipped batch_size 1 (config/inference_one_seq_params.yaml:10, README.md:67-83) in the LATENCY MODE (option
+    latency=1, csrc/latency.hip): one-window predict() calls as ONE kernel of 256 co-resident workgroups, online pushes through a
+    resident service kernel and a mailbox in pinned memory.  Same measurements as extra.small_batches / extra.online_push, same box."""
+    m = contact_cnn(device=dev.index, max_batch=64, tune={"latency": 1})
+    m.load_state_dict(sd).eval()
+    xb = windows[:1].contiguous()
+    for _ in range(50):
+        o = m.predict(xb)
+    torch.cuda.synchronize()
+    n = 1000
+    t0 = time.perf_counter()
+    for _ in range(n):
+        o = m.predict(xb)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / n * 1e6
+    plan = m.last_plan()
+    dl = float((o["logits"][0] - ref_logits[0]).abs().max().item())
+    m.close()
+    push = extra_online(contact_cnn, sd, dev, seq_np, tune={"latency": 1})
+    return {"workload": "option latency=1 (fp32): model.predict on ONE pre-normalised device-resident window, per call; dce_online_push per sample",
+            "predict_1_us_per_call": us, "plan": plan, "max_abs_dlogit_vs_batch_path_same_window": dl,
+            "online_push_us": push["us_per_push"], "online_pushes": push["pushes"],
+            "note": "inside the fp32 tolerance of the CPU restatement (tests/test_round5_gpu.py), not the batch path's bits: K is folded over the lanes by a fixed tree"}
 
 
 MODE_TEXT = {
@@ -396,6 +422,15 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
         "path_roof_windows_per_s": path_roof(precision),
         "path_frac_of_roof": (B * steps / dt) / path_roof(precision),
     }
+    if precision == "fp32_split":
+        res["dtype"] = "f32 results; every fp32 operand of the conv stack and fc.0 as three bf16 terms on the bf16 matrix pipe (six MFMAs per product, fp32 accumulate), behind the range guard"
+        try:
+            g = m.split_guard()
+            res["range_guard"] = {k: g[k] for k in ("enabled", "refused", "x_hi", "x_lo", "z_max", "guarded_launches", "windows_out_of_range", "fallbacks_run", "reason")}
+            res["range_guard"]["what"] = ("static per-layer activation bounds at dce_finalize_weights; this workload (pre-normalised windows) also carries the per-window check in the "
+                                          "conv kernel's load stage and a gated DCE_FP32 kernel sequence behind every launch (it ran `fallbacks_run` times); z-scored windows need neither")
+        except Exception:                                         # noqa: BLE001
+            pass
     if precision == "bf16_fc":
         # the reference's shipped batch sizes in this precision: its conv stack is one workgroup per window at every size, fc.0 / fc.3
         # stream their bf16 weights past up to 64 windows (fc_stream_bf16.hip)
@@ -789,6 +824,7 @@ def main():
                 "fp32_split": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s, precision="fp32_split"),
             }
             res["extra"]["bf16_fc"]["online_push"] = extra_online(contact_cnn, sd, dev, seq_np, pushes=1000, precision="bf16_fc")
+            res["extra"]["latency_mode"] = extra_latency_mode(torch, contact_cnn, sd, dev, windows, seq_np, out["logits"])
     if rank == 0:
         if world == 1 and not multi and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, windows.cpu().numpy(), seq_np, out["logits"].cpu().numpy(),

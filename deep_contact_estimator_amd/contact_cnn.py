@@ -81,6 +81,8 @@ class contact_cnn:
 
     def close(self):
         self._online_stream_own = False
+        if getattr(self, "_ctx", None) and getattr(self, "_ctx_abandoned", False):
+            self._ctx = C.c_void_p()          # a thread is still inside dce_comm_init on it (distributed.comm_bootstrap timed out): not ours to destroy
         if getattr(self, "_ctx", None):
             self._lib.dce_destroy(self._ctx)
             self._ctx = C.c_void_p()

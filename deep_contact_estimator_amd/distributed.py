@@ -109,10 +109,20 @@ def id_file_rendezvous(path: str, rank: int, make_id, timeout: float = 120.0) ->
     <16-byte nonce><128-byte id>, the nonce comes from DCE_COMM_NONCE (the launcher draws one per job; tools/launch_ranks.sh);
     rank 0 removes a left-over, writes a temporary file and renames it; the others accept only a file with THEIR nonce -- a
     stale id would otherwise send ncclCommInitRank waiting for peers that will never come -- and give up after `timeout`.
-    Without DCE_COMM_NONCE the nonce is empty and a file older than this process by more than an hour is taken for stale."""
+    Without DCE_COMM_NONCE the nonce is DERIVED from what the ranks of one job share and two jobs on a node do not: the launcher's
+    rendezvous endpoint (MASTER_ADDR:MASTER_PORT, TORCHELASTIC_RUN_ID), else the parent process id (the ranks of a launcher are
+    siblings).  Ranks started by hand from different shells with neither have to set DCE_COMM_NONCE."""
+    import hashlib
     import os
     import time
-    nonce = os.environ.get("DCE_COMM_NONCE", "").encode()[:ID_FILE_NONCE].ljust(ID_FILE_NONCE, b"\0")
+    explicit = os.environ.get("DCE_COMM_NONCE", "")
+    if explicit:
+        nonce = explicit.encode()[:ID_FILE_NONCE].ljust(ID_FILE_NONCE, b"\0")
+    else:
+        shared = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+        if not shared.strip("|"):
+            shared = f"ppid:{os.getppid()}"
+        nonce = hashlib.sha256(shared.encode()).digest()[:ID_FILE_NONCE]
     if rank == 0:
         try:
             os.unlink(path)
@@ -129,8 +139,7 @@ def id_file_rendezvous(path: str, rank: int, make_id, timeout: float = 120.0) ->
         try:
             with open(path, "rb") as f:
                 buf = f.read()
-            fresh = any(nonce) or os.path.getmtime(path) > t0 - 3600.0
-            if len(buf) == ID_FILE_NONCE + 128 and buf[:ID_FILE_NONCE] == nonce and fresh:
+            if len(buf) == ID_FILE_NONCE + 128 and buf[:ID_FILE_NONCE] == nonce:
                 return buf[ID_FILE_NONCE:]
         except FileNotFoundError:
             pass
@@ -184,6 +193,9 @@ def comm_bootstrap(model, rank: int, world: int, key: str = "dce_comm_id"):
         th = threading.Thread(target=init, daemon=True, name="dce-comm-init")
         th.start()
         if not done.wait(timeout):
+            # the daemon thread is still inside ncclCommInitRank ON THIS CONTEXT: the context must not be destroyed under it.  The model
+            # gives its context up (close() then leaves it alone: a leak, in a process that is about to report a failure anyway).
+            model._ctx_abandoned = True
             raise RuntimeError(f"dce_comm_init did not return within {timeout:.0f} s: {world - 1} peer(s) expected through {path}")
         if err:
             raise err[0]

@@ -179,7 +179,7 @@ def test_bf16_gemm_k32_two_workgroups_per_cu_bit_identical():
     import torch
     from deep_contact_estimator_amd import contact_cnn, synth
     sd = synth.make_state_dict(1, "uniform")
-    for n in (8192, 8192 + 300):
+    for n in (8192, 16384 - 100):                                  # (sizes whose rounds model picks the 256 x 128 tile; the second with a partial last row tile)
         x = torch.randn((n, 150, 54), generator=torch.Generator(device="cuda").manual_seed(n), device="cuda")
         a = contact_cnn(device=0, max_batch=n, precision="bf16_fc", tune={"bf16_k32": 1}); a.load_state_dict(sd).eval()
         b = contact_cnn(device=0, max_batch=n, precision="bf16_fc", tune={"bf16_k32": 0}); b.load_state_dict(sd).eval()

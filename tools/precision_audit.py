@@ -9,7 +9,7 @@ fc.0, fc.3, logits) on 4096 windows of each; and adversarial sets -- channels sc
 per-layer weight scales 1e-3 .. 1e3, activations pushed to the fp32 / bf16 subnormal boundary (does the matrix pipe flush the
 third term?), inputs in the top binade (bf16's largest finite number is below fp32's: the first term of a split can round to Inf).
 
-    python tools/precision_audit.py [--quick] > profiles/r4_precision_audit.json
+    python tools/precision_audit.py [--quick] > profiles/r5_precision_audit.json      (round 5: DCE_FP32_SPLIT with its range guard, and without)
 """
 import json
 import os
@@ -62,11 +62,13 @@ def torch_cpu_sequence(sd_t, seq, chunk=8192):
     return out
 
 
-def models(sd, max_batch=32768):
+def models(sd, max_batch=32768, unguarded=False):
+    """fp32, fp32_split (with its range guard: the default) and -- for the adversarial window sets -- fp32_split with the guard switched
+    off (option split_guard=0: round 4's behaviour, the rows that show what the guard is for)."""
     ms = {}
-    for p in ("fp32", "fp32_split"):
-        ms[p] = contact_cnn(device=0, max_batch=max_batch, precision=p)
-        ms[p].load_state_dict(sd).eval()
+    for name, p, tune in (("fp32", "fp32", None), ("fp32_split", "fp32_split", None)) + ((("fp32_split_unguarded", "fp32_split", {"split_guard": 0}),) if unguarded else ()):
+        ms[name] = contact_cnn(device=0, max_batch=max_batch, precision=p, tune=tune)
+        ms[name].load_state_dict(sd).eval()
     return ms
 
 
@@ -122,10 +124,13 @@ def audit_windows(name, sd, win, note):
     res = {"windows": int(win.shape[0]), "note": note, "logit_scale": float(np.nanmax(np.abs(ref["logits"]))) if np.isfinite(ref["logits"]).any() else None,
            "oracle_nonfinite_rows": int((~np.isfinite(ref["logits"])).any(1).sum()), "evaluations": {}}
     res["evaluations"]["pytorch_cpu_fp32"] = {"logits": stats(tl, ref["logits"]), "argmax": argmax_report(np.nan_to_num(tl, nan=-np.inf).argmax(1), ref["logits"], ref["pred"])}
-    for p, m in models(sd, max_batch=win.shape[0]).items():
+    for p, m in models(sd, max_batch=win.shape[0], unguarded=True).items():
         out = m.predict(win)
         res["evaluations"]["dce_" + p] = {"logits": stats(out["logits"], ref["logits"]), "argmax": argmax_report(out["pred"], ref["logits"], ref["pred"]),
                                            "plan": m.last_plan()}
+        if p == "fp32_split":
+            g = m.split_guard()
+            res["evaluations"]["dce_" + p]["range_guard"] = {k: g[k] for k in ("refused", "x_hi", "x_lo", "windows_out_of_range", "fallbacks_run", "reason")}
         m.close()
     print(f"[audit] {name}: " + "  ".join(f"{k} {v['logits']['max']}" for k, v in res["evaluations"].items()), file=sys.stderr, flush=True)
     return res
@@ -169,12 +174,23 @@ def main():
     sd_t = {k: v.copy() for k, v in sd.items()}
     sd_t["block1.0.weight"] = (sd_t["block1.0.weight"] * 1e-38 / 3.0).astype(np.float32)
     rep["sets"]["inputs_in_the_top_binade"] = audit_windows("top binade", sd_t, top, "windows x 3e37 with 2000 samples at +-3.395e38 (> bf16 max 3.3895e38: the split's first term rounds to Inf), conv1 weights x 3.3e-39 (subnormal-free: 1e-38 / 3)")
+    # a set that passes the STATIC guard (ordinary-size weights) and trips the per-window check: inputs x 3e37 with samples at 1.6e38, conv1 x 1e-8
+    top2 = (win * np.float32(3.0e37)).astype(np.float32)
+    idx = rng.integers(0, top2.size, 2000)
+    top2.reshape(-1)[idx] = np.float32(1.6e38) * np.sign(top2.reshape(-1)[idx])
+    sd_t2 = {k: v.copy() for k, v in sd.items()}
+    sd_t2["block1.0.weight"] = (sd_t2["block1.0.weight"] * np.float32(1e-8)).astype(np.float32)
+    rep["sets"]["inputs_x_3e37_conv1_x_1e-8"] = audit_windows("inputs 3e37", sd_t2, top2, "windows x 3e37 with 2000 samples at +-1.6e38 (above the guard's 2^126, below the fp32 Winograd transform's own limit 1.7e38), conv1 weights x 1e-8: passes the static guard, every window fails the per-window check")
     # ---- the rule of VERDICT r3 item 4
     verdict = {}
     for name, s in rep["sets"].items():
         ev = s["evaluations"]
         t, sp = ev["pytorch_cpu_fp32"]["logits"]["max"], ev["dce_fp32_split"]["logits"]["max"]
+        ung = ev.get("dce_fp32_split_unguarded")
         verdict[name] = {"pytorch_cpu": t, "dce_fp32": ev["dce_fp32"]["logits"]["max"], "dce_fp32_split": sp,
+                         "dce_fp32_split_unguarded": ung["logits"]["max"] if ung else None,
+                         "split_plan": ev["dce_fp32_split"].get("plan") or ev["dce_fp32_split"].get("plan_of_last_launch"),
+                         "split_nonfinite_mismatches": ev["dce_fp32_split"]["logits"]["nonfinite_mismatches"], "fp32_nonfinite_mismatches": ev["dce_fp32"]["logits"]["nonfinite_mismatches"],
                          "split_within_2x_of_pytorch_cpu": (sp is not None and t is not None and sp <= 2.0 * max(t, 1e-9)),
                          "split_within_the_contract": sp is not None and sp <= 1.0 and ev["dce_fp32_split"]["logits"]["nonfinite_mismatches"] == 0,
                          "split_above_margin_argmax_differences": ev["dce_fp32_split"]["argmax"]["above_noise_margin"]}
