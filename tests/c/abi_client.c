@@ -163,6 +163,53 @@ int main(void)
         }
     }
 
+    /* ---- 4b. the LATENCY MODE from plain C (dce_create_ex "latency=1"; csrc/latency.hip): one-window calls as one kernel, pushes through the
+     *          resident service kernel and its mailbox -- every estimate within the fp32 contract of the CPU restatement and argmax-exact
+     *          outside the noise margin; then what a robot's loop sees per push */
+    {
+        dce_ctx *lat = NULL, *none = NULL;
+        CHECK(dce_create_ex(&none, 0, 32, "no_such_option=1") == DCE_ERR_ARG && none == NULL && strstr(dce_last_error(NULL), "no_such_option"), "an unknown option must fail the creation");
+        CHECK(dce_create_ex(&lat, 0, 32, "latency=1,latency_idle_ms=50") == DCE_OK, "dce_create_ex: %s", dce_last_error(NULL));
+        for (int k = 0; k < 14; ++k) CHECK(dce_load_weight(lat, KEYS[k].key, w[k], KEYS[k].shape, KEYS[k].ndim) == DCE_OK, "%s", dce_last_error(lat));
+        CHECK(dce_finalize_weights(lat, DCE_FP32) == DCE_OK, "finalize (latency ctx): %s", dce_last_error(lat));
+        double worst_l = 0.0;
+        for (int t = 0; t < T; ++t) {
+            float lg[DCE_CLASSES]; int32_t p; uint8_t cb[4];
+            if (t == 180) { struct timespec nap = {0, 120 * 1000 * 1000}; nanosleep(&nap, NULL); }      /* the service leaves (50 ms idle) and comes back */
+            const int r = dce_online_push(lat, seq + t * DCE_CHANNELS, lg, &p, cb);
+            CHECK(r == (t >= DCE_WINDOW - 1 ? 1 : 0), "latency push %d returned %d: %s", t, r, dce_last_error(lat));
+            if (r != 1) continue;
+            const int j = t - (DCE_WINDOW - 1);
+            float top = -INFINITY, second = -INFINITY;
+            for (int k = 0; k < DCE_CLASSES; ++k) {
+                const float v = ref_logits[j * DCE_CLASSES + k];
+                worst_l = fmax(worst_l, fabs((double)lg[k] - v) / (1e-5 * maxref + 1e-4 * fabs(v)));
+                if (v > top) { second = top; top = v; } else if (v > second) second = v;
+            }
+            if (top - second > 1e-3 * maxref) CHECK(p == ref_pred[j], "latency mode: argmax of window %d: %d vs %d", j, p, ref_pred[j]);
+            uint8_t bits[4];
+            oracle_decimal2binary(p, bits);
+            CHECK(p == oracle_argmax16(lg) && memcmp(bits, cb, 4) == 0, "latency mode: pred / contact bits of window %d", j);
+        }
+        CHECK(worst_l <= 1.0, "latency mode: logits outside tolerance: err/bound = %.3f", worst_l);
+        float one[DCE_CLASSES]; int32_t p1; uint8_t c1[4];                   /* a one-window call (the service leaves first) */
+        CHECK(dce_forward_windows(lat, zwin, 1, 0, one, &p1, c1) == DCE_OK, "latency one-shot: %s", dce_last_error(lat));
+        for (int k = 0; k < DCE_CLASSES; ++k)
+            CHECK(fabs((double)one[k] - ref_logits[k]) <= 1e-5 * maxref + 1e-4 * fabs(ref_logits[k]), "latency one-shot logit %d", k);
+        for (int round = 0; round < 3; ++round) {
+            struct timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (int rep = 0; rep < 1000; ++rep) {
+                float lg[DCE_CLASSES]; int32_t p; uint8_t cb[4];
+                CHECK(dce_online_push(lat, seq + (rep % T) * DCE_CHANNELS, lg, &p, cb) == 1, "latency push (timing): %s", dce_last_error(lat));
+            }
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            printf("abi_client: latency mode: dce_online_push %.1f us per sample (1000 pushes, sample in -> estimate out; worst err/bound %.3f)\n",
+                   ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1000.0 / 1e3, worst_l);
+        }
+        dce_destroy(lat);
+    }
+
     /* ---- 5. materialised windows through dce_forward_windows */
     static float logits_w[N * DCE_CLASSES];
     CHECK(dce_forward_windows(ctx, zwin, N, 0, logits_w, NULL, NULL) == DCE_OK, "forward_windows: %s", dce_last_error(ctx));
