@@ -223,7 +223,6 @@ void conv_wino_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, FT*
 // MFMAs plus ~4 cycles for each of the ~9,400 other instructions its two waves per SIMD issue.
 // Register order of a wave's four row tiles: r[0], r[1] = the row pair that also serves the half tile, r[2], r[3] = the
 // other pair of the wave's 64 channels (so the half tile needs no runtime register choice).
-#endif  // DCE_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 #ifndef WINO4_SPLIT
@@ -514,6 +513,8 @@ void conv_wino_rt4_kernel(const float* __restrict__ src, int64_t n, ConvPack pk,
         TRACE_MARK(9);
     }
 }
+
+#endif  // DCE_EXPERIMENTS (conv_wino_rt4_kernel)
 
 // ------------------------------------------------------------------------------------------
 // One window per workgroup: the latency variant for a handful of windows (online mode, the

@@ -659,6 +659,12 @@ int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* o
 {
     if (!out || max_batch <= 0 || device_id < 0) return fail(nullptr, DCE_ERR_ARG, "dce_create: bad argument");
     *out = nullptr;
+    Tuning parsed;
+    {   // the A/B switches: the option string, else DCE_TUNE, over the defaults (one table: kTuneKeys) -- checked before anything else, so
+        // that a misspelt option is reported as what it is also on a box without a device
+        char msg[256];
+        if (!tuning_parse(options ? options : getenv("DCE_TUNE"), parsed, msg, (int)sizeof msg)) return fail(nullptr, DCE_ERR_ARG, "dce_create: %s", msg);
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -669,12 +675,8 @@ int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* o
     if (!c) return fail(nullptr, DCE_ERR_NOMEM, "out of host memory");
     c->device = device_id;
     c->max_batch = max_batch;
-    {   // the A/B switches: the option string, else DCE_TUNE, over the defaults (one table: kTuneKeys)
-        char msg[256];
-        if (!tuning_parse(options ? options : getenv("DCE_TUNE"), c->tuning, msg, (int)sizeof msg)) {
-            delete c;
-            return fail(nullptr, DCE_ERR_ARG, "dce_create: %s", msg);
-        }
+    {
+        c->tuning = parsed;
         Tuning& g = c->gate_tuning = c->tuning;                       // the gated DCE_FP32 fallback: two-window conv kernel, tile / phased GEMMs only
         g.gemm_peel = g.conv_peel = false; g.gemv = false;
         g.split_min = 1; g.split_max = 0; g.chain_min = 1; g.chain_max = 0; g.chain_max3 = 0; g.wino1_max = 0;

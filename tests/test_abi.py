@@ -42,6 +42,22 @@ def test_no_gpu_fails_loudly(lib):
         m(np.zeros((1, 150, 54), np.float32))
 
 
+def test_option_string_is_checked_before_the_device(lib):
+    """dce_create_ex's option string (the one table of A/B switches and modes): an unknown key or a malformed value
+    is DCE_ERR_ARG with a message that names it -- also on a box without a GPU; a well-formed string gets as far as the device check."""
+    import ctypes as C
+    ctx = C.c_void_p()
+    assert lib.dce_create_ex(C.byref(ctx), 0, 64, b"no_such_switch=1") == -1 and not ctx
+    assert b"no_such_switch" in lib.dce_last_error(None)
+    assert lib.dce_create_ex(C.byref(ctx), 0, 64, b"gemm_tile=yes") == -1 and b"not an integer" in lib.dce_last_error(None)
+    assert lib.dce_create_ex(C.byref(ctx), 0, 64, b"x3_bf16_terms=4") == -1
+    rc = lib.dce_create_ex(C.byref(ctx), 0, 64, b"gemm_tile=1,latency=1;chain_max=0 x3_pair=1")     # (experiments-only keys are accepted)
+    if rc == 0:
+        lib.dce_destroy(ctx)
+    else:
+        assert rc == -2 and b"no HIP device" in lib.dce_last_error(None)
+
+
 def test_null_ctx_is_an_error_not_a_crash(lib):
     assert lib.dce_finalize_weights(None, 0) < 0
     assert lib.dce_forward_windows(None, None, 0, 0, None, None, None) < 0
