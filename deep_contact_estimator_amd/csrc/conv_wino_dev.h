@@ -601,8 +601,9 @@ __device__ __forceinline__ void seg_stage1(float* __restrict__ act, const float*
 //   COHERENT    : the features are stored with agent-scope (write-through) stores: another workgroup of the SAME kernel reads them
 template <bool ZS, int NSEG, int NT1, int NT2, bool TAPS = false, bool XREG = false, bool COHERENT = false>
 __device__ __forceinline__ void conv_seg_body(float* __restrict__ act, const float* __restrict__ src, int64_t win0, int sg, const ConvPack& pk,
-                                              float* __restrict__ feat, const LayerTaps& taps, const float (*xin)[38] = nullptr)
-{
+                                              float* __restrict__ feat, const LayerTaps& taps, const float (*xin)[38] = nullptr, int chalf = -1)
+{   // chalf (latency mode): 0 / 1 = this workgroup finishes only output channels 64 chalf .. 64 chalf + 63 of conv4 (a second workgroup on the
+    // same segment takes the other half: conv1..3 are computed by both -- on CUs that would idle -- and conv4, 41 % of the stack's MFMAs, is halved)
     static_assert((NSEG == 2 && NT1 == 3 && NT2 == 2) || (NSEG == 4 && NT1 == 2 && NT2 == 1), "column tiles per segment count");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -697,6 +698,7 @@ __device__ __forceinline__ void conv_seg_body(float* __restrict__ act, const flo
             }
         }
         __syncthreads();
+        if (chalf >= 0 && (wv >> 2) != chalf) return;                  // (no barrier follows: the other half's waves are done)
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) { const int m = a4 + 16 * nt + j; boff[nt] = 2 * (m < b4 ? m : b4) - 1 - tb2; }
         wino_mfma_deep<RS2H, 32, 1, NT2, PF, 1, 46 % PF>(xrow2, boff, ap4, nullptr, ring, bias_lds + 256, co2, lane, acc);

@@ -1211,8 +1211,7 @@ int lat_push(dce_ctx* c, const float* sample, float* logits, int32_t* pred, uint
         bool dead = false;
         for (unsigned spins = 0;; ++spins) {
             if (estimate ? (__atomic_load_n(&mb->a.tag, __ATOMIC_ACQUIRE) == want_done && __atomic_load_n(&mb->b.tag, __ATOMIC_ACQUIRE) == want_done)
-                         : (__atomic_load_n(&mb->ack[0], __ATOMIC_ACQUIRE) == req && __atomic_load_n(&mb->ack[1], __ATOMIC_ACQUIRE) == req &&
-                            __atomic_load_n(&mb->ack[2], __ATOMIC_ACQUIRE) == req && __atomic_load_n(&mb->ack[3], __ATOMIC_ACQUIRE) == req)) break;
+                         : [&] { for (unsigned& a : mb->ack) if (__atomic_load_n(&a, __ATOMIC_ACQUIRE) != req) return false; return true; }()) break;
             DCE_CPU_RELAX();
             if ((spins & 0x3ff) != 0x3ff) continue;
             if (__atomic_load_n(&mb->error, __ATOMIC_ACQUIRE)) return lat_check_error(c);

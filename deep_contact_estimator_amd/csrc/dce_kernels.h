@@ -257,12 +257,12 @@ constexpr int ONLINE_ROWS = 4096;     // rows of the sample buffer; the last 149
 hipError_t launch_online_append_state(float* ring, OnlineState* state, const float* sample_host, hipStream_t st);
 
 // ---- latency mode (latency.hip; option latency=1): one window through the whole net in ONE kernel of 256 co-resident workgroups
-struct LatSync { unsigned long long feat; unsigned quit, pad; };               // fine-grained device memory: arrivals of the conv segments (monotonic: request s waits for 4 s), the service's quit word
+struct LatSync { unsigned long long feat; unsigned quit, pad; };               // fine-grained device memory: arrivals of the conv workgroups (monotonic: request s waits for 8 s), the service's quit word
 struct LatMailbox {                                                            // pinned host memory, device-visible, coherent
     unsigned req;              // host -> device: number of the newest request (written LAST, release)
     unsigned kind;             //   0 append the sample, 1 append + estimate, 2 quit
     float    sample[54];
-    unsigned ack[4];           // device -> host: conv workgroup i has taken request ack[i] (the sample slot is free)
+    unsigned ack[8];           // device -> host: conv workgroup i has taken request ack[i] (all eight: the sample slot is free)
     unsigned alive;            //   1 while the service kernel runs
     unsigned error;            //   a wait ran into its deadline (one shot or service)
     // The estimate: TWO 64-byte lines, each written by ONE 16-lane store and each carrying the estimate's number in its last word.  The

@@ -4,8 +4,9 @@
 // new sample), where the batch path's four launches cost 17.6 + 12.8 + 7.6 + 4.8 us of device time: a quarter-window conv segment per
 // workgroup, then fc.0 streaming its 38.8 MB of weights behind four 1200-link fmaf chains, fc.3, fc.6.  Here one grid of 256
 // workgroups -- one per CU, all co-resident (84 KB of LDS each) -- splits into two ROLES:
-//   * workgroups 0..3, "conv":  the four quarter-window segments of conv_wino_dev.h (z-score + conv1..4 + pools -> features);
-//   * workgroups 4..239, "fc.0": 2048 neurons = 160 x 9 + 76 x 8 rows;
+//   * workgroups 0..7, "conv":  the four quarter-window segments of conv_wino_dev.h (z-score + conv1..4 + pools -> features), two
+//                               workgroups per segment: both compute conv1..3 of it, each finishes one half of conv4's output channels;
+//   * workgroups 8..239, "fc.0": 2048 neurons = 192 x 9 + 40 x 8 rows;
 //   * workgroups 240..255, "fc.3": 32 neurons each; the first of them also fc.6 + argmax + contact bits.
 // An fc workgroup holds the weights of ITS neurons in registers (fc.0: 9 rows x 4736 floats over 512 threads = 108 VGPRs) -- they do not
 // depend on the window, so they are requested BEFORE the features exist and their 38.8 MB stream hides under the conv role's 17 us (one
@@ -14,12 +15,12 @@
 // adds -- so results are deterministic but NOT the batch path's bits (its summation tree, fc_tree.h, buys bit-identity across batch
 // sizes with four long chains); the mode is held to the fp32 tolerance against the CPU restatement instead (tests/test_round5_gpu.py).
 // The layers meet through fine-grained device memory without any cache maintenance (see below): the features behind an arrival
-// counter of the four conv segments, h1 and h2 as (value, request number) words that their readers poll.  Every wait has a deadline; a kernel that runs into one raises the mailbox's error word and leaves.
+// counter of the eight conv workgroups, h1 and h2 as (value, request number) words that their readers poll.  Every wait has a deadline; a kernel that runs into one raises the mailbox's error word and leaves.
 //
 // Two forms of the same kernel:
 //   one shot (dce_forward_windows / dce_infer_sequence with n = 1): source window in device memory, results to device pointers,
 //     stream-ordered like any other launch;
-//   service  (dce_online_push): the kernel stays resident; the four conv workgroups poll a mailbox in pinned host memory for the next
+//   service  (dce_online_push): the kernel stays resident; the conv workgroups poll a mailbox in pinned host memory for the next
 //     sample (216 bytes), keep the last 150 samples in LDS, and the first fc workgroup writes the estimate back to the mailbox: no launch,
 //     no copy, no stream operation per push.  It leaves on a quit request, or by itself after `idle` without one (the host relaunches
 //     it on the next push; the sample history also lives in device memory and is reloaded).
@@ -30,8 +31,9 @@ namespace dce {
 
 namespace {
 
-constexpr int LAT_CONV = 4, LAT_FC0 = 236, LAT_FC3 = 16, LAT_GRID = LAT_CONV + LAT_FC0 + LAT_FC3;
-constexpr int LAT_FC0_9 = FC1 - 8 * LAT_FC0;                  // fc.0 workgroups that carry 9 rows (160); the others 8
+constexpr int LAT_CONV = 8;                                   // conv workgroups: four quarter-window segments x two halves of conv4's output channels
+constexpr int LAT_FC0 = 232, LAT_FC3 = 16, LAT_GRID = LAT_CONV + LAT_FC0 + LAT_FC3;
+constexpr int LAT_FC0_9 = FC1 - 8 * LAT_FC0;                  // fc.0 workgroups that carry 9 rows (192); the others 8
 constexpr int LAT_R = 9;                                      // fc.0 rows per workgroup at most
 constexpr int LAT_N3 = FC2 / LAT_FC3;                         // fc.3 neurons per fc.3 workgroup (32)
 constexpr int LAT_S = 3;                                      // float4 slots of a 4736-float row per thread: index tid + 512 s < 1184
@@ -167,20 +169,21 @@ void latency_kernel(LatArgs a)
 
     if (blockIdx.x < LAT_CONV) {
         // ======================================================================== conv role: segment blockIdx.x of the window
-        const int sg = blockIdx.x;
+        const int sg = blockIdx.x >> 1, chalf = blockIdx.x & 1;                 // segment, half of conv4's output channels
+        const bool lead = blockIdx.x == 0;
         if constexpr (!SERVICE) {
-            if (sg == 0) LAT_TRACE(1);
-            conv_seg_body<MODE == 1, 4, 2, 1, false, false, true>(lds, a.src, 0, sg, a.pk, a.feat, LayerTaps{});
-            if (sg == 0) LAT_TRACE(2);
-            lat_arrive(&sy->feat, tid);
-            if (sg == 0) LAT_TRACE(3);
+            if (lead) LAT_TRACE(1);
+            conv_seg_body<MODE == 1, 4, 2, 1, false, false, true>(lds, a.src, 0, sg, a.pk, a.feat, LayerTaps{}, nullptr, chalf);
+            if (lead) LAT_TRACE(2);
+            lat_arrive(&sy->feat, tid);                                         // (the waves of the other channel half came back early and wait at its barrier)
+            if (lead) LAT_TRACE(3);
             return;
         } else {
             float* hist = lds + HLDS_FLOATS;                                    // [150][54], row (head + t) % 150 = sample t of the window
             LatMailbox* const mb = a.mbox;
             int head = a.hist_state[0], count = a.hist_state[1];
             for (int i = tid; i < LAT_HIST; i += 512) hist[i] = a.hist[i];
-            if (sg == 0 && tid == 0) __hip_atomic_store(&mb->alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lead && tid == 0) __hip_atomic_store(&mb->alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __syncthreads();
             unsigned last = a.req_base;
             for (;;) {
@@ -192,7 +195,7 @@ void latency_kernel(LatArgs a)
                     for (;;) {
                         const unsigned r = __hip_atomic_load(&mb->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         if (r != last) { last = r; kind = (int)__hip_atomic_load(&mb->kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                        if (sg == 0 ? (wall_clock64() - t0 > a.idle_ticks)
+                        if (lead ? (wall_clock64() - t0 > a.idle_ticks)
                                     : (__hip_atomic_load(&sy->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { kind = 2; break; }
                         __builtin_amdgcn_s_sleep(8);
                     }
@@ -203,19 +206,19 @@ void latency_kernel(LatArgs a)
                 const unsigned req = (unsigned)flag[1];
                 __syncthreads();
                 if (kind == 2) break;
-                if (sg == 0) LAT_TRACE(0);
+                if (lead) LAT_TRACE(0);
                 // ---- the sample -> the history (every conv workgroup keeps its own copy; workgroup 0 also keeps the device copy a
                 //      relaunched service starts from)
                 if (tid < CH) {
                     const float v = __hip_atomic_load(&mb->sample[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the host wrote it before the request number)
                     hist[head * CH + tid] = v;
-                    if (sg == 0) a.hist[head * CH + tid] = v;
+                    if (lead) a.hist[head * CH + tid] = v;
                 }
                 head = head + 1 == WIN ? 0 : head + 1;
                 count = count < WIN ? count + 1 : WIN;
-                if (sg == 0 && tid == 0) { a.hist_state[0] = head; a.hist_state[1] = count; }
+                if (lead && tid == 0) { a.hist_state[0] = head; a.hist_state[1] = count; }
                 __syncthreads();
-                if (tid == 0) __hip_atomic_store(&mb->ack[sg], req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the mailbox's sample is free
+                if (tid == 0) __hip_atomic_store(&mb->ack[blockIdx.x], req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // this workgroup has taken the sample
                 if (kind != 1 || count < WIN) continue;
                 // ---- the window's raw samples this thread owns (load_windows' map: rows t = 4 m + g of channel c), then the segment
                 float x[1][38];
@@ -228,16 +231,16 @@ void latency_kernel(LatArgs a)
                         x[0][m] = t < WIN ? hist[(r < WIN ? r : 0) * CH + c] : 0.f;
                     }
                 }
-                if (sg == 0) LAT_TRACE(1);
-                conv_seg_body<true, 4, 2, 1, false, true, true>(lds, nullptr, 0, sg, a.pk, a.feat, LayerTaps{}, x);
-                if (sg == 0) LAT_TRACE(2);
+                if (lead) LAT_TRACE(1);
+                conv_seg_body<true, 4, 2, 1, false, true, true>(lds, nullptr, 0, sg, a.pk, a.feat, LayerTaps{}, x, chalf);
+                if (lead) LAT_TRACE(2);
                 lat_arrive(&sy->feat, tid);
-                if (sg == 0) LAT_TRACE(3);
+                if (lead) LAT_TRACE(3);
             }
             // ---- leaving: release the fc role, tell the host
             if (tid == 0) {
                 __hip_atomic_store(&sy->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sg == 0) { lat_stores_done(); __hip_atomic_store(&mb->alive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                if (lead) { lat_stores_done(); __hip_atomic_store(&mb->alive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
             }
             return;
         }

@@ -216,9 +216,9 @@ int  dce_confusion_counts(dce_ctx* ctx, const int32_t* pred, const int64_t* labe
  * followed by a sequence number the call polls (~60 us per push on MI355X). */
 /* LATENCY MODE (option "latency=1" of dce_create_ex; DCE_FP32 contexts; csrc/latency.hip) -- the reference ships batch_size 1
  * (config/inference_one_seq_params.yaml:10).  A ONE-window dce_forward_windows / dce_infer_sequence (and their _packed forms) is then ONE
- * kernel of 256 co-resident workgroups (stream-ordered like any launch; 28 us instead of 43), and dce_online_push is served by the same
+ * kernel of 256 co-resident workgroups (stream-ordered like any launch; 26 us instead of 43), and dce_online_push is served by the same
  * kernel in RESIDENT form: started by the first push on a stream of its own, it takes every sample from a mailbox in pinned host memory
- * and answers through it (no launch, copy or stream operation per push: ~31 us per push from C instead of ~57).  It leaves when any other
+ * and answers through it (no launch, copy or stream operation per push: ~30 us per push from C instead of ~57).  It leaves when any other
  * entry point of the context is called, on dce_online_reset / dce_destroy, or by itself after latency_idle_ms (250) without a sample; the
  * next push restarts it with the sample history intact.  Results: inside the fp32 tolerance of the reference, deterministic, NOT the bits of
  * the batch path (another summation order).  The mode needs the whole device -- one workgroup per CU, 256 CUs, dce_create_ex refuses a
