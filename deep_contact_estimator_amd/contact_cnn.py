@@ -25,7 +25,7 @@ from .synth import STATE_DICT_SHAPES
 
 WINDOW, CHANNELS, CLASSES = 150, 54, 16
 PACKED_ROW = 68                        # include/dce.h DCE_PACKED_ROW: 16 fp32 logits + 4 contact bits
-PRECISIONS = {"fp32": 0, "bf16_fc": 1, "fp32_split": 2}   # fp32_split: fc.0 on three-term bf16 operands (include/dce.h DCE_FP32_SPLIT)
+PRECISIONS = {"fp32": 0, "bf16_fc": 1, "fp32_split": 2, "fp32_f16x2": 3}   # fp32_split: fc.0 on three-term bf16 operands (include/dce.h DCE_FP32_SPLIT)
 
 
 def _is_torch(x) -> bool:
@@ -392,7 +392,7 @@ class contact_cnn:
                                               p("feat"), p("h1"), p("h2"), p("logits")), self._ctx)
         return out
 
-    CONV_KERNELS = {"wino2": 0, "wino1x8": 1, "half": 2, "quarter": 3, "direct": 4, "wino1x4": 5, "wino2rt4": 6, "x3": 7}
+    CONV_KERNELS = {"wino2": 0, "wino1x8": 1, "half": 2, "quarter": 3, "direct": 4, "wino1x4": 5, "wino2rt4": 6, "x3": 7, "h2": 8}
 
     def conv_layer_taps(self, x, kernel="wino2"):
         """Parity-test hook (dce_conv_layer_taps): numpy (n<=64,150,54) pre-normalised windows through ONE named conv

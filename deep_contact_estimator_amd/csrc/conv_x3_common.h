@@ -7,6 +7,7 @@
 namespace dce {
 
 typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cx_f16x8 __attribute__((ext_vector_type(8)));
 typedef float cx_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CX_ROWS1 = 16 * 10 + 2, CX_ROWS2 = 16 * 5 + 2;      // LDS rows a stage reads: every column tile x every tap
@@ -75,19 +76,23 @@ __device__ __forceinline__ void cx_fetch_w0(const uint4* __restrict__ wp, CxW& w
 //          going out in a bunch ahead of them, during which the matrix pipe runs dry (~220 cycles of a 960-cycle K-step)
 //   NT   : terms per operand: 3 = fp32-grade products (six MFMAs each); 2 = ~17 significant bits (a1 b1 + a1 b2 + a2 b1: three MFMAs),
 //          for the precision whose features leave rounded to bf16 anyway.  The packed weights keep their three planes either way.
-template <int ROWB, int NKB, bool PRE = false, bool ILV = false, int NT = 3>
+//   F16  : (NT = 2 only; conv_h2.hip) the terms are fp16 -- 11 + 11 significand bits, scaled operands -- on v_mfma_f32_16x16x32_f16, and the
+//          packed weights hold two planes
+template <int ROWB, int NKB, bool PRE = false, bool ILV = false, int NT = 3, bool F16 = false>
 __device__ __forceinline__ void cx_layer(const char* __restrict__ xrow, const int (&sw)[3], int g,
                                          const uint4* __restrict__ wp, cx_f32x4 (&acc)[2][CX_NT], const CxW* pre = nullptr)
 {
     constexpr int S = 3 * NKB;
+    constexpr int WPL = F16 ? 2 : 3;                                  // planes of the weight pack
     static_assert(NT == 2 || NT == 3, "two or three terms");
+    static_assert(!F16 || NT == 2, "fp16 terms come in pairs");
     uint4 af[2][2][NT], bf[2][CX_NT][NT];                             // [buffer][...][plane]
     auto fetch = [&](int s, int b) {                                  // s, b compile-time at every call
         const int kb = s / 3, tap = s % 3;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int p = 0; p < NT; ++p) af[b][rt][p] = (PRE && s == 0) ? pre->f[rt][p] : wp[((s * 2 + rt) * 3 + p) * 64];
+            for (int p = 0; p < NT; ++p) af[b][rt][p] = (PRE && s == 0) ? pre->f[rt][p] : wp[((s * 2 + rt) * WPL + p) * 64];
         const char* x = xrow + tap * ROWB + (((4 * kb + g) ^ sw[tap]) << 4);
 #pragma unroll
         for (int ct = 0; ct < CX_NT; ++ct)
@@ -115,9 +120,12 @@ __device__ __forceinline__ void cx_layer(const char* __restrict__ xrow, const in
 #pragma unroll
             for (int ct = 0; ct < CX_NT; ++ct)
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                for (int rt = 0; rt < 2; ++rt) {
+                    if constexpr (F16) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                        __builtin_bit_cast(cx_f16x8, af[b][rt][TA[t]]), __builtin_bit_cast(cx_f16x8, bf[b][ct][TB[t]]), acc[rt][ct], 0, 0, 0);
+                    else acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(cx_bf16x8, af[b][rt][TA[t]]), __builtin_bit_cast(cx_bf16x8, bf[b][ct][TB[t]]), acc[rt][ct], 0, 0, 0);
+                }
         if constexpr (ILV) {
             if (s + 1 < S) {                                          // the order of this K-step's region: weights (L2) first, then the LDS reads
 #pragma unroll

@@ -6,6 +6,7 @@
 #include "dce_ctx.h"
 #include <chrono>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstddef>
 
@@ -332,8 +333,10 @@ struct GateScope {
 //                 >= 2817                        conv_x3[_permk] -> three planes  fc_x3_256x128             = DCE_FP32
 //                 (range guard refused the checkpoint, or -- behind the sequence above -- a window of the launch left the guarded
 //                  range: the DCE_FP32 row, gated on the device word the conv kernel raised)
-enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16 };
-enum class Fc0 { F32, Gemv, X3, Bf16 };
+//   DCE_FP32_F16X2  < 2817 (or a tap, or online)  = DCE_FP32
+//                 >= 2817                        conv_h2 -> two fp16 terms + scale fc_h2_256x128             = DCE_FP32
+enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16, H2 };
+enum class Fc0 { F32, Gemv, X3, Bf16, H2 };
 enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16 };
 struct Plan {
     Conv conv; int permk;                 // permk: features (and fc.0's weights) in the K order t' * 128 + c; 2: from persistent workgroups (experiments)
@@ -360,6 +363,8 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
         p.fused_rows = n;
         return p;
     }
+    const bool h2 = c->precision == DCE_FP32_F16X2 && !c->h2_refused && wino && !online && !c->want_feat && fc_gemm_h2_ok(n, FC1, FEAT);
+    if (h2) { p.conv = Conv::H2; p.fc0 = Fc0::H2; }
     const bool split = c->precision == DCE_FP32_SPLIT && !c->guard.refused && !c->gate_on;
     // DCE_FP32_SPLIT at a chip-filling batch: the conv stack writes the features straight as three bf16 planes (unless a tap wants
     // them in fp32: then a kernel of its own splits them)
@@ -376,7 +381,7 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
     // a handful of windows (online mode, batch_size 1): the weights streamed through all CUs (from 9 windows up launch_fc_gemm
     // picks the four-range / chain kernels instead); same bits as the GEMMs
     const bool gemv = tu.gemv && !c->gate_on && n <= FC_GEMV_MAX_M && !fc_split_ok(n, FC1, FEAT) && !fc_gemm_chain_ok(n, FC1, FEAT);
-    p.fc0 = x3 ? Fc0::X3 : gemv ? Fc0::Gemv : Fc0::F32;
+    p.fc0 = h2 ? Fc0::H2 : x3 ? Fc0::X3 : gemv ? Fc0::Gemv : Fc0::F32;
     p.split3 = x3 && !fused;
     p.fc3 = gemv ? Fc3::Gemv : Fc3::F32;
     if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1) && !fc_split_ok(n, FC2, FC1)) {
@@ -434,6 +439,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
       case Conv::X2Bf16:     HIP_TRY(c, launch_conv_x3_bf16(src, zscore, n, c->pkx3, featb, st, p.permk, c->tuning.x3_bf16_terms, c->src_row_dev)); break;
       case Conv::PairPlanes: HIP_TRY(c, launch_conv_x3p(src, zscore, n, c->pkx3, c->feat3, st)); break;
       case Conv::PairBf16:   HIP_TRY(c, launch_conv_x3p_bf16(src, zscore, n, c->pkx3, featb, st)); break;
+      case Conv::H2:         HIP_TRY(c, launch_conv_h2(src, zscore, n, c->pkh2, c->feat3, c->feat_scale, st)); break;
       } }
     { Timer t(c, 1);
       switch (p.fc0) {
@@ -446,6 +452,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
           else HIP_TRY(c, launch_fc_gemm_x3(c->feat3, p.permk ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, st));
           break;
       case Fc0::Bf16: HIP_TRY(c, launch_fc_gemm_bf16(c->feat, p.permk ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, st)); break;
+      case Fc0::H2:   HIP_TRY(c, launch_fc_gemm_h2(c->feat3, c->feat_scale, c->fc1w_h2, c->fc1_sw, c->fc1b, c->h1, n, FC1, FEAT, 1, st)); break;
       } }
     const int64_t nf = p.fused_rows;
     { Timer t(c, 2);
@@ -476,6 +483,7 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
     struct PlanScope { explicit PlanScope(std::vector<const char*>* p) { p->clear(); t_plan = p; } ~PlanScope() { t_plan = nullptr; } } plan_scope(&c->plan);
     c->prof = c->prof_period > 0 && (c->prof_tick++ % c->prof_period) == 0;
     if (c->precision == DCE_FP32_SPLIT && c->guard.refused) plan_note("split_guard_refused");
+    if (c->precision == DCE_FP32_F16X2 && c->h2_refused) plan_note("f16x2_refused");
     const Plan p = choose_plan(c, zscore, n);
     if (p.guarded) { ++c->guard_gen; ++c->guard_launches; }                                     // a generation per guarded launch: no reset of the device word between them
     int rc = run_plan(c, p, src, zscore, n, logits, pred, contacts, packed);
@@ -697,6 +705,8 @@ int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* o
     CREATE_TRY(init_fc_gemm());
     CREATE_TRY(init_fc_gemm_x3());
     CREATE_TRY(init_conv_x3());
+    CREATE_TRY(init_conv_h2());
+    CREATE_TRY(init_fc_gemm_h2());
     CREATE_TRY(init_conv_x3p());
     CREATE_TRY(hipMalloc(&c->feat, (size_t)max_batch * FEAT * sizeof(float)));
     CREATE_TRY(hipMalloc(&c->h1, (size_t)max_batch * FC1 * sizeof(float)));
@@ -756,7 +766,7 @@ void dce_destroy(dce_ctx* c)
     if (c->xfer_stream) { hipStreamSynchronize(c->xfer_stream); hipStreamDestroy(c->xfer_stream); }
     for (auto& slot : c->ring_ev) for (auto e : slot) if (e) hipEventDestroy(e);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->feat3); hipFree(c->h1); hipFree(c->h2); hipFree(c->part);
-    hipFree(c->d_guard); hipFree(c->fc1w_x3_own); hipFree(c->h1p); hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
+    hipFree(c->feat_scale); hipFree(c->d_guard); hipFree(c->fc1w_x3_own); hipFree(c->h1p); hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
     if (c->online_exec) hipGraphExecDestroy(c->online_exec);
     if (c->online_graph) hipGraphDestroy(c->online_graph);
     hipFree(c->d_ring); hipFree(c->d_online_state);
@@ -805,8 +815,8 @@ int dce_load_weight(dce_ctx* c, const char* key, const float* host, const int64_
 int dce_finalize_weights(dce_ctx* c, int precision)
 {
     if (!c) return DCE_ERR_ARG;
-    if (precision != DCE_FP32 && precision != DCE_BF16_FC && precision != DCE_FP32_SPLIT)
-        return fail(c, DCE_ERR_ARG, "unknown precision %d (0 = fp32, 1 = bf16 FC, 2 = fp32 with fc.0 on three-term bf16 operands)", precision);
+    if (precision != DCE_FP32 && precision != DCE_BF16_FC && precision != DCE_FP32_SPLIT && precision != DCE_FP32_F16X2)
+        return fail(c, DCE_ERR_ARG, "unknown precision %d (0 = fp32, 1 = bf16 FC, 2 = fp32 on three-term bf16 operands, 3 = fp32 tolerance on two-term fp16 operands)", precision);
     for (int k = 0; k < 14; ++k)
         if (!c->have[k]) return fail(c, DCE_ERR_STATE, "missing state_dict key '%s'", kKeys[k].name);
     DEVICE_GUARD(c);
@@ -845,7 +855,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         }
     };
     const bool want_cx = precision == DCE_FP32_SPLIT || (precision == DCE_BF16_FC && c->tuning.x3_conv);
-    const bool want_pair = want_cx && (c->tuning.x3_pair || c->tuning.x3_permk);      // fc.0's weights once more, K axis in the conv kernels' feature order t' * 128 + c
+    const bool want_pair = (want_cx && (c->tuning.x3_pair || c->tuning.x3_permk)) || precision == DCE_FP32_F16X2;      // fc.0's weights once more, K axis in the conv kernels' feature order t' * 128 + c
     std::vector<float> w1p;
     if (want_pair) { w1p.resize(c->host_w[8].size()); fc_perm_k_host(c->host_w[8].data(), FC1, w1p.data()); }
     size_t off_bf[2] = {0, 0}, off_bfp = 0;
@@ -886,6 +896,33 @@ int dce_finalize_weights(dce_ctx* c, int precision)
             if (!c->h1p) HIP_TRY(c, hipMalloc(&c->h1p, (size_t)(c->max_batch + 1) * FC1 * 3 * sizeof(unsigned short)));
         }
     }
+    // DCE_FP32_F16X2: conv1..4 and fc.0 as two fp16 terms of w * 2^sw (conv_h2.hip has the arithmetic); a non-finite weight or bias refuses the precision
+    size_t off_h2[4] = {0, 0, 0, 0}, off_h2fc = 0;
+    ConvPackH2 h2pk{};
+    int h2_fc_sw = 0;
+    bool h2_bad = false;
+    if (precision == DCE_FP32_F16X2) {
+        for (int l = 0; l < 4 && !h2_bad; ++l) {
+            const auto& w = c->host_w[2 * l]; const auto& b = c->host_w[2 * l + 1];
+            h2pk.sw[l] = h2_weight_shift(w.data(), w.size());
+            h2_bad = h2pk.sw[l] == INT_MIN;
+            if (!h2_bad) { h2pk.smax[l] = h2_input_smax(b.data(), b.size(), h2pk.sw[l]); h2_bad = h2pk.smax[l] == INT_MIN; }
+        }
+        if (!h2_bad) { h2_fc_sw = h2_weight_shift(c->host_w[8].data(), c->host_w[8].size()); h2_bad = h2_fc_sw == INT_MIN; }
+        for (int k = 9; k < 14; ++k)
+            for (float x : c->host_w[k]) h2_bad |= !std::isfinite(x);
+        h2pk.smax[4] = 100 - (h2_bad ? 0 : h2_fc_sw);                 // the features: fc.0's bias is added after the scales are taken off
+        if (!h2_bad) {
+            for (int l = 0; l < 4; ++l) {
+                off_h2[l] = reserve((conv_h2_pack_halfs(l) + 1) / 2);
+                conv_h2_pack_host(l, c->host_w[2 * l].data(), h2pk.sw[l], reinterpret_cast<unsigned short*>(img.data() + off_h2[l]));
+            }
+            off_h2fc = reserve(w1p.size());                           // two halfs per weight
+            fc_h2_pack_host(w1p.data(), FC1, FEAT, h2_fc_sw, reinterpret_cast<unsigned short*>(img.data() + off_h2fc));
+            if (!c->feat3) HIP_TRY(c, hipMalloc(&c->feat3, (size_t)(c->max_batch + 1) * FEAT * 3 * sizeof(unsigned short)));
+            if (!c->feat_scale) HIP_TRY(c, hipMalloc(&c->feat_scale, (size_t)(c->max_batch + 1) * sizeof(int)));
+        }
+    }
     if (c->d_weights) { HIP_TRY(c, hipFree(c->d_weights)); c->d_weights = nullptr; }
     HIP_TRY(c, hipMalloc(&c->d_weights, img.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -907,6 +944,14 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     c->fc1w_x3 = precision == DCE_FP32_SPLIT && !want_pair ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3) : nullptr;
     c->fc2w_x3 = precision == DCE_FP32_SPLIT && c->tuning.x3_fc3 ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3b) : nullptr;
     c->fc1w_x3p = precision == DCE_FP32_SPLIT && want_pair ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3p) : nullptr;
+    c->h2_refused = precision == DCE_FP32_F16X2 && h2_bad;
+    c->pkh2 = h2pk;
+    for (int l = 0; l < 4; ++l) {
+        c->pkh2.w[l] = precision == DCE_FP32_F16X2 && !h2_bad ? reinterpret_cast<const unsigned short*>(c->d_weights + off_h2[l]) : nullptr;
+        c->pkh2.b[l] = c->pk.b[l];
+    }
+    c->fc1w_h2 = precision == DCE_FP32_F16X2 && !h2_bad ? reinterpret_cast<const unsigned short*>(c->d_weights + off_h2fc) : nullptr;
+    c->fc1_sw = h2_fc_sw;
     c->precision = precision;
     c->guard = dce_ctx::SplitGuard{};
     if (precision == DCE_FP32_SPLIT) compute_split_guard(c);
@@ -1059,6 +1104,8 @@ int dce_conv_layer_taps(dce_ctx* c, const float* windows, int64_t n, int kernel,
         return fail(c, DCE_ERR_ARG, "dce_conv_layer_taps: need 0 < n <= min(64, max_batch) host windows and all six host outputs");
     if (kernel == 7 && c->precision != DCE_FP32_SPLIT)
         return fail(c, DCE_ERR_STATE, "dce_conv_layer_taps: kernel 7 (conv_x3) needs a context finalised with DCE_FP32_SPLIT");
+    if (kernel == 8 && (c->precision != DCE_FP32_F16X2 || c->h2_refused))
+        return fail(c, DCE_ERR_STATE, "dce_conv_layer_taps: kernel 8 (conv_h2) needs a context finalised with DCE_FP32_F16X2 (and a finite checkpoint)");
     if (c->precision == DCE_BF16_FC)
         return fail(c, DCE_ERR_STATE, "dce_conv_layer_taps: not available in DCE_BF16_FC (its conv stack is the fp32 / three-term one: tap a DCE_FP32 or DCE_FP32_SPLIT context)");
     TuningScope tuning_scope(&c->tuning);                 // the launchers below read this context's switches, not the process defaults
@@ -1074,7 +1121,8 @@ int dce_conv_layer_taps(dce_ctx* c, const float* windows, int64_t n, int kernel,
                    d + in_f + sz[0] + sz[1] + sz[2] + sz[3]};
     HIP_TRY(c, hipMemcpyAsync(d, windows, in_f * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(d + in_f, 0xff, (total - in_f) * sizeof(float), c->stream));      // untouched taps read back as NaN
-    const hipError_t e = kernel == 7 ? launch_conv_x3_taps(d, n, c->pkx3, c->feat3, c->feat, taps, c->stream)
+    const hipError_t e = kernel == 8 ? launch_conv_h2_taps(d, n, c->pkh2, c->feat3, c->feat_scale, c->feat, taps, c->stream)
+                       : kernel == 7 ? launch_conv_x3_taps(d, n, c->pkx3, c->feat3, c->feat, taps, c->stream)
                                      : launch_conv_taps(kernel, d, n, c->pk, c->feat, taps, c->stream);
     if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? DCE_ERR_ARG : DCE_ERR_HIP, "dce_conv_layer_taps: kernel %d: %s", kernel, hipGetErrorString(e));
     float* outs[5] = {conv1, conv2, pool1, conv3, conv4};

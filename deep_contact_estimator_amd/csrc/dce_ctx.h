@@ -56,6 +56,11 @@ struct dce_ctx {
     const unsigned short* fc2w_x3 = nullptr;                // ... fc.3's weights, three row-major planes [3][512][2048] (inside d_weights)
     unsigned short* h1p = nullptr;                          // ... h1 as three row-major bf16 planes [3][max_batch + 1][2048] (fc.0's epilogue writes them, fc.3 reads them)
     const unsigned short* fc1w_x3p = nullptr;               // ... and the same with the K axis in conv_x3p.hip's feature order
+    dce::ConvPackH2 pkh2{};                                 // DCE_FP32_F16X2: the conv weights as two fp16 terms, packed per lane, with their scales (conv_h2.hip)
+    const unsigned short* fc1w_h2 = nullptr;               // ... fc.0's weights [2048][148][2][32] fp16, K in the order t' * 128 + c, times 2^fc1_sw
+    int fc1_sw = 0;
+    int* feat_scale = nullptr;                             // ... the scale exponent of every window's features (max_batch)
+    bool h2_refused = false;                               // ... a non-finite weight: the precision runs the DCE_FP32 kernels
     float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
     bool want_feat = false;                                // dce_forward_taps: DCE_FP32_SPLIT keeps the fp32 features (split by a kernel of its own)
     bool want_h1 = false;                                  // dce_forward_taps: h1 is wanted in fp32 (DCE_FP32_SPLIT then keeps fc.3 on the fp32 kernels)

@@ -210,6 +210,32 @@ hipError_t launch_conv_x3p_bf16(const float* src, int zscore, int64_t n, const C
 // out[o][t' * 128 + c] = w[o][c * 37 + t'] for the (rows, 4736) fc.0 weight
 void       fc_perm_k_host(const float* w, size_t rows, float* out);
 
+// ---- DCE_FP32_F16X2 (conv_h2.hip, fc_gemm_h2.hip): fp32-tolerance results from TWO fp16 terms per operand (three MFMAs per product), every
+// operand scaled by a power of two -- per layer for the weights (sw, fixed at dce_finalize_weights), per window and layer for the
+// activations (chosen by the conv kernel from the layer's largest output) -- so that no input can leave fp16's range.
+struct ConvPackH2 {
+    const unsigned short* w[4];   // per-lane packs of the two-term weights (conv_h2_pack_host)
+    const float* b[4];            // biases, PyTorch order
+    int sw[4];                    // weight scale exponents: max|w_l| * 2^sw in [2^14, 2^15)
+    int smax[5];                  // the largest scale exponent the INPUT of conv layer l may carry (the scaled bias stays below 2^60); [4]: the features'
+};
+int        h2_weight_shift(const float* w, size_t n);                 // INT_MIN: a non-finite weight (the precision then runs the DCE_FP32 kernels)
+int        h2_input_smax(const float* bias, size_t n, int sw);        // INT_MIN: a non-finite bias
+size_t     conv_h2_pack_halfs(int layer);
+void       conv_h2_pack_host(int layer, const float* w, int sw, unsigned short* out);
+void       fc_h2_pack_host(const float* w, size_t rows, size_t K, int sw, unsigned short* out);      // [row][K-tile of 32][term (2)][32 fp16]
+hipError_t init_conv_h2();
+//   feat2: (n, 2 x 4736) fp16 in fc_gemm_h2.hip's operand layout, K in the order t' * 128 + c; feat_scale: (n) scale exponents of the rows
+hipError_t launch_conv_h2(const float* src, int zscore, int64_t n, const ConvPackH2& pk, unsigned short* feat2, int* feat_scale, hipStream_t st);
+//   ... with every layer's output and the features (n, 4736, the reference's flatten order) also written out in fp32, unscaled (dce_conv_layer_taps kernel 8)
+hipError_t launch_conv_h2_taps(const float* windows, int64_t n, const ConvPackH2& pk, unsigned short* feat2, int* feat_scale, float* feat32,
+                               const LayerTaps& taps, hipStream_t st);
+// fc.0 on two-term fp16 operands: C = act(A W^T * 2^-(row_scale[m] + sw) + bias), 256 x 128 tiles that fill the chip only
+hipError_t init_fc_gemm_h2();
+bool       fc_gemm_h2_ok(int64_t M, int N, int K);
+hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, const unsigned short* W2, int sw, const float* bias, float* C,
+                             int64_t M, int N, int K, int relu, hipStream_t st);
+
 // The same GEMMs at chip-filling sizes (fc_gemm_phased.hip): one workgroup per CU, 256x128 or 128x64 tiles,
 // LDS-DMA staging, two wave groups one phase apart; fp32 (bit-identical to the tile kernels: same K order) and
 // bf16.  launch_fc_gemm / launch_fc_gemm_bf16 dispatch here when fc_gemm_phased_ok(M, N, K, bf16).

@@ -72,7 +72,7 @@ typedef enum dce_precision {
                                   worst over 1e6 logits); argmax equal wherever the top-2 margin exceeds 1e-2 of the largest logit.
                                   BASELINE configs[4] as written ("bf16 on the FC layers, conv stays fp32") is the option
                                   x3_bf16_terms=3 -- fp32-grade conv results, band 2e-3; bench.py reports both figures */
-    DCE_FP32_SPLIT      = 2    /* fp32 results with the conv stack and fc.0 of chip-filling batches on the bf16 matrix pipe: every fp32
+    DCE_FP32_SPLIT      = 2,   /* fp32 results with the conv stack and fc.0 of chip-filling batches on the bf16 matrix pipe: every fp32
                                   operand enters as three bf16 terms (a = a1 + a2 + a3 exactly), six bf16 MFMAs per product, fp32
                                   accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; the conv stack from 128
                                   windows per call, fc.0 from 2817; below that the DCE_FP32 kernels.  Opt-in (csrc/conv_x3.hip, csrc/fc_gemm_x3.hip).
@@ -83,6 +83,15 @@ typedef enum dce_precision {
                                   for pre-normalised windows, per window in the conv kernel's load stage: a launch holding a window outside
                                   [x_lo, x_hi] is recomputed by the DCE_FP32 kernel sequence queued behind it (gated on the device, no host
                                   round trip).  z-scored windows (dce_infer_sequence) are inside the range by construction */
+    DCE_FP32_F16X2      = 3    /* fp32-TOLERANCE results with the conv stack and fc.0 of chip-filling batches (from 2817 windows per launch;
+                                  below that the DCE_FP32 kernels) on the fp16 matrix pipe: every operand is scaled by a power of two and
+                                  enters as TWO fp16 terms (11 + 11 significand bits), three MFMAs per product, fp32 accumulate
+                                  (csrc/conv_h2.hip, csrc/fc_gemm_h2.hip).  Not fp32 operands -- 22 of their 24 bits -- but the same contract
+                                  against the reference as DCE_FP32: the operand rounding costs 0.014 of the logit tolerance, a tenth of what
+                                  fp32 accumulation costs every precision here.  The scales -- per layer for the weights, per WINDOW and layer
+                                  for the activations, chosen by the kernel from the layer's largest output -- keep every operand inside
+                                  fp16's range whatever the input: no range guard, no fallback, and a window's result depends on that
+                                  window alone.  A checkpoint with a non-finite weight runs the DCE_FP32 kernels.  Opt-in */
 } dce_precision;
 /* Batch-size regimes.  DCE_FP32 gives a window the same bits whatever the size of the call it arrives in (one fixed summation tree in
  * every kernel family).  The two other precisions pick kernels by the number of windows in a launch (a call of more than max_batch
