@@ -84,6 +84,8 @@ def kernel_peak(kernel, precision):
         return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA"
     if precision == "fp32_split" and kernel == "fc1_gemm":
         return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA, six bf16 x bf16 terms per fp32 product (fc_gemm_x3.hip)"
+    if precision == "fp32_f16x2" and kernel in ("fc1_gemm", "conv_stack"):
+        return PEAK_BF16_MFMA_TFLOPS, "fp16 MFMA (same dense peak as bf16), three fp16 x fp16 terms per product" + (" (fc_gemm_h2.hip)" if kernel == "fc1_gemm" else ", direct-form conv with its tile padding (conv_h2.hip)")
     if precision in ("fp32_split", "bf16_fc") and kernel == "conv_stack":
         return PEAK_BF16_MFMA_TFLOPS, f"bf16 MFMA, {conv_terms(precision)} bf16 x bf16 terms per product, direct-form conv with its tile padding (conv_x3.hip)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA" if kernel != "fc3_tail" else "fp32 VALU (= fp32 MFMA rate)"
@@ -91,6 +93,8 @@ def kernel_peak(kernel, precision):
 
 def conv_terms(precision):
     """MFMAs per product of conv_x3.hip: six on three-term operands (fp32_split), three on two-term operands (bf16_fc's default)."""
+    if precision == "fp32_f16x2":
+        return 3
     return 3 if precision == "bf16_fc" and "x3_bf16_terms=3" not in os.environ.get("DCE_TUNE", "") else 6
 
 
@@ -98,7 +102,9 @@ def exec_flop(kernel, precision):
     """Matrix-pipe FLOPs issued per window by the kernel in this precision mode."""
     if precision == "fp32_split" and kernel == "fc1_gemm":
         return 6 * EXEC_FLOP[kernel]
-    if precision in ("fp32_split", "bf16_fc") and kernel == "conv_stack":       # direct form on 16x16 tiles: (64*160 + 64*160 + 128*80) * 192 + 128*80*384 MACs
+    if precision == "fp32_f16x2" and kernel == "fc1_gemm":
+        return 3 * EXEC_FLOP[kernel]
+    if precision in ("fp32_split", "bf16_fc", "fp32_f16x2") and kernel == "conv_stack":       # direct form on 16x16 tiles: (64*160 + 64*160 + 128*80) * 192 + 128*80*384 MACs
         return conv_terms(precision) * 2 * ((64 * 160 + 64 * 160 + 128 * 80) * 192 + 128 * 80 * 384)
     return EXEC_FLOP[kernel]
 
@@ -389,6 +395,9 @@ MODE_TEXT = {
     "fp32_split": "the bench step ({B} windows) with the conv stack and fc.0 on the bf16 matrix pipe, every fp32 operand as three bf16 terms "
                   "(six MFMAs per product, fp32 accumulate: fp32 results, not the fp32 path's bits -- opt-in, include/dce.h DCE_FP32_SPLIT); "
                   "fc.3 and fc.6 fp32 MFMA",
+    "fp32_f16x2": "the bench step ({B} windows) with the conv stack and fc.0 on the fp16 matrix pipe: every operand scaled by a power of two (per layer for "
+                  "the weights, per window and layer for the activations, chosen in the kernel) and carried as two fp16 terms, three MFMAs per product, "
+                  "fp32 accumulate -- fp32-TOLERANCE results (22-bit operands), no range guard needed (include/dce.h DCE_FP32_F16X2, opt-in); fc.3 and fc.6 fp32 MFMA",
 }
 
 
@@ -431,6 +440,9 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
                                           "conv kernel's load stage and a gated DCE_FP32 kernel sequence behind every launch (it ran `fallbacks_run` times); z-scored windows need neither")
         except Exception:                                         # noqa: BLE001
             pass
+    if precision == "fp32_f16x2":
+        res["dtype"] = ("f32 tolerance; the operands of the conv stack and fc.0 as two fp16 terms (22 significand bits) of the value times a power of two, "
+                        "three fp16 MFMAs per product, f32 accumulate")
     if precision == "bf16_fc":
         # the reference's shipped batch sizes in this precision: its conv stack is one workgroup per window at every size, fc.0 / fc.3
         # stream their bf16 weights past up to 64 windows (fc_stream_bf16.hip)
@@ -554,7 +566,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip extra.* (configs[2]/[3]/[4] measurements)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the profiled pass (no roofline block)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "fp32_split"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "fp32_split", "fp32_f16x2"],
                     help="fp32 = the headline (exact fp32 MFMA); bf16_fc = BASELINE configs[4] as the main workload; "
                          "fp32_split = fc.0 on three-term bf16 operands (fp32 results on the bf16 matrix pipe)")
     args = ap.parse_args()
@@ -718,7 +730,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16_fc": "bf16 FC operands (f32 accumulate); conv stack on two-term bf16 operands (~17 bits, f32 accumulate) in front of the features' rounding to bf16",
-                      "fp32_split": "f32 (conv stack and fc.0: f32 operands as three bf16 terms on bf16 MFMA, f32 accumulate)"}[args.precision], "data": "synthetic",
+                      "fp32_split": "f32 (conv stack and fc.0: f32 operands as three bf16 terms on bf16 MFMA, f32 accumulate)",
+                      "fp32_f16x2": "f32 tolerance (conv stack and fc.0: operands as two fp16 terms of the value times a power of two on fp16 MFMA, f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: {B} pre-normalised windows (B,150,54) fp32 per GPU per step, "
                             "HBM-resident -> fused conv stack + fc1/fc2/fc3 -> logits+argmax+contact bits "
@@ -766,7 +779,8 @@ def main():
                                       "algorithmic_GBs": kd["algorithmic_GBs"],
                                       "frac_of_8TBs": kd["algorithmic_GBs"] / PEAK_HBM_GBS},
                 "note": "achieved = matrix-pipe FLOPs issued per launch / average launch duration (HIP events on the launch "
-                        "stream, profiled pass); " + ("for this GEMM issued == algorithmic 2*M*N*K" if args.precision != "fp32_split" else
+                        "stream, profiled pass); " + ("for this GEMM issued == algorithmic 2*M*N*K" if args.precision not in ("fp32_split", "fp32_f16x2") else
+                        "fp32_f16x2: three fp16 x fp16 MFMA terms per product are issued, so issued = 3 x 2*MAC; the fp32-grade rate is algorithmic_flops_per_launch / avg_launch_ms" if args.precision == "fp32_f16x2" else
                         "fp32_split: six bf16 x bf16 MFMA terms per fp32 product are issued, so issued = 6 x (the direct form's) 2*MAC; "
                         "the fp32-grade rate is algorithmic_flops_per_launch / avg_launch_ms"),
             }
@@ -822,6 +836,7 @@ def main():
                 "streaming_1e6": extra_streaming(torch, contact_cnn, sd, dev),
                 "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s),
                 "fp32_split": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s, precision="fp32_split"),
+                "fp32_f16x2": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s, precision="fp32_f16x2"),
             }
             res["extra"]["bf16_fc"]["online_push"] = extra_online(contact_cnn, sd, dev, seq_np, pushes=1000, precision="bf16_fc")
             res["extra"]["latency_mode"] = extra_latency_mode(torch, contact_cnn, sd, dev, windows, seq_np, out["logits"])

@@ -48,6 +48,7 @@ SYMBOLS = {
     "dce_sync": (C.c_int, [C.c_void_p]),
     "dce_last_error": (C.c_char_p, [C.c_void_p]),
     "dce_debug_split3": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dce_debug_split_h2": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dce_debug_latency_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 

@@ -50,7 +50,7 @@ int h2_weight_shift(const float* w, size_t n)
     }
     if (m == 0.f) return 0;
     int sw = 14 - std::ilogb(m);
-    return sw < -100 ? -100 : sw > 100 ? 100 : sw;
+    return sw > 100 ? 100 : sw;                                        // (>= 14 - 127: the largest fp32 weights are scaled DOWN into fp16's range)
 }
 
 // the largest scale exponent a layer's INPUT may carry: bias * 2^(S + sw) stays below 2^60, S + sw below 100
@@ -63,7 +63,7 @@ int h2_input_smax(const float* bias, size_t n, int sw)
     }
     int s = 100 - sw;
     if (m > 0.f) s = std::min(s, 60 - sw - (std::ilogb(m) + 1));
-    return s < -100 ? -100 : s;
+    return s < -114 ? -114 : s;
 }
 
 static inline unsigned short h2_bits(_Float16 h) { unsigned short u; memcpy(&u, &h, 2); return u; }
@@ -132,7 +132,7 @@ __device__ __forceinline__ int hx_shift(unsigned mbits)
     const int e = (int)((mbits >> 23) & 0xffu);
     return e == 0xff ? 0 : 141 - e;
 }
-__device__ __forceinline__ int hx_clamp(int s, int hi) { return s > hi ? hi : s < -100 ? -100 : s; }
+__device__ __forceinline__ int hx_clamp(int s, int hi) { return s > hi ? hi : s < -114 ? -114 : s; }   // (14 - 127: the largest fp32 values still land in fp16's range)
 
 // the two fp16 terms of two (already scaled) values: p[k] = (term k of v0) | (term k of v1) << 16
 __device__ __forceinline__ void hx_split2(float v0, float v1, unsigned (&p)[2])
@@ -448,3 +448,12 @@ hipError_t launch_conv_h2_taps(const float* windows, int64_t n, const ConvPackH2
 }
 
 }  // namespace dce
+
+// test hook (tests/test_f16x2.py): the host split, as the conv / fc.0 weights get it
+extern "C" int dce_debug_split_h2(const float* x, size_t n, unsigned short* terms)
+{
+    const int sw = dce::h2_weight_shift(x, n);
+    if (sw == INT_MIN) return sw;
+    for (size_t i = 0; i < n; ++i) dce::h2_split_host(x[i], sw, terms[i], terms[n + i]);
+    return sw;
+}

@@ -313,6 +313,11 @@ const char* dce_last_error(dce_ctx* ctx);
  * (tests/test_x3_gpu.py::test_split_terms_are_exact).  No device involved. */
 void dce_debug_split3(const float* x, size_t n, unsigned short* planes);
 
+/* Test hook of DCE_FP32_F16X2 (csrc/conv_h2.hip): the scale exponent sw the weights x[0..n) get (max|x| * 2^sw in [2^14, 2^15); INT_MIN for a
+ * tensor with a non-finite entry) and the two fp16 terms of every x * 2^sw -- terms = [2][n] uint16, t1 = fp16(x 2^sw) round-to-nearest-even,
+ * t2 = fp16(x 2^sw - t1) -- the host routine that prepares the conv / fc.0 weights.  No device involved.  Returns sw. */
+int  dce_debug_split_h2(const float* x, size_t n, unsigned short* terms);
+
 /* Debug hook of the latency mode (option latency=1, contexts created with DCE_LAT_TRACE set): 16 stamps of the device's 100 MHz wall
  * clock taken by the last request -- [0] request seen, [1] window ready, [2] conv segment 0 done, [3] its arrival posted, [4] features
  * seen by fc workgroup 0, [5] its fc.0 rows done, [6] h1 complete, [7] its fc.3 rows done, [8] h2 complete, [9]/[10] results written. */

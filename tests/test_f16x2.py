@@ -1,0 +1,46 @@
+"""CPU (-m "not gpu"): the host half of the DCE_FP32_F16X2 precision (csrc/conv_h2.hip) -- the scale exponent and the two fp16 terms
+the conv / fc.0 weights (reference src/contact_cnn.py:10-49) are carried as.  No device involved: dce_debug_split_h2."""
+import ctypes as C
+
+import numpy as np
+
+
+def _split(x):
+    from deep_contact_estimator_amd import _lib
+    lib = _lib.load()
+    x = np.ascontiguousarray(x, np.float32)
+    terms = np.zeros((2, x.size), np.uint16)
+    sw = lib.dce_debug_split_h2(x.ctypes.data_as(C.c_void_p), C.c_size_t(x.size), terms.ctypes.data_as(C.c_void_p))
+    return sw, terms.view(np.float16).astype(np.float64)
+
+
+def test_two_fp16_terms_carry_22_bits_of_a_scaled_weight():
+    rng = np.random.default_rng(9)
+    for scale in (1.0, 1e-3, 1e3, 2.0 ** -60, 2.0 ** 40):
+        w = (rng.standard_normal(20000) * 0.05 * scale).astype(np.float32)
+        sw, t = _split(w)
+        m = np.abs(w).max()
+        assert 2.0 ** 14 <= m * 2.0 ** sw < 2.0 ** 15, (scale, sw)
+        v = w.astype(np.float64) * 2.0 ** sw
+        # the first term is the scaled value rounded to fp16 (nearest-even), the second the remainder rounded likewise
+        assert np.array_equal(t[0], v.astype(np.float32).astype(np.float16).astype(np.float64))
+        r = (v.astype(np.float32) - t[0].astype(np.float32)).astype(np.float16).astype(np.float64)
+        assert np.array_equal(t[1], r)
+        # two terms = 22 significand bits of every value that is not tiny beside the largest; below that an ABSOLUTE error of
+        # 2^-25 (fp16's subnormal spacing, half of it) -- 2^-39 of the tensor's largest entry
+        err = np.abs(t[0] + t[1] - v)
+        assert (err <= np.maximum(2.0 ** -22 * np.abs(v), 2.0 ** -25)).all()
+        assert np.isfinite(t).all()
+
+
+def test_degenerate_tensors():
+    sw, t = _split(np.zeros(8, np.float32))
+    assert sw == 0 and not t.any()
+    sw, _ = _split(np.array([1.0, np.nan], np.float32))
+    assert sw == -2 ** 31                                   # refused: the precision then runs the DCE_FP32 kernels
+    sw, _ = _split(np.array([1.0, np.inf], np.float32))
+    assert sw == -2 ** 31
+    sw, t = _split(np.array([3.0e38, -1.0], np.float32))   # the largest weights: scaled DOWN into fp16's range
+    assert 2.0 ** 14 <= 3.0e38 * 2.0 ** sw < 2.0 ** 15 and np.isfinite(t).all()
+    sw, t = _split(np.array([1e-44, 1e-45], np.float32))   # fp32 subnormals: the exponent is held at 100
+    assert sw == 100 and np.isfinite(t).all()

@@ -612,18 +612,19 @@ def test_direct_form_conv_kernel(monkeypatch, golden, case_inputs, orc):
     wino.close(); direct.close()
 
 
-@pytest.mark.parametrize("conv", ["winograd", pytest.param("direct", marks=needs_experiments), "fp32_split_guarded"])
+@pytest.mark.parametrize("conv", ["winograd", pytest.param("direct", marks=needs_experiments), "fp32_split_guarded", "fp32_f16x2"])
 def test_forward_windows_bench_batch(conv, monkeypatch, orc):
     """BASELINE configs[1] exactly as bench.py runs it: the 4096 pre-normalised windows of the bench
     step (synthetic sequence seed 2, z-scored by the library, checkpoint seed 1) through
-    dce_forward_windows -- EVERY row against the oracle, on both conv kernels and in the guarded fp32_split
-    precision (three-term bf16 operands behind the range guard: same contract)."""
+    dce_forward_windows -- EVERY row against the oracle, on both conv kernels, in the guarded fp32_split
+    precision (three-term bf16 operands behind the range guard: same contract) and in fp32_f16x2 (two-term fp16
+    operands with per-window scales: same contract)."""
     from deep_contact_estimator_amd import contact_cnn, synth
     B = 4096
     sd = synth.make_state_dict(1, "uniform")
     seq = synth.make_sequence(B + 149, seed=2).astype(np.float32)
     m = contact_cnn(device=0, max_batch=B, tune={"conv_direct": 1} if conv == "direct" else None,
-                    precision="fp32_split" if conv == "fp32_split_guarded" else "fp32")
+                    precision="fp32_split" if conv == "fp32_split_guarded" else "fp32_f16x2" if conv == "fp32_f16x2" else "fp32")
     m.load_state_dict(sd).eval()
     w = m.zscore_windows(seq, 0, B)                       # what bench.py materialises in HBM
     out = m.predict(w)
@@ -631,6 +632,8 @@ def test_forward_windows_bench_batch(conv, monkeypatch, orc):
         g = m.split_guard()
         assert m.last_plan()[0].startswith("conv_x3") and "fc_x3_256x128" in m.last_plan() and m.last_plan()[-1] == "gated_fp32_fallback", m.last_plan()
         assert g["enabled"] and not g["refused"] and g["guarded_launches"] == 1 and g["windows_out_of_range"] == 0 and g["fallbacks_run"] == 0, g
+    if conv == "fp32_f16x2":
+        assert m.last_plan()[0] == "conv_h2" and "fc_h2_256x128" in m.last_plan(), m.last_plan()
     m.close()
     ref = orc.Oracle(sd).forward_windows(w)
     assert out["logits"].shape == (B, 16)
