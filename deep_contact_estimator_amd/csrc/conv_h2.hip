@@ -210,7 +210,9 @@ __device__ __forceinline__ void hx_store(char* __restrict__ lds, const cx_f32x4 
 
 // TAPS (dce_conv_layer_taps kernel 8, parity tests): every layer's output ALSO goes to HBM in fp32, unscaled, and so do the features, as (n, 4736)
 // fp32 in the reference's flatten order c * 37 + t'
-template <bool ZS, bool TAPS>
+// OUT32 (mid-size batches, below fc_gemm_h2.hip's threshold: the FC layers then run on the fp32 kernels): the features leave unscaled, as
+// (n, 4736) fp32 in the reference's flatten order, through LDS and 16-byte stores; nothing else is written
+template <bool ZS, bool TAPS, bool OUT32 = false>
 __global__ __launch_bounds__(256, 3)
 void conv_h2_kernel(const float* __restrict__ src, int64_t n, ConvPackH2 pk, unsigned short* __restrict__ feat2, int* __restrict__ feat_scale,
                     LayerTaps taps, float* __restrict__ feat32)
@@ -375,9 +377,38 @@ void conv_h2_kernel(const float* __restrict__ src, int64_t n, ConvPackH2 pk, uns
         const int sw4[3] = {cx_swz<256>(j), cx_swz<256>(j + 1), cx_swz<256>(j + 2)};
         bias_acc(pk.b[3], 32 * wv, S + pk.sw[3]);
         cx_layer<256, 4, false, CX_ILV != 0, 2, true>(cx_lds + j * 256, sw4, g, w3 + (size_t)wv * (12 * 2 * 2 * 64), acc);
-        hx_layer_max<75>(acc, 0, j, lane, &hx_max[3]);
+        if constexpr (!OUT32) hx_layer_max<75>(acc, 0, j, lane, &hx_max[3]);
         TRACE_MARK(8);
-        __syncthreads();                                               // every wave's maximum is in (the one barrier the features' common scale costs)
+        __syncthreads();                                               // every wave's maximum is in (the one barrier the features' common scale costs; OUT32: conv4's input is dead)
+        if constexpr (OUT32) {
+            static_assert(!TAPS, "the taps ride on the product route");
+            const int e4 = S + pk.sw[3];
+            float* const fl = reinterpret_cast<float*>(cx_lds);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int co = 32 * wv + 16 * rt + 4 * g;
+#pragma unroll
+                for (int ct = 0; ct < CX_NT; ++ct) {
+                    const int t = 16 * ct + j;
+                    float q[4] = {acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r] = __builtin_ldexpf(fmaxf(fmaxf(q[r], cx_neighbour(q[r])), 0.f), -e4);
+                    if ((j & 1) == 0 && (t >> 1) < 37) {
+                        float* d = fl + co * 37 + (t >> 1);
+                        d[0] = q[0]; d[37] = q[1]; d[74] = q[2]; d[111] = q[3];
+                    }
+                }
+            }
+            __syncthreads();
+            const float nn = __builtin_nanf("");
+            for (int q = tid; q < FEAT / 4; q += 256) {
+                float4 val = reinterpret_cast<const float4*>(cx_lds)[q];
+                if (window_bad) val = make_float4(nn, nn, nn, nn);
+                reinterpret_cast<float4*>(feat32 + (size_t)win * FEAT)[q] = val;
+            }
+            TRACE_MARK(9);
+            return;
+        }
         // ---- conv4 + ReLU + MaxPool (t = 74 dropped) straight from the accumulators to HBM in the K order k' = t' * 128 + c: a lane holds four
         //      consecutive channels of one pooled position = 8 bytes per term; a row's K-tile of 32 is one 128-byte line [term 1 | term 2]
         const int e4 = S + pk.sw[3];                                   // conv4's accumulators carry 2^e4
@@ -422,7 +453,8 @@ hipError_t init_conv_h2()
 {
     hipError_t e;
     for (const void* k : {reinterpret_cast<const void*>(&conv_h2_kernel<true, false>), reinterpret_cast<const void*>(&conv_h2_kernel<false, false>),
-                          reinterpret_cast<const void*>(&conv_h2_kernel<false, true>)})
+                          reinterpret_cast<const void*>(&conv_h2_kernel<false, true>),
+                          reinterpret_cast<const void*>(&conv_h2_kernel<true, false, true>), reinterpret_cast<const void*>(&conv_h2_kernel<false, false, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CX_PLANE)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -435,6 +467,17 @@ hipError_t launch_conv_h2(const float* src, int zscore, int64_t n, const ConvPac
     plan_note("conv_h2");
     if (zscore) hipLaunchKernelGGL((conv_h2_kernel<true, false>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat2, feat_scale, LayerTaps{}, nullptr);
     else        hipLaunchKernelGGL((conv_h2_kernel<false, false>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat2, feat_scale, LayerTaps{}, nullptr);
+    return hipGetLastError();
+}
+
+// the same stack with (n, 4736) fp32 features out: DCE_FP32_F16X2 at batches below fc_gemm_h2.hip's threshold
+hipError_t launch_conv_h2_f32(const float* src, int zscore, int64_t n, const ConvPackH2& pk, float* feat, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    constexpr int L2T = 2 * CX_PLANE;
+    plan_note("conv_h2_f32");
+    if (zscore) hipLaunchKernelGGL((conv_h2_kernel<true, false, true>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, nullptr, nullptr, LayerTaps{}, feat);
+    else        hipLaunchKernelGGL((conv_h2_kernel<false, false, true>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, nullptr, nullptr, LayerTaps{}, feat);
     return hipGetLastError();
 }
 

@@ -333,9 +333,10 @@ struct GateScope {
 //                 >= 2817                        conv_x3[_permk] -> three planes  fc_x3_256x128             = DCE_FP32
 //                 (range guard refused the checkpoint, or -- behind the sequence above -- a window of the launch left the guarded
 //                  range: the DCE_FP32 row, gated on the device word the conv kernel raised)
-//   DCE_FP32_F16X2  < 2817 (or a tap, or online)  = DCE_FP32
+//   DCE_FP32_F16X2  < x3_conv_min (128), a tap, online  = DCE_FP32
+//                 .. < 2817                      conv_h2_f32 (two fp16 terms)     fc_* fp32                 = DCE_FP32
 //                 >= 2817                        conv_h2 -> two fp16 terms + scale fc_h2_256x128             = DCE_FP32
-enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16, H2 };
+enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16, H2, H2F32 };
 enum class Fc0 { F32, Gemv, X3, Bf16, H2 };
 enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16 };
 struct Plan {
@@ -365,6 +366,7 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
     }
     const bool h2 = c->precision == DCE_FP32_F16X2 && !c->h2_refused && wino && !online && !c->want_feat && fc_gemm_h2_ok(n, FC1, FEAT);
     if (h2) { p.conv = Conv::H2; p.fc0 = Fc0::H2; }
+    else if (c->precision == DCE_FP32_F16X2 && !c->h2_refused && wino && !online && n >= tu.x3_conv_min) p.conv = Conv::H2F32;   // mid-size batch (or a feature tap): two-term fp16 conv stack, fp32 features, fp32 FC kernels
     const bool split = c->precision == DCE_FP32_SPLIT && !c->guard.refused && !c->gate_on;
     // DCE_FP32_SPLIT at a chip-filling batch: the conv stack writes the features straight as three bf16 planes (unless a tap wants
     // them in fp32: then a kernel of its own splits them)
@@ -440,6 +442,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
       case Conv::PairPlanes: HIP_TRY(c, launch_conv_x3p(src, zscore, n, c->pkx3, c->feat3, st)); break;
       case Conv::PairBf16:   HIP_TRY(c, launch_conv_x3p_bf16(src, zscore, n, c->pkx3, featb, st)); break;
       case Conv::H2:         HIP_TRY(c, launch_conv_h2(src, zscore, n, c->pkh2, c->feat3, c->feat_scale, st)); break;
+      case Conv::H2F32:      HIP_TRY(c, launch_conv_h2_f32(src, zscore, n, c->pkh2, c->feat, st)); break;
       } }
     { Timer t(c, 1);
       switch (p.fc0) {

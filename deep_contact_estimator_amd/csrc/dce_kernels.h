@@ -227,6 +227,8 @@ void       fc_h2_pack_host(const float* w, size_t rows, size_t K, int sw, unsign
 hipError_t init_conv_h2();
 //   feat2: (n, 2 x 4736) fp16 in fc_gemm_h2.hip's operand layout, K in the order t' * 128 + c; feat_scale: (n) scale exponents of the rows
 hipError_t launch_conv_h2(const float* src, int zscore, int64_t n, const ConvPackH2& pk, unsigned short* feat2, int* feat_scale, hipStream_t st);
+//   ... with (n, 4736) fp32 features out, unscaled, in the reference's flatten order (mid-size batches: the FC layers on the fp32 kernels)
+hipError_t launch_conv_h2_f32(const float* src, int zscore, int64_t n, const ConvPackH2& pk, float* feat, hipStream_t st);
 //   ... with every layer's output and the features (n, 4736, the reference's flatten order) also written out in fp32, unscaled (dce_conv_layer_taps kernel 8)
 hipError_t launch_conv_h2_taps(const float* windows, int64_t n, const ConvPackH2& pk, unsigned short* feat2, int* feat_scale, float* feat32,
                                const LayerTaps& taps, hipStream_t st);

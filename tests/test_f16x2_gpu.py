@@ -95,9 +95,32 @@ def test_conv_h2_layers_vs_reference_hooks(case, golden, case_inputs, orc):
     m.close()
 
 
-@pytest.mark.parametrize("n", [1, 30, 127, 700, 2816])
+@pytest.mark.parametrize("n", [128, 700, 2049, 2816])
+def test_mid_size_batches(n, pair, orc):
+    """From 128 windows up to fc_gemm_h2's threshold the mode's conv stack already runs on two-term fp16 operands (conv_h2_kernel with fp32
+    features out; the FC layers stay on the fp32 kernels): every row against the oracle at the fp32 tolerance, a NaN window contained; and
+    the features of a chip-filling tap are the same kernel's."""
+    sd, a, b = pair
+    x = np.random.default_rng(1000 + n).standard_normal((n, 150, 54), dtype=np.float32)
+    x[3, 100, 0] = np.nan
+    out = b.predict(x)
+    plan = b.last_plan()
+    assert plan[0] == "conv_h2_f32" and "fc_h2_256x128" not in plan, plan
+    assert np.isnan(out["logits"][3]).all() and out["pred"][3] == 0
+    keep = np.arange(n) != 3
+    o = orc.Oracle(sd)
+    ref = o.forward_windows(x[keep])
+    tol_ok(out["logits"][keep], ref["logits"], f"fp32_f16x2, mid-size batch {n}")
+    _argmax_ok(out["pred"][keep], ref["logits"], ref["pred"])
+    t = b.forward_taps(x[:256] if n >= 256 else x)
+    assert b.last_plan()[0] == "conv_h2_f32", b.last_plan()
+    k2 = keep[:len(t["feat"])]
+    tol_ok(t["feat"][k2], o.forward_windows(x[:len(t["feat"])][k2], taps=True)["feat"], "features of the two-term fp16 conv stack")
+
+
+@pytest.mark.parametrize("n", [1, 30, 127])
 def test_small_batches_are_the_fp32_path(n, pair):
-    """Below a chip-filling launch the mode runs the DCE_FP32 kernels: that precision's bits."""
+    """Below 128 windows the mode runs the DCE_FP32 kernels: that precision's bits."""
     sd, a, b = pair
     x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
     ra, rb = a.predict(x), b.predict(x)
