@@ -64,7 +64,7 @@ const TuneKey kTuneKeys[] = {
     TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
     TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'),
     TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
-    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'),
+    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_ksplit, 'b'),
     TKX(bf16_k32, 'b'), TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
     TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
 };
@@ -922,7 +922,11 @@ int dce_finalize_weights(dce_ctx* c, int precision)
             }
             off_h2fc = reserve(w1p.size());                           // two halfs per weight
             fc_h2_pack_host(w1p.data(), FC1, FEAT, h2_fc_sw, reinterpret_cast<unsigned short*>(img.data() + off_h2fc));
-            if (!c->feat3) HIP_TRY(c, hipMalloc(&c->feat3, (size_t)(c->max_batch + 1) * FEAT * 3 * sizeof(unsigned short)));
+            if (!c->feat3) {                                          // two fp16 terms per feature, padded by a tile of rows (fc_gemm_h2_pad_rows)
+                const size_t halfs = std::max((size_t)(c->max_batch + 1) * FEAT * 3, (size_t)(c->max_batch + fc_gemm_h2_pad_rows()) * FEAT * 2);
+                HIP_TRY(c, hipMalloc(&c->feat3, halfs * sizeof(unsigned short)));
+                HIP_TRY(c, hipMemset(c->feat3, 0, halfs * sizeof(unsigned short)));
+            }
             if (!c->feat_scale) HIP_TRY(c, hipMalloc(&c->feat_scale, (size_t)(c->max_batch + 1) * sizeof(int)));
         }
     }

@@ -54,6 +54,8 @@ struct Tuning {
     bool x3_unfused = false;                                // 1: fp32 features + split3 kernel instead of the conv kernel's three-plane output
     bool x3_permk = true;                                   // 0: conv_x3.hip's features through LDS in the reference's flatten order instead of straight out in the order t' * 128 + c
     bool x3_fc3 = false;                                    // 1: fc.3 on three-term operands too (fc_gemm_x3.hip's 128 x 64 tile with the fused fc.6 epilogue; h1 leaves fc.0 as three planes).  Built and parity-green in round 5, and NOT faster: 64.3 us against 71 for the fp32 MFMA kernel, +9.5 us on fc.0's epilogue (profiles/r5j_split_fc3.txt) -- with 32 x 32 wave tiles a K-tile's LDS traffic is fc.0's for half its MFMAs
+    // -- DCE_FP32_F16X2
+    bool h2_ksplit = false;                                 // 1: fc.0's K-tiles dealt out between the two wave groups (fc_gemm_h2k_kernel: 64 x 128 wave tiles, 48-MFMA phases, three LDS buffers)
     bool split_guard = true;                                // 0: no range guard (static bound at finalize, per-window exponent check + fp32 fallback): the round-4 behaviour, for the A/B and the audit
     // -- experiments build only (ignored by the product library)
     bool gemm_lockstep = false, gemm_pipe = false, gemm_ki = false;
@@ -235,6 +237,7 @@ hipError_t launch_conv_h2_taps(const float* windows, int64_t n, const ConvPackH2
 // fc.0 on two-term fp16 operands: C = act(A W^T * 2^-(row_scale[m] + sw) + bias), 256 x 128 tiles that fill the chip only
 hipError_t init_fc_gemm_h2();
 bool       fc_gemm_h2_ok(int64_t M, int N, int K);
+int        fc_gemm_h2_pad_rows();                                     // rows A2's buffer must hold beyond M (ragged tiles read them)
 hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, const unsigned short* W2, int sw, const float* bias, float* C,
                              int64_t M, int N, int K, int relu, hipStream_t st);
 

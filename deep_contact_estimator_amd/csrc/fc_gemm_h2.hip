@@ -218,10 +218,190 @@ void fc_gemm_h2_kernel(const unsigned short* __restrict__ A2, const int* __restr
     else store_tile(std::false_type{});
 }
 
+
+// ---- the same GEMM with the K-TILES dealt out between the two wave groups (option h2_ksplit): a wave owns 64 x 128 of the tile -- 2 x 4 blocks,
+// 128 accumulator registers -- for every OTHER K-tile, so a phase is 48 MFMAs against 24 fragment reads per wave (0.5 per MFMA; the N-split form
+// above: 24 against 16, 0.67, and a load phase as long as the math phase beside it), and a K-tile's fragments are read by four waves instead of
+// eight (96 KB of LDS reads per 48 KB tile instead of 128).  Three buffers: tile p + 2 is issued by the group that loads tile p, in phase p, and
+// first read in phase p + 2.  At the end the groups exchange halves of their accumulators through LDS (fixed order: even tiles + odd tiles) and
+// each finishes two of the four column blocks.
+__global__ __launch_bounds__(512, 2)
+void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __restrict__ row_scale, const unsigned short* __restrict__ W2, int sw,
+                        const float* __restrict__ bias, float* __restrict__ C,
+                        int M, int N, int K, int relu, int mtiles, int ntiles, int sn_log2)
+{
+    constexpr int BM = H2_BM, ROWB = H2_ROWB, TILE = H2_TILE, NCH = H2_NCH, NQA = H2_NQA;
+    extern __shared__ __attribute__((aligned(16))) char h2_smem[];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, li = bid >> 3;
+    const int sid = (li >> 5) * 8 + xcd;
+    const int within = li & 31;
+    const int sn = 1 << sn_log2, sm = 32 >> sn_log2;
+    const int nsn = ntiles >> sn_log2;
+    const int tm = (sid / nsn) * sm + (within >> sn_log2);
+    const int tn = (sid % nsn) * sn + (within & (sn - 1));
+    if (tm >= mtiles) return;
+    const int m0 = tm * BM, n0 = tn * H2_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2;                                // K-tile parity of this wave's group; waves w and w+4 share a SIMD
+    const int wm = (wid & 3) * 64;                           // this wave's rows of the block tile (all 128 columns)
+    const int i = lane & 31, h = lane >> 5;
+
+    // (pieces: ONE per-lane offset for the A panel and one for the W panel -- a piece's 8 rows start 32 rows behind the previous one's, which moves
+    //  the wave-uniform base, not the lanes; rows past M are READ (the feature buffer is padded by a tile of rows) and never stored)
+    const size_t rowb = (size_t)K * 4;
+    unsigned voffA, voffW;
+    {
+        const int lr = lane >> 3, slot = lane & 7, w4 = wid & 3;
+        const int r = 8 * w4 + lr;                                        // row of piece 0; swz(r + 32 j) = swz(r)
+        voffA = voffW = (unsigned)((size_t)r * rowb + 16 * (slot ^ h2_swz(r)));
+        asm volatile("" : "+v"(voffA), "+v"(voffW));
+    }
+    const char* sA = reinterpret_cast<const char*>(A2) + (size_t)m0 * rowb;
+    const char* sW = reinterpret_cast<const char*>(W2) + (size_t)n0 * rowb;
+    const unsigned lds_wave = h2_lds_addr(h2_smem) + (wid & 3) * 1024;
+    auto issue = [&](unsigned lds0, size_t ko) {
+        const unsigned keep = h2_m0_begin(lds0);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (j < NQA) h2_piece(sA + ko + (size_t)j * 32 * rowb, voffA);
+            else         h2_piece(sW + ko + (size_t)(j - NQA) * 32 * rowb, voffW);
+        }
+        h2_m0_end(keep);
+    };
+
+    const int swz = h2_swz(i);
+    unsigned fa[2][2], fb[2][2];                                          // [term][kq]: byte offsets of block 0 in buffer 0
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+            const int o = 16 * ((4 * p + 2 * kq + h) ^ swz);
+            fa[p][kq] = (wm + i) * ROWB + o;
+            fb[p][kq] = (BM + i) * ROWB + o;
+            asm volatile("" : "+v"(fa[p][kq]), "+v"(fb[p][kq]));
+        }
+
+    h2_f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 af[2][2][2], bf[2][2][4];                                      // [kq][term][block]
+    auto load_frags = [&](unsigned bo) {                                  // bo: the buffer's byte offset
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) af[kq][p][blk] = *reinterpret_cast<const float4*>(h2_smem + (fa[p][kq] + bo) + blk * 32 * ROWB);
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) bf[kq][p][blk] = *reinterpret_cast<const float4*>(h2_smem + (fb[p][kq] + bo) + blk * 32 * ROWB);
+            }
+    };
+    auto math = [&]() {
+        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(h2_f16x8, af[kq][TA[t]][a]), __builtin_bit_cast(h2_f16x8, bf[kq][TB[t]][b]), acc[a][b], 0, 0, 0);
+    };
+
+    const int KT = K / H2_KT;                                             // even, >= 4 (checked by the launcher)
+    // Phase p = 0 .. KT: group p & 1 issues tile p + 2 and reads tile p's fragments, the other group multiplies tile p - 1.
+    //   WAR: the buffer of tile p + 2 held tile p - 1, read in phase p - 1, which ended with lgkmcnt(0) + barrier;
+    //   RAW: tile p + 2 is first read in phase p + 2; its issuing group waits vmcnt(0) at the end of its math phase p + 1, ahead of that barrier.
+    issue(lds_wave + grp * TILE, (size_t)grp * ROWB);                     // tiles 0 (group 0) and 1 (group 1)
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (grp == 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // group 1 sits out phase 0 (tile 1 has landed when it ends)
+    unsigned bu = grp, bn = grp == 0 ? 2 : 0;                             // buffers of tile u and of tile u + 2
+#pragma unroll 1
+    for (int u = grp; u < KT; u += 2) {
+        // ---- load phase (phase u)
+        if (u + 2 < KT) issue(lds_wave + bn * TILE, (size_t)(u + 2) * ROWB);
+        load_frags(bu * TILE);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- math phase (phase u + 1)
+        math();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        bu = bn; bn = bn == 0 ? 2 : bn - 1;                               // (u + 2) % 3, (u + 4) % 3: 0 -> 2 -> 1 -> 0
+    }
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");                 // same number of barriers for both groups
+
+    // ---- the groups exchange halves: group g keeps column blocks 2g, 2g + 1 and sends the other two (64 floats per lane) through LDS; then
+    //      the epilogue on this wave's two column blocks.  (G is the group as a compile-time constant: a run-time index into the accumulators
+    //      would put them in scratch.)
+    auto finish = [&](auto gc) {
+        constexpr int G = decltype(gc)::value;
+        float* const x = reinterpret_cast<float*>(h2_smem) + ((size_t)wid * 64 * 64);      // this wave's 16 KB: [64 values][64 lanes]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[((a * 2 + b) * 16 + r) * 64 + lane] = acc[a][2 * (1 - G) + b][r];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const float* const y = reinterpret_cast<const float*>(h2_smem) + ((size_t)(wid ^ 4) * 64 * 64);   // the partner wave (same rows, other group)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float mine = acc[a][2 * G + b][r], theirs = y[((a * 2 + b) * 16 + r) * 64 + lane];
+                    acc[a][2 * G + b][r] = G == 0 ? mine + theirs : theirs + mine;        // even tiles + odd tiles, whoever adds
+                }
+        auto store_tile = [&](auto full) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                int ex[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (!decltype(full)::value && row >= M) row = M - 1;
+                    ex[r] = -(row_scale[row] + sw);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int col = n0 + 64 * G + 32 * b + i;
+                    const float bv = bias[col];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        float v = __builtin_ldexpf(acc[a][2 * G + b][r], ex[r]) + bv;
+                        if (relu) v = v < 0.f ? 0.f : v;
+                        if (decltype(full)::value || row < M) C[(size_t)row * N + col] = v;
+                    }
+                }
+            }
+        };
+        if (m0 + BM <= M) store_tile(std::true_type{});
+        else store_tile(std::false_type{});
+    };
+    if (grp == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
+}
+
 hipError_t init_fc_gemm_h2()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * H2_TILE);
 }
+
+int fc_gemm_h2_pad_rows() { return H2_BM; }                       // rows the A operand's buffer holds beyond M (read by ragged tiles, never used)
 
 // 256 x 128 tiles must fill the chip (as the phased fp32 kernel asks of its large tile)
 bool fc_gemm_h2_ok(int64_t M, int N, int K)
@@ -243,6 +423,12 @@ hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, con
     const int sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
+    // (the K-split form reads whole tiles of A rows: the caller's buffer is padded by H2_BM rows -- fc_gemm_h2_pad_rows)
+    if (tune().h2_ksplit && (K / H2_KT) % 2 == 0 && K / H2_KT >= 4) {
+        plan_note("fc_h2k_256x128");
+        hipLaunchKernelGGL(fc_gemm_h2k_kernel, dim3(grid), dim3(512), 3 * H2_TILE, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+        return hipGetLastError();
+    }
     plan_note("fc_h2_256x128");
     hipLaunchKernelGGL(fc_gemm_h2_kernel, dim3(grid), dim3(512), H2_LDS, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
     return hipGetLastError();

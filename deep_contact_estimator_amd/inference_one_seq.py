@@ -41,9 +41,10 @@ def main(argv=None):
                         default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "config",
                                              "inference_one_seq_params.yaml"))
     parser.add_argument("--fused", action="store_true", help="one fused pass instead of the batch loop")
-    parser.add_argument("--precision", default=None, choices=["fp32", "bf16_fc", "fp32_split"],
+    parser.add_argument("--precision", default=None, choices=["fp32", "bf16_fc", "fp32_split", "fp32_f16x2"],
                         help="arithmetic of the library (default fp32 = the reference's; the YAML may carry a `precision` key too): "
-                             "bf16_fc = bf16 operands on fc.0 / fc.3; fp32_split = fp32 results on the bf16 matrix pipe (DESIGN.md 4.1x / 4.2x)")
+                             "bf16_fc = bf16 operands on fc.0 / fc.3; fp32_split = fp32 results on the bf16 matrix pipe (DESIGN.md 4.1x / 4.2x); "
+                             "fp32_f16x2 = the fp32 tolerance from two fp16 terms per operand with per-window scales (DESIGN.md 4.6)")
     args = parser.parse_args(argv)
     config = yaml.safe_load(open(args.config_name))
 

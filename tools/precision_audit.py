@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Precision audit (run on the GPU box): three fp32 evaluations of the path -- the reference's own arithmetic (PyTorch-CPU fp32,
 oracle/torch_ref.py), DCE_FP32 (exact fp32 MFMA, one fmaf chain per output) and DCE_FP32_SPLIT (fp32 operands as three bf16 terms on
-the bf16 matrix pipe) -- each against the fp64-accumulating oracle, as err / bound with bound = 1e-5 max|ref| + 1e-4 |ref| (the
+the bf16 matrix pipe) -- and a fourth that claims the fp32 TOLERANCE, not fp32 operands: DCE_FP32_F16X2 (two fp16 terms of the operand times
+a power of two chosen per window and layer, three MFMAs per product) -- each against the fp64-accumulating oracle, as err / bound with bound = 1e-5 max|ref| + 1e-4 |ref| (the
 contract of BASELINE.json's "logits within a stated fp32 tolerance"; reference src/contact_cnn.py:60-66, utils/data_handler.py:55-56).
 
 Sets: 1e6 N(0,1) windows and 200k AR(1) windows through the z-score entry (logits of every window); per-layer taps (features,
@@ -66,7 +67,7 @@ def models(sd, max_batch=32768, unguarded=False):
     """fp32, fp32_split (with its range guard: the default) and -- for the adversarial window sets -- fp32_split with the guard switched
     off (option split_guard=0: round 4's behaviour, the rows that show what the guard is for)."""
     ms = {}
-    for name, p, tune in (("fp32", "fp32", None), ("fp32_split", "fp32_split", None)) + ((("fp32_split_unguarded", "fp32_split", {"split_guard": 0}),) if unguarded else ()):
+    for name, p, tune in (("fp32", "fp32", None), ("fp32_split", "fp32_split", None), ("fp32_f16x2", "fp32_f16x2", None)) + ((("fp32_split_unguarded", "fp32_split", {"split_guard": 0}),) if unguarded else ()):
         ms[name] = contact_cnn(device=0, max_batch=max_batch, precision=p, tune=tune)
         ms[name].load_state_dict(sd).eval()
     return ms
@@ -103,6 +104,11 @@ def audit_sequence(name, sd, seq, taps_n=4096):
         t = m.forward_taps(zw)
         e["layers"] = {k: stats(t[k], ref_t[k]) for k in ("feat", "h1", "h2", "logits")}
         e["layers_plan"] = m.last_plan()
+        if p == "fp32_f16x2":                                  # the two-term fp16 conv stack itself, layer by layer
+            ct = m.conv_layer_taps(zw[:64], "h2")
+            lt = [o.layer_taps(w) for w in zw[:8]]
+            e["conv_h2_layers_8_windows"] = {k: stats(ct[k][:8], np.stack([t[k] for t in lt])) for k in ("conv1", "conv2", "pool1", "conv3", "conv4")}
+            e["conv_h2_layers_8_windows"]["feat_64_windows"] = stats(ct["feat"], ref_t["feat"][:64])
         if p == "fp32_split":                                  # the three-term conv stack itself, layer by layer (the tap takes <= 64 windows)
             ct = m.conv_layer_taps(zw[:64], "x3")
             lt = [o.layer_taps(w) for w in zw[:8]]
@@ -187,7 +193,12 @@ def main():
         ev = s["evaluations"]
         t, sp = ev["pytorch_cpu_fp32"]["logits"]["max"], ev["dce_fp32_split"]["logits"]["max"]
         ung = ev.get("dce_fp32_split_unguarded")
+        h2 = ev["dce_fp32_f16x2"]
         verdict[name] = {"pytorch_cpu": t, "dce_fp32": ev["dce_fp32"]["logits"]["max"], "dce_fp32_split": sp,
+                         "dce_fp32_f16x2": h2["logits"]["max"], "f16x2_plan": h2.get("plan") or h2.get("plan_of_last_launch"),
+                         "f16x2_nonfinite_mismatches": h2["logits"]["nonfinite_mismatches"],
+                         "f16x2_within_the_contract": h2["logits"]["max"] is not None and h2["logits"]["max"] <= 1.0 and h2["logits"]["nonfinite_mismatches"] == 0,
+                         "f16x2_above_margin_argmax_differences": h2["argmax"]["above_noise_margin"],
                          "dce_fp32_split_unguarded": ung["logits"]["max"] if ung else None,
                          "split_plan": ev["dce_fp32_split"].get("plan") or ev["dce_fp32_split"].get("plan_of_last_launch"),
                          "split_nonfinite_mismatches": ev["dce_fp32_split"]["logits"]["nonfinite_mismatches"], "fp32_nonfinite_mismatches": ev["dce_fp32"]["logits"]["nonfinite_mismatches"],
