@@ -36,6 +36,7 @@
 
 namespace dce {
 
+constexpr int H2_SMAX = 180;                                       // scale exponents live in [-114, 180]: 2^127 .. 2^-149 are brought to [2^14, 2^15) (subnormals: to below it)
 typedef _Float16 hx_f16x2 __attribute__((ext_vector_type(2)));
 typedef float hx_f32x2 __attribute__((ext_vector_type(2)));
 
@@ -49,11 +50,11 @@ int h2_weight_shift(const float* w, size_t n)
         m = std::fmax(m, std::fabs(w[i]));
     }
     if (m == 0.f) return 0;
-    int sw = 14 - std::ilogb(m);
-    return sw > 100 ? 100 : sw;                                        // (>= 14 - 127: the largest fp32 weights are scaled DOWN into fp16's range)
+    return 14 - std::ilogb(m);                                         // -113 (the largest fp32 weights are scaled DOWN into fp16's range) .. 163 (fp32 subnormals: ldexp is exact)
 }
 
-// the largest scale exponent a layer's INPUT may carry: bias * 2^(S + sw) stays below 2^60, S + sw below 100
+// the largest scale exponent a layer's INPUT may carry: bias * 2^(S + sw) stays below 2^60 (nothing else bounds it: the exponents are integers
+// that only ever enter v_ldexp_f32; H2_SMAX covers fp32's smallest subnormal)
 int h2_input_smax(const float* bias, size_t n, int sw)
 {
     float m = 0.f;
@@ -61,7 +62,7 @@ int h2_input_smax(const float* bias, size_t n, int sw)
         if (!std::isfinite(bias[i])) return INT_MIN;
         m = std::fmax(m, std::fabs(bias[i]));
     }
-    int s = 100 - sw;
+    int s = H2_SMAX;
     if (m > 0.f) s = std::min(s, 60 - sw - (std::ilogb(m) + 1));
     return s < -114 ? -114 : s;
 }
@@ -144,6 +145,22 @@ __device__ __forceinline__ void hx_split2(float v0, float v1, unsigned (&p)[2])
     p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hx_f32x2{r0, r1}, hx_f16x2));
 }
 
+// ... of two values times the power of two sc (wave-uniform, an SGPR): v_fma_mixlo/hi_f16 multiply and round to fp16 in one instruction (the
+// product with a power of two is exact, so this is the one rounding of v_cvt_pk_f16_f32), v_fma_mix_f32 forms v * sc - h1 with the fp16
+// term read in place (exact): five instructions per pair where ldexp + convert + convert back + subtract + convert take eight
+__device__ __forceinline__ void hx_split2s(float v0, float v1, float sc, unsigned (&p)[2])
+{
+    unsigned h;
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(v0), "s"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(v1), "s"(sc));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v0), "s"(sc), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v1), "s"(sc), "v"(h));
+    p[0] = h;
+    p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hx_f32x2{r0, r1}, hx_f16x2));
+}
+__device__ __forceinline__ float hx_pow2(int t) { return __builtin_bit_cast(float, (unsigned)(127 + t) << 23); }      // -126 <= t <= 127
+
 // a wave's largest output of a layer (after ReLU; the pool cannot raise it), columns t < T only, -> one LDS atomic
 template <int T>
 __device__ __forceinline__ void hx_layer_max(const cx_f32x4 (&acc)[2][CX_NT], int ct0, int j, int lane, unsigned* word)
@@ -171,6 +188,7 @@ template <int ROWB_OUT, bool POOL, int T, bool TAPS = false>
 __device__ __forceinline__ void hx_store(char* __restrict__ lds, const cx_f32x4 (&acc)[2][CX_NT], int co0, int ct0, int j, int g, int shift,
                                          float* __restrict__ tap = nullptr, float* __restrict__ tap_pool = nullptr, int unscale = 0)
 {
+    const float sc = hx_pow2(shift);                                   // (next_shift keeps |shift| <= 126)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const int co = co0 + 16 * rt + 4 * g;
@@ -192,11 +210,9 @@ __device__ __forceinline__ void hx_store(char* __restrict__ lds, const cx_f32x4 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tap_pool[(size_t)(co + r) * (T / 2) + (t >> 1)] = __builtin_ldexpf(v[r], unscale);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = __builtin_ldexpf(v[r], shift);
             unsigned lo[2], hi[2];
-            hx_split2(v[0], v[1], lo);
-            hx_split2(v[2], v[3], hi);
+            hx_split2s(v[0], v[1], sc, lo);
+            hx_split2s(v[2], v[3], sc, hi);
             if (ok) {
                 char* d = lds + cx_addr<ROWB_OUT>(row, co);
 #pragma unroll
@@ -328,9 +344,10 @@ void conv_h2_kernel(const float* __restrict__ src, int64_t n, ConvPackH2 pk, uns
     auto next_shift = [&](int l) {
         const unsigned m = __builtin_amdgcn_readfirstlane(hx_max[l]);
         const int e = S + pk.sw[l];                                    // the accumulators' scale exponent
-        const int Sn = hx_clamp(e + hx_shift(m), pk.smax[l + 1]);
-        S = Sn;
-        return Sn - e;
+        int t = hx_clamp(e + hx_shift(m), pk.smax[l + 1]) - e;
+        t = t > 126 ? 126 : t < -126 ? -126 : t;                       // the multiplier 2^t is a float (beyond: a layer whose largest output is below 2^-112 of its products' scale -- any scale serves it)
+        S = e + t;
+        return t;
     };
 
     // ---- stage 1 (T = 150, 64 channels in and out): wave = row-tile pair wv & 1, column tiles 5 (wv >> 1) ..
@@ -412,9 +429,17 @@ void conv_h2_kernel(const float* __restrict__ src, int64_t n, ConvPackH2 pk, uns
         // ---- conv4 + ReLU + MaxPool (t = 74 dropped) straight from the accumulators to HBM in the K order k' = t' * 128 + c: a lane holds four
         //      consecutive channels of one pooled position = 8 bytes per term; a row's K-tile of 32 is one 128-byte line [term 1 | term 2]
         const int e4 = S + pk.sw[3];                                   // conv4's accumulators carry 2^e4
-        const int shift = next_shift(3);                               // (S is now the features' scale exponent)
+        const float scf = hx_pow2(next_shift(3));                      // (S is now the features' scale exponent)
         if (tid == 0) feat_scale[win] = window_bad ? 0 : S;
         unsigned short* const out = feat2 + (size_t)win * (2 * FEAT);
+        if (window_bad) {                                              // (wave-uniform) a non-finite sample: NaN in every term of the window's features
+            for (int q = tid; q < 2 * FEAT / 8; q += 256) reinterpret_cast<uint4*>(out)[q] = make_uint4(0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u);
+            if constexpr (TAPS) {
+                for (int q = tid; q < FEAT; q += 256) feat32[(size_t)win * FEAT + q] = __builtin_nanf("");
+            }
+            TRACE_MARK(9);
+            return;
+        }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int co = 32 * wv + 16 * rt + 4 * g;
@@ -432,12 +457,11 @@ void conv_h2_kernel(const float* __restrict__ src, int64_t n, ConvPackH2 pk, uns
                 if constexpr (TAPS) {
                     if ((j & 1) == 0 && (t >> 1) < 37)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) feat32[(size_t)win * FEAT + (co + r) * 37 + (t >> 1)] = window_bad ? __builtin_nanf("") : __builtin_ldexpf(q[r], -e4);
+                        for (int r = 0; r < 4; ++r) feat32[(size_t)win * FEAT + (co + r) * 37 + (t >> 1)] = __builtin_ldexpf(q[r], -e4);
                 }
                 unsigned lo[2], hi[2];
-                hx_split2(__builtin_ldexpf(q[0], shift), __builtin_ldexpf(q[1], shift), lo);
-                hx_split2(__builtin_ldexpf(q[2], shift), __builtin_ldexpf(q[3], shift), hi);
-                if (window_bad) lo[0] = lo[1] = hi[0] = hi[1] = 0x7e007e00u;          // a non-finite sample: NaN in every term of the window's features
+                hx_split2s(q[0], q[1], scf, lo);
+                hx_split2s(q[2], q[3], scf, hi);
                 if ((j & 1) == 0 && (t >> 1) < 37) {
                     const int k = (t >> 1) * 128 + co;
 #pragma unroll

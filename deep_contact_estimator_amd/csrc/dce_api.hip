@@ -64,9 +64,9 @@ const TuneKey kTuneKeys[] = {
     TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
     TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'),
     TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
-    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_ksplit, 'b'),
+    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'),
     TKX(bf16_k32, 'b'), TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
-    TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
+    TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(h2_ksplit, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
 };
 #undef TK
 #undef TKX
@@ -914,7 +914,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         if (!h2_bad) { h2_fc_sw = h2_weight_shift(c->host_w[8].data(), c->host_w[8].size()); h2_bad = h2_fc_sw == INT_MIN; }
         for (int k = 9; k < 14; ++k)
             for (float x : c->host_w[k]) h2_bad |= !std::isfinite(x);
-        h2pk.smax[4] = 100 - (h2_bad ? 0 : h2_fc_sw);                 // the features: fc.0's bias is added after the scales are taken off
+        h2pk.smax[4] = 180;                                           // the features: fc.0's bias is added after the scales are taken off (conv_h2.hip H2_SMAX)
         if (!h2_bad) {
             for (int l = 0; l < 4; ++l) {
                 off_h2[l] = reserve((conv_h2_pack_halfs(l) + 1) / 2);

@@ -54,8 +54,6 @@ struct Tuning {
     bool x3_unfused = false;                                // 1: fp32 features + split3 kernel instead of the conv kernel's three-plane output
     bool x3_permk = true;                                   // 0: conv_x3.hip's features through LDS in the reference's flatten order instead of straight out in the order t' * 128 + c
     bool x3_fc3 = false;                                    // 1: fc.3 on three-term operands too (fc_gemm_x3.hip's 128 x 64 tile with the fused fc.6 epilogue; h1 leaves fc.0 as three planes).  Built and parity-green in round 5, and NOT faster: 64.3 us against 71 for the fp32 MFMA kernel, +9.5 us on fc.0's epilogue (profiles/r5j_split_fc3.txt) -- with 32 x 32 wave tiles a K-tile's LDS traffic is fc.0's for half its MFMAs
-    // -- DCE_FP32_F16X2
-    bool h2_ksplit = false;                                 // 1: fc.0's K-tiles dealt out between the two wave groups (fc_gemm_h2k_kernel: 64 x 128 wave tiles, 48-MFMA phases, three LDS buffers)
     bool split_guard = true;                                // 0: no range guard (static bound at finalize, per-window exponent check + fp32 fallback): the round-4 behaviour, for the A/B and the audit
     // -- experiments build only (ignored by the product library)
     bool gemm_lockstep = false, gemm_pipe = false, gemm_ki = false;
@@ -64,6 +62,7 @@ struct Tuning {
     bool x3_persist = false, x3_pair = false;
     long long x3_persist_min = 1024, x3_pair_min = 1024;
     bool conv_direct = false;                               // the direct-form conv stack of round 1 (conv_stack.hip)
+    bool h2_ksplit = false;                                 // DCE_FP32_F16X2: fc.0's K-tiles dealt out between the two wave groups (fc_gemm_h2k_kernel: 64 x 128 wave tiles, 48-MFMA phases, three LDS buffers; round 5: measured 5 % slower)
     bool one_per_cu = false, trace_wino1 = false;           // trace builds
 };
 // parses "key=value,..." over `t`; false + message on an unknown key or a malformed value

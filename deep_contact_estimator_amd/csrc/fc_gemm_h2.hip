@@ -219,7 +219,11 @@ void fc_gemm_h2_kernel(const unsigned short* __restrict__ A2, const int* __restr
 }
 
 
-// ---- the same GEMM with the K-TILES dealt out between the two wave groups (option h2_ksplit): a wave owns 64 x 128 of the tile -- 2 x 4 blocks,
+
+#if DCE_EXPERIMENTS
+// ---- (experiments build, option h2_ksplit=1; measured 5 % SLOWER than the N-split kernel above: 203.7 against 194.1 us per 4096 windows by HIP
+// events, 214.5 against 203.8 under the tracer, profiles/r5q_f16x2_ksplit_ab.txt -- fewer, longer phases and a quarter less LDS traffic do not
+// buy time on a kernel that runs at the clock the board grants it) the same GEMM with the K-TILES dealt out between the two wave groups: a wave owns 64 x 128 of the tile -- 2 x 4 blocks,
 // 128 accumulator registers -- for every OTHER K-tile, so a phase is 48 MFMAs against 24 fragment reads per wave (0.5 per MFMA; the N-split form
 // above: 24 against 16, 0.67, and a load phase as long as the math phase beside it), and a K-tile's fragments are read by four waves instead of
 // eight (96 KB of LDS reads per 48 KB tile instead of 128).  Three buffers: tile p + 2 is issued by the group that loads tile p, in phase p, and
@@ -393,12 +397,16 @@ void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __rest
     if (grp == 0) finish(std::integral_constant<int, 0>{});
     else finish(std::integral_constant<int, 1>{});
 }
+#endif
 
 hipError_t init_fc_gemm_h2()
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS);
+#if DCE_EXPERIMENTS
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * H2_TILE);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * H2_TILE);
+#endif
+    return e;
 }
 
 int fc_gemm_h2_pad_rows() { return H2_BM; }                       // rows the A operand's buffer holds beyond M (read by ragged tiles, never used)
@@ -423,12 +431,14 @@ hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, con
     const int sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
+#if DCE_EXPERIMENTS
     // (the K-split form reads whole tiles of A rows: the caller's buffer is padded by H2_BM rows -- fc_gemm_h2_pad_rows)
     if (tune().h2_ksplit && (K / H2_KT) % 2 == 0 && K / H2_KT >= 4) {
         plan_note("fc_h2k_256x128");
         hipLaunchKernelGGL(fc_gemm_h2k_kernel, dim3(grid), dim3(512), 3 * H2_TILE, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
         return hipGetLastError();
     }
+#endif
     plan_note("fc_h2_256x128");
     hipLaunchKernelGGL(fc_gemm_h2_kernel, dim3(grid), dim3(512), H2_LDS, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
     return hipGetLastError();

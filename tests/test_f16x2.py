@@ -42,5 +42,5 @@ def test_degenerate_tensors():
     assert sw == -2 ** 31
     sw, t = _split(np.array([3.0e38, -1.0], np.float32))   # the largest weights: scaled DOWN into fp16's range
     assert 2.0 ** 14 <= 3.0e38 * 2.0 ** sw < 2.0 ** 15 and np.isfinite(t).all()
-    sw, t = _split(np.array([1e-44, 1e-45], np.float32))   # fp32 subnormals: the exponent is held at 100
-    assert sw == 100 and np.isfinite(t).all()
+    sw, t = _split(np.array([1e-44, 1e-45], np.float32))   # fp32 subnormals: scaled UP into fp16's range (ldexp is exact)
+    assert sw == 161 and np.isfinite(t).all() and 2.0 ** 14 <= t[0][0] < 2.0 ** 15

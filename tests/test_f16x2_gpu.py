@@ -190,6 +190,48 @@ def test_input_scale_sweep(e, orc):
     m.close()
 
 
+@pytest.mark.parametrize("e", [-100, -118])
+def test_audit_set_inputs_and_conv1_bias_scaled_down_conv2_weights_up(e, orc):
+    """tools/precision_audit.py's `inputs_x_2^e` sets: windows x 2^e, conv1's bias with them, conv2's weights x 2^-e -- conv1's activations sit at
+    2^e, conv2's weights at 2^-e: the scale exponents of the input (14 - e) and of conv2's weights leave any 'comfortable' range (the first
+    build capped S + sw at 100 and lost these sets by four orders of magnitude: profiles/r5p_precision_audit.json)."""
+    from deep_contact_estimator_amd import synth
+    sd = {k: v.copy() for k, v in synth.make_state_dict(1, "uniform").items()}
+    sd["block1.0.bias"] = (sd["block1.0.bias"] * np.float32(2.0 ** e)).astype(np.float32)
+    sd["block1.2.weight"] = (sd["block1.2.weight"] * np.float32(2.0 ** -e)).astype(np.float32)
+    x = (np.random.default_rng(2026).standard_normal((N0, 150, 54), dtype=np.float32) * np.float32(2.0 ** e)).astype(np.float32)
+    m = _model(sd, N0)
+    out = m.predict(x)
+    assert _is_h2(m.last_plan()), m.last_plan()
+    rows = np.r_[0:128, N0 - 128:N0]
+    ref = orc.Oracle(sd).forward_windows(x[rows])
+    assert np.isfinite(ref["logits"]).all()
+    tol_ok(out["logits"][rows], ref["logits"], f"audit set inputs x 2^{e}")
+    _argmax_ok(out["pred"][rows], ref["logits"], ref["pred"])
+    m.close()
+
+
+def test_audit_set_inputs_in_the_top_binade(orc):
+    """tools/precision_audit.py's `inputs_in_the_top_binade`: windows x 3e37 with samples at +-3.395e38 (above bf16's largest finite number, 2^128
+    within a hair), conv1's weights x 3.3e-39 -- fp32 SUBNORMALS, which the host scales up exactly (sw = 14 + 131)."""
+    from deep_contact_estimator_amd import synth
+    sd = {k: v.copy() for k, v in synth.make_state_dict(1, "uniform").items()}
+    sd["block1.0.weight"] = (sd["block1.0.weight"] * 1e-38 / 3.0).astype(np.float32)
+    rng = np.random.default_rng(2027)
+    x = (rng.standard_normal((N0, 150, 54), dtype=np.float32) * np.float32(3.0e37)).astype(np.float32)
+    idx = rng.integers(0, x.size, 2000)
+    x.reshape(-1)[idx] = np.float32(3.395e38) * np.sign(x.reshape(-1)[idx])
+    m = _model(sd, N0)
+    out = m.predict(x)
+    assert _is_h2(m.last_plan()), m.last_plan()
+    rows = np.r_[0:128, N0 - 128:N0]
+    ref = orc.Oracle(sd).forward_windows(x[rows])
+    assert np.isfinite(ref["logits"]).all()
+    tol_ok(out["logits"][rows], ref["logits"], "audit set: top binade")
+    _argmax_ok(out["pred"][rows], ref["logits"], ref["pred"])
+    m.close()
+
+
 @pytest.mark.parametrize("kind", ["alternating_1e3", "alternating_1e-3", "tiny_weights_large_bias", "large_bias_everywhere", "zero_bias", "mixed_window_scales"])
 def test_checkpoint_and_window_scale_sweep(kind, orc):
     """Checkpoints whose layers swing the activations over many decades, biases far above / below the products, and windows of very different
@@ -239,9 +281,10 @@ def test_non_finite_checkpoint_runs_the_fp32_kernels(pair):
     m.close(); a.close()
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("n", [3072, 4100, 8192])
 def test_fc0_with_the_k_tiles_dealt_out_between_the_wave_groups(n, pair, orc):
-    """Option h2_ksplit (fc_gemm_h2k_kernel: 64 x 128 wave tiles, each wave group every other K-tile, three LDS buffers, the groups' sums added
+    """(experiments build: measured 5 % slower than the N-split kernel.)  Option h2_ksplit (fc_gemm_h2k_kernel: 64 x 128 wave tiles, each wave group every other K-tile, three LDS buffers, the groups' sums added
     at the end): another association of the same fp32 accumulation -- the contract against the oracle, a ragged last tile (4100: it reads
     the padding rows of the feature buffer), and fp32 rounding away from the N-split kernel's result."""
     from deep_contact_estimator_amd import synth
