@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the fp32_split and bf16_fc precisions (run on the GPU box): 10,000 bench-sized steps each, checked for bit
+"""Soak of the fp32_split and bf16_fc precisions -- or of the precisions named on the command line (fp32_f16x2) -- (run on the GPU box): 10,000 bench-sized steps each, checked for bit
 stability against the first; 1e6-window streaming calls repeated; 200 context create / use / destroy cycles per precision
 checked for device-memory leaks (the modes own extra buffers: three-plane features, split weights)."""
 import os, sys, time, json
@@ -10,7 +10,7 @@ from deep_contact_estimator_amd import contact_cnn, synth
 res = {}
 sd = synth.make_state_dict(1, "uniform")
 seq = torch.from_numpy(synth.make_sequence(4096 + 149, 5).astype(np.float32)).cuda()
-for prec in ("fp32_split", "bf16_fc"):
+for prec in (sys.argv[1:] or ("fp32_split", "bf16_fc")):
     free0 = torch.cuda.mem_get_info()[0]
     m = contact_cnn(device=0, max_batch=4096, precision=prec); m.load_state_dict(sd)
     x = m.zscore_windows(seq)
