@@ -64,7 +64,7 @@ const TuneKey kTuneKeys[] = {
     TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
     TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'),
     TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
-    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'),
+    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_fc3, 'b'),
     TKX(bf16_k32, 'b'), TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
     TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(h2_ksplit, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
 };
@@ -338,7 +338,7 @@ struct GateScope {
 //                 >= 2817                        conv_h2 -> two fp16 terms + scale fc_h2_256x128             = DCE_FP32
 enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16, H2, H2F32 };
 enum class Fc0 { F32, Gemv, X3, Bf16, H2 };
-enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16 };
+enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16, FusedH2 };
 struct Plan {
     Conv conv; int permk;                 // permk: features (and fc.0's weights) in the K order t' * 128 + c; 2: from persistent workgroups (experiments)
     Fc0 fc0; bool split3;                 // split3: fp32 features split by a kernel of their own in front of fc_gemm_x3 (taps, x3_unfused)
@@ -393,6 +393,7 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
         // (same bits, rows are independent) instead of paying a full round for it.
         const int64_t rest = n % 4096;
         p.fc3 = (x3 && !c->want_h1 && c->fc2w_x3 && c->h1p && fc23_x3_ok(n)) ? Fc3::FusedX3 : Fc3::Fused;      // fc.3 on three-term operands too (h1 then leaves fc.0 as three planes)
+        if (h2 && tu.h2_fc3 && !c->want_h1 && c->fc2w_h2 && c->h1h && fc23_h2_ok(n)) p.fc3 = Fc3::FusedH2;     // DCE_FP32_F16X2: fc.3 on two-term fp16 operands (h1 leaves fc.0 as two fp16 terms + row scales)
         const bool cut = p.fc3 == Fc3::Fused && tu.gemm_peel && !c->gate_on && n > 4096 && rest && (rest <= 8 || fc_split_ok(rest, FC2, FC1) || fc_gemm_chain_ok(rest, FC2, FC1));
         p.fused_rows = cut ? n - rest : n;
     }
@@ -455,7 +456,10 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
           else HIP_TRY(c, launch_fc_gemm_x3(c->feat3, p.permk ? c->fc1w_x3p : c->fc1w_x3, c->fc1b, c->h1, n, FC1, FEAT, 1, st));
           break;
       case Fc0::Bf16: HIP_TRY(c, launch_fc_gemm_bf16(c->feat, p.permk ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, st)); break;
-      case Fc0::H2:   HIP_TRY(c, launch_fc_gemm_h2(c->feat3, c->feat_scale, c->fc1w_h2, c->fc1_sw, c->fc1b, c->h1, n, FC1, FEAT, 1, st)); break;
+      case Fc0::H2:
+          if (p.fc3 == Fc3::FusedH2) HIP_TRY(c, launch_fc_gemm_h2(c->feat3, c->feat_scale, c->fc1w_h2, c->fc1_sw, c->fc1b, c->h1, n, FC1, FEAT, 1, st, c->h1h, c->h1_scale, c->fc1_eW, c->fc1_eB));
+          else HIP_TRY(c, launch_fc_gemm_h2(c->feat3, c->feat_scale, c->fc1w_h2, c->fc1_sw, c->fc1b, c->h1, n, FC1, FEAT, 1, st));
+          break;
       } }
     const int64_t nf = p.fused_rows;
     { Timer t(c, 2);
@@ -464,6 +468,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
       case Fc3::Gemv: HIP_TRY(c, launch_fc_gemv(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, st)); break;
       case Fc3::Bf16: HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, st)); break;
       case Fc3::FusedX3: HIP_TRY(c, launch_fc23_fused_x3(c->h1p, c->fc2w_x3, c->fc2b, c->fc3w, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
+      case Fc3::FusedH2: HIP_TRY(c, launch_fc23_fused_h2(c->h1h, c->h1_scale, c->fc2w_h2, c->fc2_sw, c->fc2b, c->fc3w, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
       case Fc3::FusedBf16: HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
       case Fc3::Fused:
           HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, nf, st));
@@ -471,7 +476,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
           break;
       } }
     { Timer t(c, 3);
-      if (p.fc3 == Fc3::Fused || p.fc3 == Fc3::FusedX3 || p.fc3 == Fc3::FusedBf16) {
+      if (p.fc3 == Fc3::Fused || p.fc3 == Fc3::FusedX3 || p.fc3 == Fc3::FusedBf16 || p.fc3 == Fc3::FusedH2) {
           HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, st, packed));
           if (nf < n) HIP_TRY(c, launch_fc3_tail(c->h2 + nf * FC2, c->fc3w, c->fc3b, n - nf, logits ? logits + nf * NCLS : nullptr, pred ? pred + nf : nullptr,
                                                  contacts ? contacts + nf * 4 : nullptr, st, nullptr, 0, nullptr, packed ? packed + nf * PACKED_ROW : nullptr));
@@ -769,7 +774,7 @@ void dce_destroy(dce_ctx* c)
     if (c->xfer_stream) { hipStreamSynchronize(c->xfer_stream); hipStreamDestroy(c->xfer_stream); }
     for (auto& slot : c->ring_ev) for (auto e : slot) if (e) hipEventDestroy(e);
     hipFree(c->d_weights); hipFree(c->feat); hipFree(c->feat3); hipFree(c->h1); hipFree(c->h2); hipFree(c->part);
-    hipFree(c->feat_scale); hipFree(c->d_guard); hipFree(c->fc1w_x3_own); hipFree(c->h1p); hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
+    hipFree(c->feat_scale); hipFree(c->h1h); hipFree(c->h1_scale); hipFree(c->d_guard); hipFree(c->fc1w_x3_own); hipFree(c->h1p); hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
     if (c->online_exec) hipGraphExecDestroy(c->online_exec);
     if (c->online_graph) hipGraphDestroy(c->online_graph);
     hipFree(c->d_ring); hipFree(c->d_online_state);
@@ -900,9 +905,9 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         }
     }
     // DCE_FP32_F16X2: conv1..4 and fc.0 as two fp16 terms of w * 2^sw (conv_h2.hip has the arithmetic); a non-finite weight or bias refuses the precision
-    size_t off_h2[4] = {0, 0, 0, 0}, off_h2fc = 0;
+    size_t off_h2[4] = {0, 0, 0, 0}, off_h2fc = 0, off_h2fc2 = 0;
     ConvPackH2 h2pk{};
-    int h2_fc_sw = 0;
+    int h2_fc_sw = 0, h2_fc2_sw = 0, h2_eW = 0, h2_eB = 0;
     bool h2_bad = false;
     if (precision == DCE_FP32_F16X2) {
         for (int l = 0; l < 4 && !h2_bad; ++l) {
@@ -922,6 +927,25 @@ int dce_finalize_weights(dce_ctx* c, int precision)
             }
             off_h2fc = reserve(w1p.size());                           // two halfs per weight
             fc_h2_pack_host(w1p.data(), FC1, FEAT, h2_fc_sw, reinterpret_cast<unsigned short*>(img.data() + off_h2fc));
+            if (c->tuning.h2_fc3) {                                   // fc.3 on two-term operands: its weights likewise; h1's row-scale bound |h1| <= sqrt(K) max|feat| max_n ||W1_n||_2 + max|b1|
+                h2_fc2_sw = h2_weight_shift(c->host_w[10].data(), c->host_w[10].size());
+                off_h2fc2 = reserve(c->host_w[10].size());
+                fc_h2_pack_host(c->host_w[10].data(), FC2, FC1, h2_fc2_sw, reinterpret_cast<unsigned short*>(img.data() + off_h2fc2));
+                double wn = 0.0;
+                for (int r = 0; r < FC1; ++r) {
+                    double q = 0.0;
+                    for (int k = 0; k < FEAT; ++k) { const double x = c->host_w[8][(size_t)r * FEAT + k]; q += x * x; }
+                    wn = std::max(wn, q);
+                }
+                const double cw = std::sqrt((double)FEAT) * std::sqrt(wn);
+                float bm = 0.f;
+                for (float x : c->host_w[9]) bm = std::fmax(bm, std::fabs(x));
+                h2_eW = cw > 0.0 ? std::ilogb(cw) + 1 : -300;
+                h2_eB = bm > 0.f ? std::ilogb(bm) + 1 : -300;
+                const size_t rows = (size_t)c->max_batch + fc_gemm_h2_pad_rows();
+                if (!c->h1h) { HIP_TRY(c, hipMalloc(&c->h1h, rows * FC1 * 2 * sizeof(unsigned short))); HIP_TRY(c, hipMemset(c->h1h, 0, rows * FC1 * 2 * sizeof(unsigned short))); }
+                if (!c->h1_scale) { HIP_TRY(c, hipMalloc(&c->h1_scale, rows * sizeof(int))); HIP_TRY(c, hipMemset(c->h1_scale, 0, rows * sizeof(int))); }
+            }
             if (!c->feat3) {                                          // two fp16 terms per feature, padded by a tile of rows (fc_gemm_h2_pad_rows)
                 const size_t halfs = std::max((size_t)(c->max_batch + 1) * FEAT * 3, (size_t)(c->max_batch + fc_gemm_h2_pad_rows()) * FEAT * 2);
                 HIP_TRY(c, hipMalloc(&c->feat3, halfs * sizeof(unsigned short)));
@@ -959,6 +983,8 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     }
     c->fc1w_h2 = precision == DCE_FP32_F16X2 && !h2_bad ? reinterpret_cast<const unsigned short*>(c->d_weights + off_h2fc) : nullptr;
     c->fc1_sw = h2_fc_sw;
+    c->fc2w_h2 = precision == DCE_FP32_F16X2 && !h2_bad && c->tuning.h2_fc3 ? reinterpret_cast<const unsigned short*>(c->d_weights + off_h2fc2) : nullptr;
+    c->fc2_sw = h2_fc2_sw; c->fc1_eW = h2_eW; c->fc1_eB = h2_eB;
     c->precision = precision;
     c->guard = dce_ctx::SplitGuard{};
     if (precision == DCE_FP32_SPLIT) compute_split_guard(c);

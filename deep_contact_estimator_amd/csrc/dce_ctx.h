@@ -61,6 +61,10 @@ struct dce_ctx {
     int fc1_sw = 0;
     int* feat_scale = nullptr;                             // ... the scale exponent of every window's features (max_batch)
     bool h2_refused = false;                               // ... a non-finite weight: the precision runs the DCE_FP32 kernels
+    const unsigned short* fc2w_h2 = nullptr;               // ... fc.3's weights [512][64][2][32] fp16 times 2^fc2_sw
+    int fc2_sw = 0, fc1_eW = 0, fc1_eB = 0;                // ... and the two static exponents of h1's row-scale bound (fc_gemm_h2.hip OUT2)
+    unsigned short* h1h = nullptr;                         // ... h1 as two fp16 terms [max_batch + pad][64][2][32] (fc.0's epilogue writes it, fc.3 reads it)
+    int* h1_scale = nullptr;                               // ... with its row scale exponents
     float* part = nullptr;                                 // fc.6 chunk sums [8][max_batch][16] (fused fc.3 epilogue)
     bool want_feat = false;                                // dce_forward_taps: DCE_FP32_SPLIT keeps the fp32 features (split by a kernel of its own)
     bool want_h1 = false;                                  // dce_forward_taps: h1 is wanted in fp32 (DCE_FP32_SPLIT then keeps fc.3 on the fp32 kernels)

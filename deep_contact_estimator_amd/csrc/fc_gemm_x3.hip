@@ -354,13 +354,20 @@ void fc_gemm_x3_kernel(const unsigned short* __restrict__ A3, const unsigned sho
         X3_MARK(0);
         if (!(X3_EXP & 2) || u == 0) load_frags(buf);
         X3_MARK(1);
+        // (sched_barrier, round 5: MFMAs carry no memory dependence, and without it hipcc of ROCm 7.2 moves two thirds of the math phase up between the
+        //  fragment reads of the load phase, across the barrier -- found in the ISA while building fc_gemm_h2.hip, which inherited it; fc_gemm_phased.hip
+        //  has carried the same fence since round 2)
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         // ---- math phase
         X3_MARK(2);
         math(false, 0, 0);
         X3_MARK(3);
+        __builtin_amdgcn_sched_barrier(0);
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #endif
     };
 #pragma unroll 1

@@ -49,7 +49,7 @@ def _argmax_ok(got_pred, ref_logits, ref_pred):
 
 
 def _is_h2(plan):
-    return plan[0] == "conv_h2" and ("fc_h2_256x128" in plan or "fc_h2k_256x128" in plan)
+    return plan[0] == "conv_h2" and any(k in plan for k in ("fc_h2_256x128", "fc_h2_256x128_out2", "fc_h2k_256x128"))
 
 
 @pytest.mark.parametrize("n", [3072, 4096, 4100, 8192])
@@ -289,11 +289,11 @@ def test_fc0_with_the_k_tiles_dealt_out_between_the_wave_groups(n, pair, orc):
     the padding rows of the feature buffer), and fp32 rounding away from the N-split kernel's result."""
     from deep_contact_estimator_amd import synth
     sd, a, b = pair
-    m = _model(sd, 8192, tune={"h2_ksplit": 1})
+    m = _model(sd, 8192, tune={"h2_ksplit": 1, "h2_fc3": 0})
     x = np.random.default_rng(7 + n).standard_normal((n, 150, 54), dtype=np.float32)
     x[n - 1, 5, 5] = np.nan                                  # the last row of a ragged tile
     out, base = m.predict(x), b.predict(x)
-    assert "fc_h2k_256x128" in m.last_plan() and "fc_h2_256x128" in b.last_plan(), (m.last_plan(), b.last_plan())
+    assert "fc_h2k_256x128" in m.last_plan() and _is_h2(b.last_plan()), (m.last_plan(), b.last_plan())
     assert np.isnan(out["logits"][n - 1]).all()
     rows = np.r_[0:160, n - 97:n - 1]
     ref = orc.Oracle(sd).forward_windows(x[rows])
@@ -303,3 +303,28 @@ def test_fc0_with_the_k_tiles_dealt_out_between_the_wave_groups(n, pair, orc):
     again = m.predict(x)
     assert np.array_equal(out["logits"], again["logits"], equal_nan=True)          # deterministic
     m.close()
+
+
+@pytest.mark.parametrize("n", [3072, 4096, 4100, 8192])
+def test_fc3_on_two_term_operands_and_without(n, pair, orc):
+    """fc.3 + fc.6's chunk sums on two-term fp16 operands (the default: h1 leaves fc.0 as two fp16 terms with a row scale from a Cauchy-Schwarz
+    bound, fc_gemm_h2k_kernel<H2KFc3> with the fused fc.6 epilogue) against the option h2_fc3=0 (fp32 h1, the DCE_FP32 kernels behind fc.0):
+    both within the contract of the oracle, fp32 rounding apart; h2 and h1 taps take the fp32 route."""
+    sd, a, b = pair
+    m0 = _model(sd, 8192, tune={"h2_fc3": 0})
+    x = np.random.default_rng(900 + n).standard_normal((n, 150, 54), dtype=np.float32)
+    x[n - 1] *= np.float32(1e-20)                              # a ragged tile's last row, with a scale of its own
+    x[5] *= np.float32(1e15)
+    o1, o0 = b.predict(x), m0.predict(x)
+    assert "fc23_fused_h2_128x64" in b.last_plan() and "fc_h2_256x128_out2" in b.last_plan(), b.last_plan()
+    assert "fc23_fused_h2_128x64" not in m0.last_plan() and "fc_h2_256x128" in m0.last_plan(), m0.last_plan()
+    rows = np.r_[0:160, n - 96:n]
+    ref = orc.Oracle(sd).forward_windows(x[rows])
+    for what, o in (("fc.3 on two-term operands", o1), ("fc.3 on the fp32 kernels", o0)):
+        tol_ok(o["logits"][rows], ref["logits"], f"{what}, {n} windows")
+        _argmax_ok(o["pred"][rows], ref["logits"], ref["pred"])
+    assert np.abs(o1["logits"].astype(np.float64) - o0["logits"]).max() < 2e-5 * np.abs(ref["logits"]).max()
+    t = b.forward_taps(x[:3072])                             # taps: fp32 features / h1 / h2 -> the fp32 route behind conv_h2_f32
+    assert "fc23_fused_h2_128x64" not in b.last_plan(), b.last_plan()
+    tol_ok(t["logits"][:160], ref["logits"][:160], "taps route")
+    m0.close()
