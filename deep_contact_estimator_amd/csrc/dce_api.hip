@@ -338,7 +338,7 @@ struct GateScope {
 //                 >= 2817                        conv_h2 -> two fp16 terms + scale fc_h2_256x128             = DCE_FP32
 enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16, H2, H2F32 };
 enum class Fc0 { F32, Gemv, X3, Bf16, H2 };
-enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16, FusedH2 };
+enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16, FusedH2, H2 };
 struct Plan {
     Conv conv; int permk;                 // permk: features (and fc.0's weights) in the K order t' * 128 + c; 2: from persistent workgroups (experiments)
     Fc0 fc0; bool split3;                 // split3: fp32 features split by a kernel of their own in front of fc_gemm_x3 (taps, x3_unfused)
@@ -396,7 +396,8 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
         if (h2 && tu.h2_fc3 && !c->want_h1 && c->fc2w_h2 && c->h1h && fc23_h2_ok(n)) p.fc3 = Fc3::FusedH2;     // DCE_FP32_F16X2: fc.3 on two-term fp16 operands (h1 leaves fc.0 as two fp16 terms + row scales)
         const bool cut = p.fc3 == Fc3::Fused && tu.gemm_peel && !c->gate_on && n > 4096 && rest && (rest <= 8 || fc_split_ok(rest, FC2, FC1) || fc_gemm_chain_ok(rest, FC2, FC1));
         p.fused_rows = cut ? n - rest : n;
-    }
+    } else if (h2 && tu.h2_fc3 && !c->want_h1 && c->fc2w_h2 && c->h1h && fc_gemm_h2_ok(n, FC2, FC1))
+        p.fc3 = Fc3::H2;                                              // a launch past the fused tile's one round: fc.3 on fc.0's 256 x 128 kernel (h2 in fp32), then the tail
     return p;
 }
 
@@ -457,7 +458,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
           break;
       case Fc0::Bf16: HIP_TRY(c, launch_fc_gemm_bf16(c->feat, p.permk ? c->fc1w_bf16p : c->fc1w_bf16, c->fc1b, c->h1, 1, n, FC1, FEAT, 1, st)); break;
       case Fc0::H2:
-          if (p.fc3 == Fc3::FusedH2) HIP_TRY(c, launch_fc_gemm_h2(c->feat3, c->feat_scale, c->fc1w_h2, c->fc1_sw, c->fc1b, c->h1, n, FC1, FEAT, 1, st, c->h1h, c->h1_scale, c->fc1_eW, c->fc1_eB));
+          if (p.fc3 == Fc3::FusedH2 || p.fc3 == Fc3::H2) HIP_TRY(c, launch_fc_gemm_h2(c->feat3, c->feat_scale, c->fc1w_h2, c->fc1_sw, c->fc1b, c->h1, n, FC1, FEAT, 1, st, c->h1h, c->h1_scale, c->fc1_eW, c->fc1_eB));
           else HIP_TRY(c, launch_fc_gemm_h2(c->feat3, c->feat_scale, c->fc1w_h2, c->fc1_sw, c->fc1b, c->h1, n, FC1, FEAT, 1, st));
           break;
       } }
@@ -468,6 +469,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
       case Fc3::Gemv: HIP_TRY(c, launch_fc_gemv(c->h1, c->fc2w, c->fc2b, c->h2, n, FC2, FC1, 1, st)); break;
       case Fc3::Bf16: HIP_TRY(c, launch_fc_gemm_bf16(c->h1, c->fc2w_bf16, c->fc2b, c->h2, 0, n, FC2, FC1, 1, st)); break;
       case Fc3::FusedX3: HIP_TRY(c, launch_fc23_fused_x3(c->h1p, c->fc2w_x3, c->fc2b, c->fc3w, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
+      case Fc3::H2: HIP_TRY(c, launch_fc_gemm_h2(c->h1h, c->h1_scale, c->fc2w_h2, c->fc2_sw, c->fc2b, c->h2, n, FC2, FC1, 1, st)); break;
       case Fc3::FusedH2: HIP_TRY(c, launch_fc23_fused_h2(c->h1h, c->h1_scale, c->fc2w_h2, c->fc2_sw, c->fc2b, c->fc3w, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
       case Fc3::FusedBf16: HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
       case Fc3::Fused:

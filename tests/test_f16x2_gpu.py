@@ -328,3 +328,22 @@ def test_fc3_on_two_term_operands_and_without(n, pair, orc):
     assert "fc23_fused_h2_128x64" not in b.last_plan(), b.last_plan()
     tol_ok(t["logits"][:160], ref["logits"][:160], "taps route")
     m0.close()
+
+
+def test_fc3_in_launches_past_the_fused_tile(orc):
+    """32768 windows per launch (what the 1e6-window sequence runs): fc.3 on fc.0's 256 x 128 two-term kernel (h2 in fp32) + the tail kernel."""
+    from deep_contact_estimator_amd import synth
+    sd = synth.make_state_dict(1, "uniform")
+    m = _model(sd, 32768)
+    n = 32768 + 5000
+    seq = synth.make_sequence(n + 149, seed=12).astype(np.float32)
+    out = m.infer_sequence(seq[:32768 + 149])
+    plan = m.last_plan()
+    assert plan[0] == "conv_h2" and plan.count("fc_h2_256x128") == 1 and "fc_h2_256x128_out2" in plan and "fc3_tail" in plan, plan
+    rows = np.r_[0:128, 20000:20128, 32768 - 128:32768]
+    ref = orc.Oracle(sd).forward_windows(orc.zscore_windows(seq[:32768 + 149])[rows])
+    tol_ok(out["logits"][rows], ref["logits"], "32768-window launch")
+    _argmax_ok(out["pred"][rows], ref["logits"], ref["pred"])
+    full = m.infer_sequence(seq)                              # two launches: 32768 + 5000 (the fused tile's regime)
+    assert np.array_equal(full["logits"][:32768], out["logits"])
+    m.close()
