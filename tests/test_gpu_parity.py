@@ -633,7 +633,7 @@ def test_forward_windows_bench_batch(conv, monkeypatch, orc):
         assert m.last_plan()[0].startswith("conv_x3") and "fc_x3_256x128" in m.last_plan() and m.last_plan()[-1] == "gated_fp32_fallback", m.last_plan()
         assert g["enabled"] and not g["refused"] and g["guarded_launches"] == 1 and g["windows_out_of_range"] == 0 and g["fallbacks_run"] == 0, g
     if conv == "fp32_f16x2":
-        assert m.last_plan()[0] == "conv_h2" and "fc_h2_256x128" in m.last_plan(), m.last_plan()
+        assert m.last_plan()[0] == "conv_h2" and "fc_h2_256x128_out2" in m.last_plan() and "fc23_fused_h2_128x64" in m.last_plan(), m.last_plan()
     m.close()
     ref = orc.Oracle(sd).forward_windows(w)
     assert out["logits"].shape == (B, 16)
