@@ -347,3 +347,35 @@ def test_fc3_in_launches_past_the_fused_tile(orc):
     full = m.infer_sequence(seq)                              # two launches: 32768 + 5000 (the fused tile's regime)
     assert np.array_equal(full["logits"][:32768], out["logits"])
     m.close()
+
+
+@pytest.mark.parametrize("kind", ["aligned_rows", "aligned_rows_large_bias", "one_hot_rows"])
+def test_h1_row_scale_bound_is_safe_where_it_is_tight(kind, orc):
+    """h1's row scale comes from |h1| <= sqrt(K) max|feat| max_n ||W1_n||_2 + max|b1| (fc_gemm_h2_kernel<OUT2>).  Checkpoints that push h1 towards
+    that bound: fc.0 rows that all point along the (non-negative) features -- the Cauchy-Schwarz case --, the same with a bias that dominates, and
+    one-hot rows (h1 = single features: far BELOW the bound, the subnormal side).  No overflow, the contract holds."""
+    from deep_contact_estimator_amd import synth
+    sd = {k: v.copy() for k, v in synth.make_state_dict(1, "uniform").items()}
+    rng = np.random.default_rng(31)
+    w = sd["fc.0.weight"]
+    if kind.startswith("aligned"):
+        sd["fc.0.weight"] = (np.abs(rng.standard_normal(w.shape).astype(np.float32)) * np.float32(0.02) + np.float32(0.05)).astype(np.float32)
+        if kind.endswith("large_bias"):
+            sd["fc.0.bias"] = (sd["fc.0.bias"] * np.float32(1e6)).astype(np.float32)
+        sd["fc.3.weight"] = (sd["fc.3.weight"] * np.float32(1e-2)).astype(np.float32)          # keeps the logits at an ordinary size
+    else:
+        z = np.zeros_like(w)
+        z[np.arange(w.shape[0]), rng.integers(0, w.shape[1], w.shape[0])] = 1.0
+        sd["fc.0.weight"] = z
+    x = rng.standard_normal((N0, 150, 54), dtype=np.float32)
+    x[7] *= np.float32(1e12)
+    x[8] *= np.float32(1e-12)
+    m = _model(sd, N0)
+    out = m.predict(x)
+    assert "fc23_fused_h2_128x64" in m.last_plan(), m.last_plan()
+    rows = np.r_[0:160, N0 - 96:N0]
+    ref = orc.Oracle(sd).forward_windows(x[rows])
+    assert np.isfinite(ref["logits"]).all() and np.isfinite(out["logits"]).all()
+    tol_ok(out["logits"][rows], ref["logits"], kind)
+    _argmax_ok(out["pred"][rows], ref["logits"], ref["pred"])
+    m.close()
