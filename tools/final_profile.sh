@@ -6,7 +6,9 @@ case "$1" in
     for p in bf16_fc fp32_split fp32_f16x2; do rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5z_stats_$p -o r5z_$p -- python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extras --no-kernel-timing --precision $p > gpurun_out/r5z_stats_$p.log 2>&1; done
     python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5z_bench.json 2> gpurun_out/r5z_bench.err
     tail -c 400 gpurun_out/r5z_bench.json ;;
-2)  # the other precisions' bench lines, fp32_f16x2's counters, latency tools, the GPU suite
+2)  # the driver's bench line once more (profiles/pmc_latest.json now carries this build's hash: roofline.traffic is not stale), the other
+    # precisions' bench lines, fp32_f16x2's counters, latency tools, the GPU suite
+    python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5z_bench.json 2> gpurun_out/r5z_bench.err
     python bench.py --gpus 1 --steps 20 --warmup 5 --precision bf16_fc --no-cpu-baseline --no-extras > gpurun_out/r5z_bench_bf16.json 2>> gpurun_out/r5z_bench.err
     python bench.py --gpus 1 --steps 20 --warmup 5 --precision fp32_f16x2 --no-cpu-baseline --no-extras > gpurun_out/r5z_bench_f16x2.json 2>> gpurun_out/r5z_bench.err
     python bench.py --gpus 1 --steps 20 --warmup 5 --precision fp32_split --no-cpu-baseline --no-extras > gpurun_out/r5z_bench_fp32_split.json 2>> gpurun_out/r5z_bench.err
