@@ -22,10 +22,10 @@ def _model(precision, max_batch=8192, tune=None):
     return contact_cnn(device=0, max_batch=max_batch, precision=precision, tune=tune)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32_split", "bf16_fc"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32_split", "fp32_f16x2", "bf16_fc"])
 def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs, orc):
-    """One 4096-window launch per precision against logits the reference itself produced: fp32 and fp32_split within the fp32
-    tolerance and argmax-exact outside the noise margin, bf16_fc within its band (bf16 operands of fc.0 / fc.3)."""
+    """One 4096-window launch per precision against logits the reference itself produced: fp32, fp32_split and fp32_f16x2 within the
+    fp32 tolerance and argmax-exact outside the noise margin, bf16_fc within its band (bf16 operands of fc.0 / fc.3)."""
     g = golden("chip_ar1")
     sd, seq = case_inputs(g)
     m = _model(precision, max_batch=4096)
@@ -54,6 +54,7 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs, or
         assert np.array_equal(out["pred"][safe], g["pred"][safe])
         assert (out["pred"] != g["pred"]).sum() <= 2
         if precision == "fp32": assert "fc_phased256x128" in plan and "fc23_fused_phased128x64" in plan, plan
+        elif precision == "fp32_f16x2": assert plan[:3] == ["conv_h2", "fc_h2_256x128_out2", "fc23_fused_h2_128x64"], plan
         else: assert "fc_x3_256x128" in plan and any(k.startswith("conv_x3") for k in plan), plan
     assert np.array_equal(out["contacts"], ((out["pred"][:, None] & np.array([8, 4, 2, 1])) != 0).astype(np.uint8))
     m.close()
