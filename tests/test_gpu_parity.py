@@ -299,6 +299,19 @@ def test_full_size_properties(models, orc):
     assert np.array_equal(pb[lo:lo + span][safe], refb["pred"][safe])
     assert (pb[lo:lo + span] != refb["pred"]).mean() < 5e-3
     mb.close()
+    # ... and in fp32_f16x2 (two fp16 terms per operand, per-window scales; 32768-window launches: fc.3 on the 256 x 128 two-term kernel + the tail):
+    # the same oracle rows, the fp32 contract as stated, argmax and contact bits exact outside the noise margin; sub-range re-runs bit-exact
+    mh = contact_cnn(device=0, max_batch=32768, precision="fp32_f16x2"); mh.load_state_dict(synth.make_state_dict(1, "uniform")).eval()
+    oh = mh.infer_sequence(seq)
+    torch.cuda.synchronize()
+    assert mh.last_plan()[0] == "conv_h2", mh.last_plan()
+    lh = oh["logits"].cpu().numpy(); ph = oh["pred"].cpu().numpy(); ch = oh["contacts"].cpu().numpy()
+    assert lh.shape == (N, 16) and np.isfinite(lh).all() and np.array_equal(ph, lh.argmax(axis=1))
+    tol_ok(lh[lo:lo + span], ref["logits"], "1e6-run, 65,536 contiguous windows vs oracle (fp32_f16x2)")
+    _argmax_contract(ph[lo:lo + span], ch[lo:lo + span], ref["logits"], ref["pred"], ref["contacts"])
+    sub = mh.infer_sequence(seq[32768:32768 + 32768 + 149])       # a whole launch of the run, alone: a window's bits depend on that window alone
+    assert np.array_equal(sub["logits"].cpu().numpy(), lh[32768:65536])
+    mh.close()
 
 
 def test_bf16_fc_precision(models, orc):
