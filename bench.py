@@ -109,16 +109,20 @@ def exec_flop(kernel, precision):
     return EXEC_FLOP[kernel]
 
 
-def kernel_table(prof, B, precision):
+def kernel_table(prof, B, precision, steps=None):
+    """Per-kernel averages of the profiled pass.  `steps`: the number of steps that pass ran -- a precision that queues a second, gated launch per
+    stage behind every step (fp32_split's range guard: the DCE_FP32 fallback, ~5 us per gated-off launch) has two timed spans per stage and
+    step; its stage time is the SUM of both per step, not their mean."""
     out = {}
     for k, v in prof.items():
         if v["launches"] == 0:
             continue
-        avg_s = v["ms"] / v["launches"] * 1e-3
+        n = steps if steps and v["launches"] > steps else v["launches"]
+        avg_s = v["ms"] / n * 1e-3
         peak, pipe = kernel_peak(k, precision)
         ex = exec_flop(k, precision) * B / avg_s / 1e12
         out[k] = {
-            "avg_ms": avg_s * 1e3, "launches": v["launches"], "pipe": pipe, "peak_tflops": peak,
+            "avg_ms": avg_s * 1e3, "launches": v["launches"], "steps": n, "pipe": pipe, "peak_tflops": peak,
             "executed_tflops": ex, "frac": ex / peak,
             "algorithmic_tflops": ALGO_FLOP[k] * B / avg_s / 1e12,
             "algorithmic_GBs": ALGO_BYTES[k] * B / avg_s / 1e9,
@@ -418,7 +422,7 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
     torch.cuda.synchronize()
     prof = m.profile_read(reset=True)
     m.profile(0)
-    kern = kernel_table(prof, B, precision)
+    kern = kernel_table(prof, B, precision, steps=max(steps, 50))
     lg, lr = out["logits"], ref_out["logits"]
     flips = int((out["pred"] != ref_out["pred"]).sum().item())
     res = {
@@ -724,7 +728,7 @@ def main():
     res = None
     if rank == 0:
         wps = world * B * args.steps / elapsed
-        kernels = kernel_table(prof, B, args.precision)
+        kernels = kernel_table(prof, B, args.precision, steps=psteps)
         res = {
             "metric": METRIC, "value": wps, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
