@@ -844,6 +844,13 @@ def main():
             }
             res["extra"]["bf16_fc"]["online_push"] = extra_online(contact_cnn, sd, dev, seq_np, pushes=1000, precision="bf16_fc")
             res["extra"]["latency_mode"] = extra_latency_mode(torch, contact_cnn, sd, dev, windows, seq_np, out["logits"])
+            # the same step in every precision of the library, side by side (`value` above is the first: the reference's arithmetic)
+            res["precisions"] = {
+                "fp32": {"windows_per_s": res["value"], "contract": "fp32 tolerance (|d| <= 1e-5 max|ref| + 1e-4 |ref|), argmax exact outside the noise margin", "operands": "fp32 (fp32 MFMA)"},
+                "fp32_split": {"windows_per_s": res["extra"]["fp32_split"]["windows_per_s"], "contract": "the same", "operands": "fp32 as three bf16 terms (six bf16 MFMAs per product), range-guarded"},
+                "fp32_f16x2": {"windows_per_s": res["extra"]["fp32_f16x2"]["windows_per_s"], "contract": "the same", "operands": "two fp16 terms of the value times a per-window power of two (22 bits; three fp16 MFMAs per product)"},
+                "bf16_fc": {"windows_per_s": res["extra"]["bf16_fc"]["windows_per_s"], "contract": "logits within 6e-3 of the largest logit (BASELINE configs[4])", "operands": "bf16 on fc.0 / fc.3, two bf16 terms in the conv stack"},
+            }
     if rank == 0:
         if world == 1 and not multi and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, windows.cpu().numpy(), seq_np, out["logits"].cpu().numpy(),
