@@ -300,6 +300,21 @@ int main(void)
         for (int i = 0; i < N2; ++i) flips += pr2[i] != rp2[i];
         CHECK(flips <= 6, "split mode: %d argmax differences of %d", flips, N2);
         printf("abi_client: DCE_FP32_SPLIT, %d windows: err/bound %.3f, %d sub-margin argmax differences, plan %s\n", N2, wst, flips, plan);
+        /* ---- 8b. the same context finalised again with DCE_FP32_F16X2 (two fp16 terms per operand, per-window scales chosen in the kernel;
+         *          csrc/conv_h2.hip, csrc/fc_gemm_h2.hip): same input, same oracle rows, same tolerance; the scaled sequence (x 2^-60) too --
+         *          the z-score makes it the same windows, so the same bits must come back */
+        CHECK(dce_finalize_weights(c2, DCE_FP32_F16X2) == DCE_OK, "finalize (f16x2): %s", dce_last_error(c2));
+        CHECK(dce_infer_sequence(c2, seq2, T2, DCE_WINDOW, 0, lg2, pr2, NULL) == DCE_OK, "infer (f16x2): %s", dce_last_error(c2));
+        CHECK(dce_last_plan(c2, plan, sizeof plan) == DCE_OK && strstr(plan, "conv_h2") != NULL && strstr(plan, "fc_h2_256x128") != NULL && strstr(plan, "fc23_fused_h2_128x64") != NULL,
+              "two-term fp16 kernels not in the plan: %s", plan);
+        wst = 0.0;
+        for (int e = 0; e < N2 * DCE_CLASSES; ++e)
+            wst = fmax(wst, fabs((double)lg2[e] - rl2[e]) / (1e-5 * mr + 1e-4 * fabs(rl2[e])));
+        CHECK(wst <= 1.0, "f16x2 mode: logits outside tolerance: err/bound = %.3f", wst);
+        flips = 0;
+        for (int i = 0; i < N2; ++i) flips += pr2[i] != rp2[i];
+        CHECK(flips <= 6, "f16x2 mode: %d argmax differences of %d", flips, N2);
+        printf("abi_client: DCE_FP32_F16X2, %d windows: err/bound %.3f, %d sub-margin argmax differences, plan %s\n", N2, wst, flips, plan);
         dce_destroy(c2);
         free(seq2); free(lg2); free(rl2); free(pr2); free(rp2); free(rc2); free(zw2);
     }
