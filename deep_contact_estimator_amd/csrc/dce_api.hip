@@ -64,7 +64,7 @@ const TuneKey kTuneKeys[] = {
     TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
     TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'),
     TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
-    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_fc3, 'b'),
+    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_fc3, 'b'), TK(h2_min_tiles, 'i'),
     TKX(bf16_k32, 'b'), TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
     TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(h2_ksplit, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
 };
@@ -334,8 +334,9 @@ struct GateScope {
 //                 (range guard refused the checkpoint, or -- behind the sequence above -- a window of the launch left the guarded
 //                  range: the DCE_FP32 row, gated on the device word the conv kernel raised)
 //   DCE_FP32_F16X2  < x3_conv_min (128), a tap, online  = DCE_FP32
-//                 .. < 2817                      conv_h2_f32 (two fp16 terms)     fc_* fp32                 = DCE_FP32
-//                 >= 2817                        conv_h2 -> two fp16 terms + scale fc_h2_256x128             = DCE_FP32
+//                 .. < h2_min_tiles (1281)       conv_h2_f32 (two fp16 terms)     fc_* fp32                 = DCE_FP32
+//                 .. <= 12288                    conv_h2 -> two fp16 terms + scale fc_h2_256x128[_out2]      fused two-term 128x64 + combine
+//                 > 12288                        (as above)                        (as above)                fc_h2_256x128 (h2 fp32) + tail
 enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16, H2, H2F32 };
 enum class Fc0 { F32, Gemv, X3, Bf16, H2 };
 enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16, FusedH2, H2 };
@@ -364,7 +365,7 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
         p.fused_rows = n;
         return p;
     }
-    const bool h2 = c->precision == DCE_FP32_F16X2 && !c->h2_refused && wino && !online && !c->want_feat && fc_gemm_h2_ok(n, FC1, FEAT);
+    const bool h2 = c->precision == DCE_FP32_F16X2 && !c->h2_refused && wino && !online && !c->want_feat && fc_gemm_h2_ok(n, FC1, FEAT, tu.h2_min_tiles);
     if (h2) { p.conv = Conv::H2; p.fc0 = Fc0::H2; }
     else if (c->precision == DCE_FP32_F16X2 && !c->h2_refused && wino && !online && n >= tu.x3_conv_min) p.conv = Conv::H2F32;   // mid-size batch (or a feature tap): two-term fp16 conv stack, fp32 features, fp32 FC kernels
     const bool split = c->precision == DCE_FP32_SPLIT && !c->guard.refused && !c->gate_on;
@@ -386,17 +387,18 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
     p.fc0 = h2 ? Fc0::H2 : x3 ? Fc0::X3 : gemv ? Fc0::Gemv : Fc0::F32;
     p.split3 = x3 && !fused;
     p.fc3 = gemv ? Fc3::Gemv : Fc3::F32;
-    if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1) && !fc_split_ok(n, FC2, FC1)) {
+    const bool h2f3 = h2 && tu.h2_fc3 && !c->want_h1 && c->fc2w_h2 && c->h1h;                   // DCE_FP32_F16X2: fc.3 on two-term fp16 operands too (h1 leaves fc.0 as two fp16 terms + row scales)
+    if (h2f3 && fc23_h2_ok(n)) { p.fc3 = Fc3::FusedH2; p.fused_rows = n; }
+    else if (fc23_fused_ok(n, 0) && !fc_gemm_chain_ok(n, FC2, FC1) && !fc_split_ok(n, FC2, FC1)) {
         // chip-filling batch: fc.3's GEMM finishes fc.6's chunk sums in its epilogue (h2 never leaves the CU unless a tap asks for
         // it); one small kernel adds them up.  Same summation tree as the tail kernel.  The fused kernel runs whole rounds of 256
         // tiles = 4096 windows: a batch that ends up to 2048 windows past a round gives that remainder to the chain kernel + tail
         // (same bits, rows are independent) instead of paying a full round for it.
         const int64_t rest = n % 4096;
         p.fc3 = (x3 && !c->want_h1 && c->fc2w_x3 && c->h1p && fc23_x3_ok(n)) ? Fc3::FusedX3 : Fc3::Fused;      // fc.3 on three-term operands too (h1 then leaves fc.0 as three planes)
-        if (h2 && tu.h2_fc3 && !c->want_h1 && c->fc2w_h2 && c->h1h && fc23_h2_ok(n)) p.fc3 = Fc3::FusedH2;     // DCE_FP32_F16X2: fc.3 on two-term fp16 operands (h1 leaves fc.0 as two fp16 terms + row scales)
         const bool cut = p.fc3 == Fc3::Fused && tu.gemm_peel && !c->gate_on && n > 4096 && rest && (rest <= 8 || fc_split_ok(rest, FC2, FC1) || fc_gemm_chain_ok(rest, FC2, FC1));
         p.fused_rows = cut ? n - rest : n;
-    } else if (h2 && tu.h2_fc3 && !c->want_h1 && c->fc2w_h2 && c->h1h && fc_gemm_h2_ok(n, FC2, FC1))
+    } else if (h2f3 && fc_gemm_h2_ok(n, FC2, FC1, tu.x3_min_tiles))
         p.fc3 = Fc3::H2;                                              // a launch past the fused tile's one round: fc.3 on fc.0's 256 x 128 kernel (h2 in fp32), then the tail
     return p;
 }

@@ -55,6 +55,7 @@ struct Tuning {
     bool x3_permk = true;                                   // 0: conv_x3.hip's features through LDS in the reference's flatten order instead of straight out in the order t' * 128 + c
     bool x3_fc3 = false;                                    // 1: fc.3 on three-term operands too (fc_gemm_x3.hip's 128 x 64 tile with the fused fc.6 epilogue; h1 leaves fc.0 as three planes).  Built and parity-green in round 5, and NOT faster: 64.3 us against 71 for the fp32 MFMA kernel, +9.5 us on fc.0's epilogue (profiles/r5j_split_fc3.txt) -- with 32 x 32 wave tiles a K-tile's LDS traffic is fc.0's for half its MFMAs
     // -- DCE_FP32_F16X2
+    int h2_min_tiles = 96;                                  // 256x128 tiles a launch needs for fc.0 on fc_gemm_h2.hip (96: from 1281 windows -- below that the fp32 FC kernels behind conv_h2_f32 are as fast; one round of tiles takes fc.0 ~170 us whatever their number)
     bool h2_fc3 = true;                                     // 0: fc.3 + fc.6 chunk sums on the fp32 kernels instead of two-term fp16 operands (fc_gemm_h2k_kernel<H2KFc3>; h1 then leaves fc.0 in fp32)
     bool split_guard = true;                                // 0: no range guard (static bound at finalize, per-window exponent check + fp32 fallback): the round-4 behaviour, for the A/B and the audit
     // -- experiments build only (ignored by the product library)
@@ -237,7 +238,7 @@ hipError_t launch_conv_h2_taps(const float* windows, int64_t n, const ConvPackH2
                                const LayerTaps& taps, hipStream_t st);
 // fc.0 on two-term fp16 operands: C = act(A W^T * 2^-(row_scale[m] + sw) + bias), 256 x 128 tiles that fill the chip only
 hipError_t init_fc_gemm_h2();
-bool       fc_gemm_h2_ok(int64_t M, int N, int K);
+bool       fc_gemm_h2_ok(int64_t M, int N, int K, int min_tiles);
 int        fc_gemm_h2_pad_rows();                                     // rows A2's buffer must hold beyond M (ragged tiles read them)
 //   H1 != NULL: h1 leaves as two fp16 terms [row][N / 32][2][32] with its row scales in h1_scale (the operand of fc.3 below) instead of fp32 in C
 hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, const unsigned short* W2, int sw, const float* bias, float* C,

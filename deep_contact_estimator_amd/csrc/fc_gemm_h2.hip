@@ -509,14 +509,14 @@ hipError_t init_fc_gemm_h2()
 
 int fc_gemm_h2_pad_rows() { return H2_BM; }                       // rows an A operand's buffer holds beyond M (read by ragged tiles of the K-split kernels, never used)
 
-// 256 x 128 tiles must fill the chip (as the phased fp32 kernel asks of its large tile)
-bool fc_gemm_h2_ok(int64_t M, int N, int K)
+// min_tiles: 256 x 128 tiles the launch must have (fc.0: option h2_min_tiles; fc.3 on this kernel: a chip-filling launch, x3_min_tiles)
+bool fc_gemm_h2_ok(int64_t M, int N, int K, int min_tiles)
 {
     if (N % H2_BN || K % H2_KT || K < 2 * H2_KT || M <= 0) return false;
     const int nt = N / H2_BN;
     if ((nt & (nt - 1)) != 0) return false;
     if ((size_t)(M > N ? M : N) * K * 4 >= (1ull << 32)) return false;              // per-lane offsets are 32-bit
-    return ((M + H2_BM - 1) / H2_BM) * nt >= tune().x3_min_tiles;
+    return ((M + H2_BM - 1) / H2_BM) * nt >= min_tiles;
 }
 
 //   H1 != NULL: h1 leaves as two fp16 terms [row][N / 32][2][32] with its row scales in h1_scale (the operand of the fc.3 kernels below); eW, eB:
@@ -524,7 +524,7 @@ bool fc_gemm_h2_ok(int64_t M, int N, int K)
 hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, const unsigned short* W2, int sw, const float* bias, float* C,
                              int64_t M, int N, int K, int relu, hipStream_t st, unsigned short* H1, int* h1_scale, int eW, int eB)
 {
-    if (!fc_gemm_h2_ok(M, N, K)) return hipErrorInvalidValue;
+    if (!fc_gemm_h2_ok(M, N, K, 1)) return hipErrorInvalidValue;
     const int mtiles = (int)((M + H2_BM - 1) / H2_BM), ntiles = N / H2_BN;
     int sn_log2 = tune().phased_sn;
     while ((1 << sn_log2) > ntiles) --sn_log2;
@@ -547,8 +547,8 @@ hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, con
 // fc.3 (+ReLU) on two-term fp16 operands with fc.6's chunk sums finished in the epilogue: h1 = [M + pad][64][2][32] fp16 with its row scales
 // (fc_gemm_h2_kernel<OUT2>), W2p = fc.3's weights in the same layout times 2^sw; part: [8][part_rows][16] chunk sums; h2_out: NULL or (M, 512) fp32
 bool fc23_h2_ok(int64_t M)
-{
-    return fc23_fused_ok(M, 0) && (size_t)(M + H2KFc3::BM) * FC1 * 4 < (1ull << 32);
+{   // up to one and a half rounds of 128 x 64 tiles (12288 windows); longer launches put fc.3 on the 256 x 128 kernel + the tail (as the fp32 path does)
+    return M > 0 && M <= 12288 && (size_t)(M + H2KFc3::BM) * FC1 * 4 < (1ull << 32);
 }
 hipError_t launch_fc23_fused_h2(const unsigned short* h1, const int* h1_scale, const unsigned short* W2p, int sw, const float* b2, const float* W3,
                                 float* part, int64_t part_rows, float* h2_out, int64_t M, hipStream_t st)

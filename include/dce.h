@@ -83,7 +83,7 @@ typedef enum dce_precision {
                                   for pre-normalised windows, per window in the conv kernel's load stage: a launch holding a window outside
                                   [x_lo, x_hi] is recomputed by the DCE_FP32 kernel sequence queued behind it (gated on the device, no host
                                   round trip).  z-scored windows (dce_infer_sequence) are inside the range by construction */
-    DCE_FP32_F16X2      = 3    /* fp32-TOLERANCE results with the conv stack (from 128 windows per launch), fc.0 and fc.3 (from 2817; below
+    DCE_FP32_F16X2      = 3    /* fp32-TOLERANCE results with the conv stack (from 128 windows per launch), fc.0 and fc.3 (from 1281; below
                                   that the DCE_FP32 kernels) on the fp16 matrix pipe: every operand is scaled by a power of two and
                                   enters as TWO fp16 terms (11 + 11 significand bits), three MFMAs per product, fp32 accumulate
                                   (csrc/conv_h2.hip, csrc/fc_gemm_h2.hip; 2.5 x DCE_FP32's throughput at 4096 windows).  Not fp32 operands -- 22 of their 24 bits -- but the same contract
@@ -101,7 +101,7 @@ typedef enum dce_precision {
  * kernels by size -- up to 256 windows per launch one weight-streaming kernel whose results do not depend on the number of windows (an
  * online push gives the bits of a sequence call in launches of <= 256), above that tile / phased GEMMs with other fp32 summation orders:
  * an h1 value at a bf16 rounding boundary may round the other way, <= 2e-2 of the largest logit.  DCE_FP32_F16X2: below 128 windows the
- * DCE_FP32 kernels, from 128 the two-term fp16 conv stack, from 2817 fc.0 / fc.3 on two-term operands too (launches past 12288 windows: fc.3 on
+ * DCE_FP32 kernels, from 128 the two-term fp16 conv stack, from 1281 fc.0 / fc.3 on two-term operands too (launches past 12288 windows: fc.3 on
  * another tile) -- within a regime a window's bits depend on that window alone; between regimes they differ by fp32 rounding (<= 2e-5 of the
  * largest logit).  Tested:
  * tests/test_round4_gpu.py::test_batch_size_regimes_stay_within_the_mode_tolerance.  A caller that needs call-size invariance uses DCE_FP32. */
