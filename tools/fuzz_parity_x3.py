@@ -13,7 +13,7 @@ from oracle import oracle as orc
 TRIALS = int(os.environ.get("TRIALS", 60))
 PRECISION = os.environ.get("PRECISION", "fp32_split")
 rng = np.random.default_rng(int(os.environ.get("SEED", 77)))
-edges = [100, 127, 128, 129, 255, 256, 700, 1023, 1025, 2048, 2815, 2816, 2817, 2900, 3072, 3333, 4096, 4099, 5003]
+edges = [100, 127, 128, 129, 255, 256, 700, 1023, 1025, 1280, 1281, 1290, 2048, 2815, 2816, 2817, 2900, 3072, 3333, 4096, 4099, 5003]
 worst, flips, total, plans = 0.0, 0, 0, {}
 t0 = time.time()
 for trial in range(TRIALS):
