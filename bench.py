@@ -86,13 +86,16 @@ def kernel_peak(kernel, precision):
         return PEAK_BF16_MFMA_TFLOPS, "bf16 MFMA, six bf16 x bf16 terms per fp32 product (fc_gemm_x3.hip)"
     if precision == "fp32_f16x2" and kernel in ("fc1_gemm", "conv_stack"):
         return PEAK_BF16_MFMA_TFLOPS, "fp16 MFMA (same dense peak as bf16), three fp16 x fp16 terms per product" + (" (fc_gemm_h2.hip)" if kernel == "fc1_gemm" else ", direct-form conv with its tile padding (conv_h2.hip)")
+    if precision == "bf16_fc" and kernel == "conv_stack" and conv_terms(precision) == 3 and "bf16_conv_h2=0" not in os.environ.get("DCE_TUNE", ""):
+        return PEAK_BF16_MFMA_TFLOPS, "fp16 MFMA (same dense peak as bf16), three fp16 x fp16 terms per product, direct-form conv with its tile padding (conv_h2.hip)"
     if precision in ("fp32_split", "bf16_fc") and kernel == "conv_stack":
         return PEAK_BF16_MFMA_TFLOPS, f"bf16 MFMA, {conv_terms(precision)} bf16 x bf16 terms per product, direct-form conv with its tile padding (conv_x3.hip)"
     return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA" if kernel != "fc3_tail" else "fp32 VALU (= fp32 MFMA rate)"
 
 
 def conv_terms(precision):
-    """MFMAs per product of conv_x3.hip: six on three-term operands (fp32_split), three on two-term operands (bf16_fc's default)."""
+    """MFMAs per product of the direct-form conv stacks: six on three bf16 terms (conv_x3.hip: fp32_split, bf16_fc with x3_bf16_terms=3), three on two
+    terms (conv_h2.hip on fp16: fp32_f16x2 and bf16_fc's default; conv_x3.hip on bf16: bf16_fc with bf16_conv_h2=0)."""
     if precision == "fp32_f16x2":
         return 3
     return 3 if precision == "bf16_fc" and "x3_bf16_terms=3" not in os.environ.get("DCE_TUNE", "") else 6
@@ -393,9 +396,9 @@ def extra_latency_mode(torch, contact_cnn, sd, dev, windows, seq_np, ref_logits)
 
 
 MODE_TEXT = {
-    "bf16_fc": "BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; conv stack on two-term bf16 "
-               "operands (three MFMAs per product, ~17 significant bits in front of the features' rounding to bf16, conv_x3.hip NT = 2; "
-               "option x3_bf16_terms=3: fp32_split's six-MFMA products, x3_conv=0: the fp32 Winograd kernel), fc.6 fp32",
+    "bf16_fc": "BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; conv stack with results of fp32 grade "
+               "(two fp16 terms per operand with per-window scales, three MFMAs per product, conv_h2.hip; options: bf16_conv_h2=0: two bf16 terms, ~17 bits; "
+               "x3_bf16_terms=3: three bf16 terms, six MFMAs per product; x3_conv=0: the fp32 Winograd kernel), features rounded to bf16, fc.6 fp32",
     "fp32_split": "the bench step ({B} windows) with the conv stack and fc.0 on the bf16 matrix pipe, every fp32 operand as three bf16 terms "
                   "(six MFMAs per product, fp32 accumulate: fp32 results, not the fp32 path's bits -- opt-in, include/dce.h DCE_FP32_SPLIT); "
                   "fc.3 and fc.6 fp32 MFMA",
@@ -453,27 +456,27 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
         sb = extra_small_batches(torch, m, windows, sizes=(1, 30, 64, 256, 1024))
         res["small_batches"] = {"workload": "model.predict on b pre-normalised device-resident windows in this precision", "batches": sb["batches"]}
     m.close()
-    if precision == "bf16_fc" and conv_terms(precision) == 3:
-        # the same step with the conv stack on THREE-term operands (fp32-grade features in front of their rounding to bf16: the
-        # round-3 form of the mode), so that the line shows what the two-term stack buys and what it changes
-        try:
-            m3 = contact_cnn(device=dev.index, max_batch=B, precision=precision, tune={"x3_bf16_terms": 3})
-            m3.load_state_dict(sd).eval()
-            settle(torch, lambda: m3.predict(windows), min(settle_s, 0.5))
+    if precision == "bf16_fc" and conv_terms(precision) == 3 and "bf16_conv_h2=0" not in os.environ.get("DCE_TUNE", ""):
+        # The mode as it ships runs its conv stack on two FP16 terms with per-window scales (conv_h2.hip: results of fp32 grade -- BASELINE
+        # configs[4] as it is written).  The same step with the two other conv stacks the mode has had, so that the line shows what each costs
+        # and changes: TWO bf16 terms (~17 bits; rounds 4-5, option bf16_conv_h2=0) and THREE bf16 terms (fp32-grade at six MFMAs per product; round 3)
+        def variant(tune):
+            mv = contact_cnn(device=dev.index, max_batch=B, precision=precision, tune=tune)
+            mv.load_state_dict(sd).eval()
+            settle(torch, lambda: mv.predict(windows), min(settle_s, 0.5))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            o3 = run_steps(m3, windows, steps)
+            ov = run_steps(mv, windows, steps)
             torch.cuda.synchronize()
-            dt3 = time.perf_counter() - t0
-            f3 = int((o3["pred"] != ref_out["pred"]).sum().item())
-            res["three_term_conv_stack"] = {
-                "switch": "x3_bf16_terms=3", "note": "BASELINE configs[4] as written: fp32-grade conv results in front of the bf16 FC layers", "windows_per_s": B * steps / dt3, "ms_per_step": dt3 / steps * 1e3, "plan": m3.last_plan(),
-                "vs_fp32_same_input": {"max_abs_dlogit": float((o3["logits"] - lr).abs().max().item()), "argmax_flips": f3},
-                "vs_two_term_same_input": {"max_abs_dlogit": float((o3["logits"] - lg).abs().max().item()),
-                                           "argmax_differences": int((o3["pred"] != out["pred"]).sum().item())}}
-            m3.close()
-        finally:
-            pass
+            dtv = time.perf_counter() - t0
+            r = {"switch": ",".join(f"{k}={v}" for k, v in tune.items()), "windows_per_s": B * steps / dtv, "ms_per_step": dtv / steps * 1e3, "plan": mv.last_plan(),
+                 "vs_fp32_same_input": {"max_abs_dlogit": float((ov["logits"] - lr).abs().max().item()), "argmax_flips": int((ov["pred"] != ref_out["pred"]).sum().item())},
+                 "vs_the_mode_as_it_ships_same_input": {"max_abs_dlogit": float((ov["logits"] - lg).abs().max().item()), "argmax_differences": int((ov["pred"] != out["pred"]).sum().item())}}
+            mv.close()
+            return r
+        res["conv_stack"] = "two fp16 terms per operand with per-window scales (conv_h2.hip): conv results of fp32 grade in front of the bf16 FC layers = BASELINE configs[4] as written"
+        res["two_term_bf16_conv_stack"] = dict(variant({"bf16_conv_h2": 0}), note="conv stack on two bf16 terms (~17 significant bits) at every size: the mode's default in rounds 4-5")
+        res["three_term_conv_stack"] = dict(variant({"x3_bf16_terms": 3}), note="conv stack on three bf16 terms (fp32 operands, six MFMAs per product): the mode's form in round 3")
     # BASELINE configs[2] in this precision too: the 1e6-window sequence, HBM-resident, max_batch 32768 (median of 3 after a warm call)
     ms = contact_cnn(device=dev.index, max_batch=32768, precision=precision)
     ms.load_state_dict(sd).eval()
@@ -733,7 +736,7 @@ def main():
             "metric": METRIC, "value": wps, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16_fc": "bf16 FC operands (f32 accumulate); conv stack on two-term bf16 operands (~17 bits, f32 accumulate) in front of the features' rounding to bf16",
+            "dtype": {"fp32": "f32", "bf16_fc": "bf16 FC operands (f32 accumulate); conv stack of f32 grade (two fp16 terms per operand with per-window scales, f32 accumulate) in front of the features' rounding to bf16",
                       "fp32_split": "f32 (conv stack and fc.0: f32 operands as three bf16 terms on bf16 MFMA, f32 accumulate)",
                       "fp32_f16x2": "f32 tolerance (conv stack and fc.0: operands as two fp16 terms of the value times a power of two on fp16 MFMA, f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {
@@ -849,7 +852,7 @@ def main():
                 "fp32": {"windows_per_s": res["value"], "contract": "fp32 tolerance (|d| <= 1e-5 max|ref| + 1e-4 |ref|), argmax exact outside the noise margin", "operands": "fp32 (fp32 MFMA)"},
                 "fp32_split": {"windows_per_s": res["extra"]["fp32_split"]["windows_per_s"], "contract": "the same", "operands": "fp32 as three bf16 terms (six bf16 MFMAs per product), range-guarded"},
                 "fp32_f16x2": {"windows_per_s": res["extra"]["fp32_f16x2"]["windows_per_s"], "contract": "the same", "operands": "two fp16 terms of the value times a per-window power of two (22 bits; three fp16 MFMAs per product)"},
-                "bf16_fc": {"windows_per_s": res["extra"]["bf16_fc"]["windows_per_s"], "contract": "logits within 6e-3 of the largest logit (BASELINE configs[4])", "operands": "bf16 on fc.0 / fc.3, two bf16 terms in the conv stack"},
+                "bf16_fc": {"windows_per_s": res["extra"]["bf16_fc"]["windows_per_s"], "contract": "logits within 6e-3 of the largest logit (BASELINE configs[4])", "operands": "bf16 on fc.0 / fc.3; conv stack of fp32 grade (two fp16 terms, per-window scales)"},
             }
     if rank == 0:
         if world == 1 and not multi and not args.no_cpu_baseline:

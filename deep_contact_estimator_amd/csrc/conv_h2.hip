@@ -228,7 +228,10 @@ __device__ __forceinline__ void hx_store(char* __restrict__ lds, const cx_f32x4 
 // fp32 in the reference's flatten order c * 37 + t'
 // OUT32 (mid-size batches, below fc_gemm_h2.hip's threshold: the FC layers then run on the fp32 kernels): the features leave unscaled, as
 // (n, 4736) fp32 in the reference's flatten order, through LDS and 16-byte stores; nothing else is written
-template <bool ZS, bool TAPS, bool OUT32 = false>
+// OUTBF (DCE_BF16_FC with the option bf16_conv_h2: BASELINE configs[4] as it is written -- bf16 on the FC layers, conv results of fp32 grade): the
+// features leave rounded to bf16 (nearest-even of the unscaled value), (n, 4736) in the K order t' * 128 + c, straight from the accumulators --
+// bf16 has fp32's range: no scale, no maximum, no barrier
+template <bool ZS, bool TAPS, bool OUT32 = false, bool OUTBF = false>
 __global__ __launch_bounds__(256, 3)
 void conv_h2_kernel(const float* __restrict__ src, int64_t n, ConvPackH2 pk, unsigned short* __restrict__ feat2, int* __restrict__ feat_scale,
                     LayerTaps taps, float* __restrict__ feat32)
@@ -394,6 +397,29 @@ void conv_h2_kernel(const float* __restrict__ src, int64_t n, ConvPackH2 pk, uns
         const int sw4[3] = {cx_swz<256>(j), cx_swz<256>(j + 1), cx_swz<256>(j + 2)};
         bias_acc(pk.b[3], 32 * wv, S + pk.sw[3]);
         cx_layer<256, 4, false, CX_ILV != 0, 2, true>(cx_lds + j * 256, sw4, g, w3 + (size_t)wv * (12 * 2 * 2 * 64), acc);
+        if constexpr (OUTBF) {
+            static_assert(!TAPS && !OUT32, "one feature format per instantiation");
+            const int e4 = S + pk.sw[3];
+            unsigned short* const outb = feat2 + (size_t)win * FEAT;
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int co = 32 * wv + 16 * rt + 4 * g;
+#pragma unroll
+                for (int ct = 0; ct < CX_NT; ++ct) {
+                    const int t = 16 * ct + j;
+                    float q[4] = {acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r] = __builtin_ldexpf(fmaxf(fmaxf(q[r], cx_neighbour(q[r])), 0.f), -e4);
+                    unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(hx_f32x2{q[0], q[1]}, bf2));
+                    unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(hx_f32x2{q[2], q[3]}, bf2));
+                    if (window_bad) lo = hi = 0x7fc07fc0u;              // a non-finite sample: NaN features
+                    if ((j & 1) == 0 && (t >> 1) < 37) *reinterpret_cast<uint2*>(outb + (t >> 1) * 128 + co) = make_uint2(lo, hi);
+                }
+            }
+            TRACE_MARK(9);
+            return;
+        }
         if constexpr (!OUT32) hx_layer_max<75>(acc, 0, j, lane, &hx_max[3]);
         TRACE_MARK(8);
         __syncthreads();                                               // every wave's maximum is in (the one barrier the features' common scale costs; OUT32: conv4's input is dead)
@@ -478,7 +504,8 @@ hipError_t init_conv_h2()
     hipError_t e;
     for (const void* k : {reinterpret_cast<const void*>(&conv_h2_kernel<true, false>), reinterpret_cast<const void*>(&conv_h2_kernel<false, false>),
                           reinterpret_cast<const void*>(&conv_h2_kernel<false, true>),
-                          reinterpret_cast<const void*>(&conv_h2_kernel<true, false, true>), reinterpret_cast<const void*>(&conv_h2_kernel<false, false, true>)})
+                          reinterpret_cast<const void*>(&conv_h2_kernel<true, false, true>), reinterpret_cast<const void*>(&conv_h2_kernel<false, false, true>),
+                          reinterpret_cast<const void*>(&conv_h2_kernel<true, false, false, true>), reinterpret_cast<const void*>(&conv_h2_kernel<false, false, false, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CX_PLANE)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -502,6 +529,17 @@ hipError_t launch_conv_h2_f32(const float* src, int zscore, int64_t n, const Con
     plan_note("conv_h2_f32");
     if (zscore) hipLaunchKernelGGL((conv_h2_kernel<true, false, true>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, nullptr, nullptr, LayerTaps{}, feat);
     else        hipLaunchKernelGGL((conv_h2_kernel<false, false, true>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, nullptr, nullptr, LayerTaps{}, feat);
+    return hipGetLastError();
+}
+
+// ... with (n, 4736) bf16 features out in the K order t' * 128 + c: DCE_BF16_FC with the option bf16_conv_h2 (its fc.0 takes the K-permuted bf16 weights)
+hipError_t launch_conv_h2_bf16(const float* src, int zscore, int64_t n, const ConvPackH2& pk, unsigned short* feat, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    constexpr int L2T = 2 * CX_PLANE;
+    plan_note("conv_h2_bf16_permk");
+    if (zscore) hipLaunchKernelGGL((conv_h2_kernel<true, false, false, true>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, nullptr, LayerTaps{}, nullptr);
+    else        hipLaunchKernelGGL((conv_h2_kernel<false, false, false, true>), dim3((unsigned)n), dim3(256), L2T, st, src, n, pk, feat, nullptr, LayerTaps{}, nullptr);
     return hipGetLastError();
 }
 

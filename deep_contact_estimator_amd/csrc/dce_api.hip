@@ -62,7 +62,7 @@ const TuneKey kTuneKeys[] = {
     TK(fc23, 'i'), TK(gemm_peel, 'b'), TK(conv_peel, 'b'), TK(gemm_small_deep, 'b'), TK(gemv, 'b'),
     TK(split_min, 'l'), TK(split_max, 'l'), TK(chain_min, 'l'), TK(chain_max, 'l'), TK(chain_max3, 'l'), TK(chain_bn16_max, 'l'),
     TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
-    TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'),
+    TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'), TK(bf16_conv_h2, 'b'), TK(bf16_conv_h2_min, 'l'),
     TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
     TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_fc3, 'b'), TK(h2_min_tiles, 'i'),
     TKX(bf16_k32, 'b'), TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
@@ -327,7 +327,8 @@ struct GateScope {
 //
 //   precision     windows per chunk              conv stack                       fc.0                      fc.3 / fc.6
 //   DCE_FP32      any                            conv_wino* (fp32 MFMA)           fc_* fp32                 fused 128x64 + combine (one round of tiles) | fc_* fp32 + tail
-//   DCE_BF16_FC   any                            conv_x2_bf16[_permk] (two-term)  bf16 stream / tile / phased  fused bf16 + combine | bf16 + tail
+//   DCE_BF16_FC   <= 256 (and taps, online)      conv_x2_bf16[_permk] (two bf16 terms)  bf16 stream / tile / phased  fused bf16 + combine | bf16 + tail
+//                 > 256                          conv_h2_bf16_permk (two fp16 terms + scales: fp32-grade)   (as above)
 //   DCE_FP32_SPLIT  < x3_conv_min (128)          = DCE_FP32
 //                 .. < fc.0's 192 tiles (2817)   conv_x3_f32 (three-term)         fc_* fp32                 = DCE_FP32
 //                 >= 2817                        conv_x3[_permk] -> three planes  fc_x3_256x128             = DCE_FP32
@@ -337,7 +338,7 @@ struct GateScope {
 //                 .. < h2_min_tiles (1281)       conv_h2_f32 (two fp16 terms)     fc_* fp32                 = DCE_FP32
 //                 .. <= 12288                    conv_h2 -> two fp16 terms + scale fc_h2_256x128[_out2]      fused two-term 128x64 + combine
 //                 > 12288                        (as above)                        (as above)                fc_h2_256x128 (h2 fp32) + tail
-enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16, H2, H2F32 };
+enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16, H2, H2F32, H2Bf16 };
 enum class Fc0 { F32, Gemv, X3, Bf16, H2 };
 enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16, FusedH2, H2 };
 struct Plan {
@@ -360,6 +361,9 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
         const bool pair = DCE_EXPERIMENTS && tu.x3_conv && tu.x3_pair && wino && !online && !c->want_feat && n >= tu.x3_pair_min;
         p.conv = pair ? Conv::PairBf16 : x3c ? Conv::X2Bf16 : Conv::WinoBf16;
         p.permk = pair ? 1 : (x3c && tu.x3_permk && !c->want_feat && c->fc1w_bf16p) ? ((DCE_EXPERIMENTS && tu.x3_persist && n >= tu.x3_persist_min) ? 2 : 1) : 0;
+        if (tu.bf16_conv_h2 && tu.x3_conv && tu.x3_bf16_terms == 2 && n >= tu.bf16_conv_h2_min && c->pkh2.w[0] && c->fc1w_bf16p && wino && !online && !c->want_feat && !pair) {
+            p.conv = Conv::H2Bf16; p.permk = 1;                       // conv results of fp32 grade from two fp16 terms with per-window scales (conv_h2.hip): configs[4] as written
+        }
         p.fc0 = Fc0::Bf16;
         p.fc3 = fc23_fused_ok(n, 1) ? Fc3::FusedBf16 : Fc3::Bf16;
         p.fused_rows = n;
@@ -447,6 +451,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
       case Conv::PairBf16:   HIP_TRY(c, launch_conv_x3p_bf16(src, zscore, n, c->pkx3, featb, st)); break;
       case Conv::H2:         HIP_TRY(c, launch_conv_h2(src, zscore, n, c->pkh2, c->feat3, c->feat_scale, st)); break;
       case Conv::H2F32:      HIP_TRY(c, launch_conv_h2_f32(src, zscore, n, c->pkh2, c->feat, st)); break;
+      case Conv::H2Bf16:     HIP_TRY(c, launch_conv_h2_bf16(src, zscore, n, c->pkh2, featb, st)); break;
       } }
     { Timer t(c, 1);
       switch (p.fc0) {
@@ -913,14 +918,15 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     ConvPackH2 h2pk{};
     int h2_fc_sw = 0, h2_fc2_sw = 0, h2_eW = 0, h2_eB = 0;
     bool h2_bad = false;
-    if (precision == DCE_FP32_F16X2) {
+    const bool h2_conv_only = precision == DCE_BF16_FC && c->tuning.bf16_conv_h2 && want_pair;      // DCE_BF16_FC with its conv stack on conv_h2.hip: the conv packs alone
+    if (precision == DCE_FP32_F16X2 || h2_conv_only) {
         for (int l = 0; l < 4 && !h2_bad; ++l) {
             const auto& w = c->host_w[2 * l]; const auto& b = c->host_w[2 * l + 1];
             h2pk.sw[l] = h2_weight_shift(w.data(), w.size());
             h2_bad = h2pk.sw[l] == INT_MIN;
             if (!h2_bad) { h2pk.smax[l] = h2_input_smax(b.data(), b.size(), h2pk.sw[l]); h2_bad = h2pk.smax[l] == INT_MIN; }
         }
-        if (!h2_bad) { h2_fc_sw = h2_weight_shift(c->host_w[8].data(), c->host_w[8].size()); h2_bad = h2_fc_sw == INT_MIN; }
+        if (!h2_bad && !h2_conv_only) { h2_fc_sw = h2_weight_shift(c->host_w[8].data(), c->host_w[8].size()); h2_bad = h2_fc_sw == INT_MIN; }
         for (int k = 9; k < 14; ++k)
             for (float x : c->host_w[k]) h2_bad |= !std::isfinite(x);
         h2pk.smax[4] = 180;                                           // the features: fc.0's bias is added after the scales are taken off (conv_h2.hip H2_SMAX)
@@ -929,9 +935,11 @@ int dce_finalize_weights(dce_ctx* c, int precision)
                 off_h2[l] = reserve((conv_h2_pack_halfs(l) + 1) / 2);
                 conv_h2_pack_host(l, c->host_w[2 * l].data(), h2pk.sw[l], reinterpret_cast<unsigned short*>(img.data() + off_h2[l]));
             }
+            if (!h2_conv_only) {
             off_h2fc = reserve(w1p.size());                           // two halfs per weight
             fc_h2_pack_host(w1p.data(), FC1, FEAT, h2_fc_sw, reinterpret_cast<unsigned short*>(img.data() + off_h2fc));
-            if (c->tuning.h2_fc3) {                                   // fc.3 on two-term operands: its weights likewise; h1's row-scale bound |h1| <= sqrt(K) max|feat| max_n ||W1_n||_2 + max|b1|
+            }
+            if (c->tuning.h2_fc3 && !h2_conv_only) {                                   // fc.3 on two-term operands: its weights likewise; h1's row-scale bound |h1| <= sqrt(K) max|feat| max_n ||W1_n||_2 + max|b1|
                 h2_fc2_sw = h2_weight_shift(c->host_w[10].data(), c->host_w[10].size());
                 off_h2fc2 = reserve(c->host_w[10].size());
                 fc_h2_pack_host(c->host_w[10].data(), FC2, FC1, h2_fc2_sw, reinterpret_cast<unsigned short*>(img.data() + off_h2fc2));
@@ -950,12 +958,12 @@ int dce_finalize_weights(dce_ctx* c, int precision)
                 if (!c->h1h) { HIP_TRY(c, hipMalloc(&c->h1h, rows * FC1 * 2 * sizeof(unsigned short))); HIP_TRY(c, hipMemset(c->h1h, 0, rows * FC1 * 2 * sizeof(unsigned short))); }
                 if (!c->h1_scale) { HIP_TRY(c, hipMalloc(&c->h1_scale, rows * sizeof(int))); HIP_TRY(c, hipMemset(c->h1_scale, 0, rows * sizeof(int))); }
             }
-            if (!c->feat3) {                                          // two fp16 terms per feature, padded by a tile of rows (fc_gemm_h2_pad_rows)
+            if (!c->feat3 && !h2_conv_only) {                         // two fp16 terms per feature, padded by a tile of rows (fc_gemm_h2_pad_rows)
                 const size_t halfs = std::max((size_t)(c->max_batch + 1) * FEAT * 3, (size_t)(c->max_batch + fc_gemm_h2_pad_rows()) * FEAT * 2);
                 HIP_TRY(c, hipMalloc(&c->feat3, halfs * sizeof(unsigned short)));
                 HIP_TRY(c, hipMemset(c->feat3, 0, halfs * sizeof(unsigned short)));
             }
-            if (!c->feat_scale) HIP_TRY(c, hipMalloc(&c->feat_scale, (size_t)(c->max_batch + 1) * sizeof(int)));
+            if (!c->feat_scale && !h2_conv_only) HIP_TRY(c, hipMalloc(&c->feat_scale, (size_t)(c->max_batch + 1) * sizeof(int)));
         }
     }
     if (c->d_weights) { HIP_TRY(c, hipFree(c->d_weights)); c->d_weights = nullptr; }
@@ -982,7 +990,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     c->h2_refused = precision == DCE_FP32_F16X2 && h2_bad;
     c->pkh2 = h2pk;
     for (int l = 0; l < 4; ++l) {
-        c->pkh2.w[l] = precision == DCE_FP32_F16X2 && !h2_bad ? reinterpret_cast<const unsigned short*>(c->d_weights + off_h2[l]) : nullptr;
+        c->pkh2.w[l] = (precision == DCE_FP32_F16X2 || h2_conv_only) && !h2_bad ? reinterpret_cast<const unsigned short*>(c->d_weights + off_h2[l]) : nullptr;
         c->pkh2.b[l] = c->pk.b[l];
     }
     c->fc1w_h2 = precision == DCE_FP32_F16X2 && !h2_bad ? reinterpret_cast<const unsigned short*>(c->d_weights + off_h2fc) : nullptr;

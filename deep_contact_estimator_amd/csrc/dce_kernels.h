@@ -46,6 +46,8 @@ struct Tuning {
     // -- DCE_BF16_FC
     bool bf16_stream = true;                                // 0: fc.0 / fc.3 at <= 256 windows on the 64x64 tile GEMM instead of fc_stream_bf16.hip
     long long x3_bf16_min = 1;                              // windows from which the mode's conv stack runs on conv_x3.hip (below: the fp32 kernels, features rounded on the store)
+    bool bf16_conv_h2 = true;                               // the mode's conv stack on conv_h2.hip -- two FP16 terms per operand with per-window scales: results of fp32 grade (22-bit operands) at three MFMAs per product, i.e. BASELINE configs[4] as it is written ("conv stays fp32") -- in launches of at least bf16_conv_h2_min windows; 0: conv_x3.hip on two bf16 terms (~17 bits) at every size
+    long long bf16_conv_h2_min = 257;                       // (up to 256 windows -- one-window calls, online pushes -- the mode stays on conv_x3.hip's two-term form, whose results do not depend on the size of the launch)
     int x3_bf16_terms = 2;                                  // 3: the mode's conv stack on three-term operands (six MFMAs per product) -- BASELINE configs[4] as written ("conv stays fp32"-grade)
     // -- DCE_FP32_SPLIT
     bool x3_conv = true;                                    // 0: keep the fp32 Winograd conv stack (three-plane feature store) instead of conv_x3.hip (both bf16-pipe precisions)
@@ -233,6 +235,8 @@ hipError_t init_conv_h2();
 hipError_t launch_conv_h2(const float* src, int zscore, int64_t n, const ConvPackH2& pk, unsigned short* feat2, int* feat_scale, hipStream_t st);
 //   ... with (n, 4736) fp32 features out, unscaled, in the reference's flatten order (mid-size batches: the FC layers on the fp32 kernels)
 hipError_t launch_conv_h2_f32(const float* src, int zscore, int64_t n, const ConvPackH2& pk, float* feat, hipStream_t st);
+//   ... with (n, 4736) bf16 features out (nearest-even of the unscaled values), K in the order t' * 128 + c: DCE_BF16_FC with the option bf16_conv_h2
+hipError_t launch_conv_h2_bf16(const float* src, int zscore, int64_t n, const ConvPackH2& pk, unsigned short* feat, hipStream_t st);
 //   ... with every layer's output and the features (n, 4736, the reference's flatten order) also written out in fp32, unscaled (dce_conv_layer_taps kernel 8)
 hipError_t launch_conv_h2_taps(const float* windows, int64_t n, const ConvPackH2& pk, unsigned short* feat2, int* feat_scale, float* feat32,
                                const LayerTaps& taps, hipStream_t st);

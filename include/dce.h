@@ -61,17 +61,20 @@ typedef enum dce_status {
 
 typedef enum dce_precision {
     DCE_FP32            = 0,   /* fp32 MFMA everywhere (exact fp32 fmaf chains) -- the headline path */
-    DCE_BF16_FC         = 1,   /* bf16 operands (fp32 accumulate) on fc.0 / fc.3, whose inputs -- the features and h1 -- are rounded to bf16
-                                  (8 significant bits).  The conv stack in front of that rounding runs on the bf16 matrix pipe with every
-                                  operand as TWO bf16 terms (~17 significant bits, three MFMAs per product; csrc/conv_x3.hip, NT = 2) at
-                                  every batch size: the mode's error against an fp64 evaluation is that of its bf16 FC operands, with
-                                  two terms as with three (option x3_bf16_terms=3; profiles/r4h_bf16_terms_audit.json).  CONTRACT of the
-                                  mode: logits within 6e-3 of the largest logit of an fp32 / fp64 evaluation (the price of 8-bit operands on
-                                  fc.0 / fc.3), and as close to the CPU restatement of the mode (oracle_forward_windows_bf16fc: the two
-                                  differ where a value sits on a bf16 rounding boundary -- <= 3e-3 on every fixture and fuzz set, 4.2e-3
-                                  worst over 1e6 logits); argmax equal wherever the top-2 margin exceeds 1e-2 of the largest logit.
-                                  BASELINE configs[4] as written ("bf16 on the FC layers, conv stays fp32") is the option
-                                  x3_bf16_terms=3 -- fp32-grade conv results, band 2e-3; bench.py reports both figures */
+    DCE_BF16_FC         = 1,   /* BASELINE configs[4]: bf16 operands (fp32 accumulate) on fc.0 / fc.3, whose inputs -- the features and h1 -- are
+                                  rounded to bf16 (8 significant bits); the conv stack in front of that rounding keeps results of fp32 grade.
+                                  In launches of more than 256 windows it runs on the fp16 matrix pipe with every operand as TWO fp16 terms of
+                                  the value times a per-window power of two (22 significant bits, three MFMAs per product; csrc/conv_h2.hip,
+                                  see DCE_FP32_F16X2); up to 256 windows (one-window calls, online pushes) and in the taps on two bf16 terms
+                                  (~17 bits; csrc/conv_x3.hip, NT = 2), whose results do not depend on the size of the launch -- the mode's
+                                  error against an fp64 evaluation is that of its bf16 FC operands either way (profiles/r4h_bf16_terms_audit.json).
+                                  Options: bf16_conv_h2=0 (two bf16 terms at every size: the default of rounds 4-5), x3_bf16_terms=3 (three
+                                  bf16 terms, six MFMAs per product: round 3).  CONTRACT of the mode: logits within 6e-3 of the largest logit
+                                  of an fp32 / fp64 evaluation (the price of 8-bit operands on fc.0 / fc.3), and as close to the CPU
+                                  restatement of the mode (oracle_forward_windows_bf16fc: the two differ where a value sits on a bf16
+                                  rounding boundary -- <= 3e-3 on every fixture and fuzz set, 4.2e-3 worst over 1e6 logits with the two-term
+                                  bf16 stack, <= 2e-3 with the fp32-grade ones); argmax equal wherever the top-2 margin exceeds 1e-2 of the
+                                  largest logit; bench.py reports the step with all three conv stacks */
     DCE_FP32_SPLIT      = 2,   /* fp32 results with the conv stack and fc.0 of chip-filling batches on the bf16 matrix pipe: every fp32
                                   operand enters as three bf16 terms (a = a1 + a2 + a3 exactly), six bf16 MFMAs per product, fp32
                                   accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; the conv stack from 128
@@ -97,7 +100,7 @@ typedef enum dce_precision {
  * every kernel family).  The two other precisions pick kernels by the number of windows in a launch (a call of more than max_batch
  * windows is several launches: the last one may fall into another regime).  DCE_FP32_SPLIT: below 128 windows the DCE_FP32 kernels, from
  * 128 the three-term conv stack, from 2817 the split fc.0 -- the same window may differ in its last bits between a small and a large call
- * (both within the fp32 tolerance of the reference, <= 2e-5 of the largest logit apart).  DCE_BF16_FC: one conv kernel at every size, FC
+ * (both within the fp32 tolerance of the reference, <= 2e-5 of the largest logit apart).  DCE_BF16_FC: one conv kernel up to 256 windows, another above (both far inside the mode's band), FC
  * kernels by size -- up to 256 windows per launch one weight-streaming kernel whose results do not depend on the number of windows (an
  * online push gives the bits of a sequence call in launches of <= 256), above that tile / phased GEMMs with other fp32 summation orders:
  * an h1 value at a bf16 rounding boundary may round the other way, <= 2e-2 of the largest logit.  DCE_FP32_F16X2: below 128 windows the

@@ -111,7 +111,7 @@ def test_tapped_kernels_produce_the_product_features(model_of):
 # ------------------------------------------------------------------------------------------------
 # batch sizes chosen per bf16 kernel: phased 256x128 + fused 128x64 (4096), phased 128x64 (3000 / 700), 64x64 tiles (300), the
 # weight-streaming kernel with one, two and four 64-window blocks (1 / 40, 100, 256), a ragged size past a round (4100)
-@pytest.mark.parametrize("terms", [2, 3])                           # the mode as it ships / BASELINE configs[4] as written (fp32-grade conv results: the tighter band)
+@pytest.mark.parametrize("terms", ["h2", 2, 3])                     # the mode as it ships (conv results of fp32 grade from two fp16 terms with per-window scales above 256 windows: BASELINE configs[4] as written) / two bf16 terms at every size (bf16_conv_h2=0) / three bf16 terms
 @pytest.mark.parametrize("n", [1, 40, 100, 256, 300, 700, 3000, 4096, 4100])
 def test_bf16_fc_vs_independent_restatement(n, terms, model_of, orc):
     """DCE_BF16_FC (BASELINE configs[4]: the reference's fc layers, src/contact_cnn.py:47-58, with fc.0 / fc.3 on bf16
@@ -127,9 +127,9 @@ def test_bf16_fc_vs_independent_restatement(n, terms, model_of, orc):
     from deep_contact_estimator_amd import synth
     sd = synth.make_state_dict(1, "uniform")
     x = np.random.default_rng(11 + n).standard_normal((n, 150, 54), dtype=np.float32)
-    if terms == 3 and n not in (1, 300, 4096, 4100):
-        pytest.skip("the three-term form of the mode is covered at one size per FC kernel family")
-    m16 = model_of(precision="bf16_fc", max_batch=8192, tune={"x3_bf16_terms": terms})
+    if terms != "h2" and n not in (1, 300, 4096, 4100):
+        pytest.skip("the options are covered at one size per FC kernel family")
+    m16 = model_of(precision="bf16_fc", max_batch=8192, tune=None if terms == "h2" else {"bf16_conv_h2": 0} if terms == 2 else {"x3_bf16_terms": 3})
     m32 = model_of(max_batch=8192)
     nt = min(n, 512)                                               # taps on a bounded slice keep the CPU side in seconds
     sl = slice(n - nt, n)                                          # ... the LAST rows: partial tiles / the peeled remainder
@@ -175,6 +175,7 @@ def test_bf16_fc_vs_independent_restatement(n, terms, model_of, orc):
     # (5) end to end: predict() is the same bits as the tap run, and stays within the accumulated rounding-boundary
     # band of the restatement (a few 1-ulp differences in feat / h1 move a logit by ~1e-4 of the logit scale)
     out = m16.predict(x)
+    if terms == "h2": assert m16.last_plan()[0] == ("conv_h2_bf16_permk" if n > 256 else "conv_x2_bf16_permk"), m16.last_plan()
     ref = orc.Oracle(sd, bf16_fc=True).forward_windows(x[sl])
     scale = np.abs(ref["logits"]).max()
     if m16.last_plan()[0].endswith("_permk"):

@@ -39,7 +39,7 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs, or
         flips = out["pred"] != g["pred"]
         assert err < 2e-2 * scale, (err, scale)
         assert flips.mean() < 0.02 and (g["margin"][flips] < 4 * err + 1e-6).all()
-        assert plan[0].startswith("conv_x2_bf16") and "fc_phased256x128" in plan, plan      # two-term operands: three MFMAs per product
+        assert plan[0] == "conv_h2_bf16_permk" and "fc_phased256x128" in plan, plan         # conv results of fp32 grade (two fp16 terms, per-window scales), bf16 FC
     else:
         # Against the fp64-statistics evaluation (the oracle) on the same rows: the contract as stated, every logit.  Against the
         # reference's own numbers: the reference z-scores in fp32 and on this sequence sits up to 1.15 bounds from that evaluation
@@ -62,7 +62,7 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs, or
 
 @pytest.mark.parametrize("n", [128, 515, 4096, 4099])
 def test_bf16_fc_conv_stack_on_two_term_operands(n, orc):
-    """DCE_BF16_FC's conv stack by default: conv_x3.hip with NT = 2 -- operands as two bf16 terms, a1 b1 + a1 b2 + a2 b1 (three MFMAs per
+    """DCE_BF16_FC's conv stack up to 256 windows per launch, in the online pushes and with the option bf16_conv_h2=0: conv_x3.hip with NT = 2 -- operands as two bf16 terms, a1 b1 + a1 b2 + a2 b1 (three MFMAs per
     product, ~17 significant bits), two LDS planes, three workgroups per CU -- against the same kernel on three-term operands
     (option x3_bf16_terms=3, fp32-grade).  The features leave rounded to bf16 (8 bits), so the two may differ only where a value sits
     within ~2^-17 of a rounding boundary: few values, one bf16 ulp each; the logits agree far inside the mode's band and the error
@@ -70,7 +70,7 @@ def test_bf16_fc_conv_stack_on_two_term_operands(n, orc):
     order), the z-score entry."""
     from deep_contact_estimator_amd import synth
     sd = synth.make_state_dict(1, "uniform")
-    a = _model("bf16_fc"); a.load_state_dict(sd).eval()
+    a = _model("bf16_fc", tune={"bf16_conv_h2": 0}); a.load_state_dict(sd).eval()
     b = _model("bf16_fc", tune={"x3_bf16_terms": 3}); b.load_state_dict(sd).eval()
     x = np.random.default_rng(50 + n).standard_normal((n, 150, 54), dtype=np.float32)
     x[n // 2, 3, 7] = np.inf
