@@ -766,7 +766,7 @@ def main():
                 try:
                     from deep_contact_estimator_amd import build as dce_build
                     pmc = json.load(open(pmc_path))
-                    ent = pmc.get(dom, {}) if args.precision == "fp32" else pmc.get({"conv_stack": "conv_x3", "fc1_gemm": "fc1_gemm_bf16", "fc2_gemm": "fc2_gemm_bf16"}.get(dom, dom) + "@bf16_fc", {})
+                    ent = pmc.get(dom, {}) if args.precision == "fp32" else pmc.get({"conv_stack": "conv_h2" if "conv_h2@bf16_fc" in pmc else "conv_x3", "fc1_gemm": "fc1_gemm_bf16", "fc2_gemm": "fc2_gemm_bf16"}.get(dom, dom) + "@bf16_fc", {})
                     traffic = ent.get("hbm_bytes_per_launch")
                     # stale = the counters were collected on a library built from other sources than the one timed here
                     prof_hash, here_hash = pmc.get("_meta", {}).get("source_hash"), dce_build.built_hash()

@@ -83,7 +83,7 @@ def main(tag):
         lines += ["", "bf16-FC mode (`--precision bf16_fc`), same step:", "",
                   "| kernel | MFMA busy | LDS busy: SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE/8) | bank-conflict cycles / LDS active | LDS instructions per launch | L2 hit rate | TCC_REQ |",
                   "|---|---|---|---|---|---|---|"]
-        for k in ("conv_stack", "conv_x3", "fc1_gemm_bf16", "fc2_gemm_bf16"):
+        for k in ("conv_stack", "conv_h2", "conv_x3", "fc1_gemm_bf16", "fc2_gemm_bf16"):      # (conv_h2: the mode's conv stack since the end of round 5; conv_x3: before, and with bf16_conv_h2=0)
             c = b16.get(k)
             if not c or "GRBM_GUI_ACTIVE" not in c:
                 continue
@@ -95,7 +95,7 @@ def main(tag):
                          f"{c.get('SQ_INSTS_LDS', 0):.3g} | {hit:.3f} | {c.get('TCC_REQ', 0):.3g} |")
     # HBM traffic of the bf16-FC step's kernels against their algorithmic bytes (windows in + bf16 features out; bf16 features + bf16 W1 in, bf16 h1
     # out; bf16 h1 + bf16 W2 + W3 in, chunk sums out)
-    algo16 = {"conv_x3": (150 * 54 * 4 + 4736 * 2) * B + 2 * (96768 * 3) + 4 * 384, "fc1_gemm_bf16": (4736 * 2 + 2048 * 2) * B + 2 * 2048 * 4736 + 4 * 2048,
+    algo16 = {"conv_h2": (150 * 54 * 4 + 4736 * 2) * B + 2 * (96768 * 2) + 4 * 384, "conv_x3": (150 * 54 * 4 + 4736 * 2) * B + 2 * (96768 * 3) + 4 * 384, "fc1_gemm_bf16": (4736 * 2 + 2048 * 2) * B + 2 * 2048 * 4736 + 4 * 2048,
               "fc2_gemm_bf16": (2048 * 2 + 8 * 64) * B + 2 * 512 * 2048 + 4 * (512 + 16 * 512)}
     if any("FETCH_SIZE" in c for c in b16.values()):
         lines += ["", "| kernel (bf16-FC step) | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes/launch (2*FETCH+WRITE)*1024 | algorithmic bytes/launch | ratio |", "|---|---|---|---|---|---|"]
