@@ -15,7 +15,7 @@ from oracle import oracle as orc
 
 TRIALS = int(os.environ.get("TRIALS", 60))
 rng = np.random.default_rng(int(os.environ.get("SEED", 91)))
-edges = [1, 2, 8, 9, 30, 64, 65, 127, 128, 129, 255, 256, 511, 512, 700, 1023, 1025, 2048, 3000, 3072, 3333, 4096, 4099, 5003]
+edges = [1, 2, 8, 9, 30, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512, 700, 1023, 1025, 2048, 3000, 3072, 3333, 4096, 4099, 5003]
 worst, flips, total, plans = 0.0, 0, 0, {}
 t0 = time.time()
 for trial in range(TRIALS):
