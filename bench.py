@@ -762,11 +762,13 @@ def main():
             kd = kernels[dom]
             traffic, traffic_src, traffic_stale = None, None, None
             pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc_path) and args.precision in ("fp32", "bf16_fc"):      # counters exist for the fp32 kernels and for the bf16-FC step's
+            if os.path.exists(pmc_path) and args.precision in ("fp32", "bf16_fc", "fp32_f16x2"):      # counters exist for the fp32 kernels, for the bf16-FC step's and for the two-term fp16 step's
                 try:
                     from deep_contact_estimator_amd import build as dce_build
                     pmc = json.load(open(pmc_path))
-                    ent = pmc.get(dom, {}) if args.precision == "fp32" else pmc.get({"conv_stack": "conv_h2" if "conv_h2@bf16_fc" in pmc else "conv_x3", "fc1_gemm": "fc1_gemm_bf16", "fc2_gemm": "fc2_gemm_bf16"}.get(dom, dom) + "@bf16_fc", {})
+                    if args.precision == "fp32": ent = pmc.get(dom, {})
+                    elif args.precision == "fp32_f16x2": ent = pmc.get(dom + "@fp32_f16x2", {})
+                    else: ent = pmc.get({"conv_stack": "conv_h2" if "conv_h2@bf16_fc" in pmc else "conv_x3", "fc1_gemm": "fc1_gemm_bf16", "fc2_gemm": "fc2_gemm_bf16"}.get(dom, dom) + "@bf16_fc", {})
                     traffic = ent.get("hbm_bytes_per_launch")
                     # stale = the counters were collected on a library built from other sources than the one timed here
                     prof_hash, here_hash = pmc.get("_meta", {}).get("source_hash"), dce_build.built_hash()

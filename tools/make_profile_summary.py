@@ -106,6 +106,31 @@ def main(tag):
             hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
             lines.append(f"| {k} | {c['FETCH_SIZE']:.0f} | {c['WRITE_SIZE']:.0f} | {hbm / 1e6:.1f} MB | {algo / 1e6:.1f} MB | {hbm / algo:.2f} |")
             latest[k + "@bf16_fc"] = {"hbm_bytes_per_launch": hbm, "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"], "algorithmic_bytes_per_launch": algo, "profile": tag}
+    # fp32_f16x2 (tools/profile_f16x2.sh <tag>_f16x2, when it was run on the same build): HBM traffic of the two-term fp16 step's kernels against their
+    # algorithmic bytes (windows in + two-term features and scales out; two-term features and W1 in, two-term h1 and scales out; two-term h1 and W2 + W3 in, chunk sums out)
+    h2 = {}
+    for part in ("fetch", "write", "sq"):
+        p = os.path.join(out, f"{tag}_f16x2_pmc_{part}", f"{tag}_f16x2_counter_collection.csv")
+        if os.path.exists(p):
+            for k, v in pmc_summary.main([p]).items():
+                h2.setdefault(k, {}).update(v)
+    hp2 = os.path.join(out, f"{tag}_f16x2_source_hash.txt")
+    same_build = os.path.exists(hp2) and os.path.exists(os.path.join(out, f"{tag}_source_hash.txt")) and open(hp2).read().strip() == open(os.path.join(out, f"{tag}_source_hash.txt")).read().strip()
+    algo_h2 = {"conv_h2": ("conv_stack", (150 * 54 * 4 + 4736 * 4 + 4) * B + 2 * (96768 * 2) + 4 * 384),
+               "fc1_gemm_h2": ("fc1_gemm", (4736 * 4 + 2048 * 4 + 4) * B + 4 * 2048 * 4736 + 4 * 2048),
+               "fc1_gemm_h2k": ("fc2_gemm", (2048 * 4 + 8 * 64) * B + 4 * 512 * 2048 + 4 * (512 + 16 * 512))}
+    if same_build and any("FETCH_SIZE" in c for c in h2.values()):
+        lines += ["", "fp32_f16x2 (`--precision fp32_f16x2`), same step, same build:", "",
+                  "| kernel | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes/launch (2*FETCH+WRITE)*1024 | algorithmic bytes/launch | ratio | MFMA busy |", "|---|---|---|---|---|---|---|"]
+        for k, (slot, algo) in algo_h2.items():
+            c = h2.get(k)
+            if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                continue
+            hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+            busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (c["GRBM_GUI_ACTIVE"] / 8) if "GRBM_GUI_ACTIVE" in c else float("nan")
+            lines.append(f"| {k} | {c['FETCH_SIZE']:.0f} | {c['WRITE_SIZE']:.0f} | {hbm / 1e6:.1f} MB | {algo / 1e6:.1f} MB | {hbm / algo:.2f} | {busy:.3f} |")
+            latest[slot + "@fp32_f16x2"] = {"hbm_bytes_per_launch": hbm, "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"], "algorithmic_bytes_per_launch": algo,
+                                           "mfma_busy_frac": busy, "profile": tag + "_f16x2"}
     # the build these counters were taken on (tools/profile_gpu.sh records the hash of the .so's sources on the box):
     # bench.py marks roofline.traffic stale when the library it times was built from other sources
     hp = os.path.join(out, f"{tag}_source_hash.txt")
