@@ -575,7 +575,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the profiled pass (no roofline block)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "fp32_split", "fp32_f16x2"],
                     help="fp32 = the headline (exact fp32 MFMA); bf16_fc = BASELINE configs[4] as the main workload; "
-                         "fp32_split = fc.0 on three-term bf16 operands (fp32 results on the bf16 matrix pipe)")
+                         "fp32_split = conv stack and fc.0 on three-term bf16 operands (fp32 results on the bf16 matrix pipe, range-guarded); "
+                         "fp32_f16x2 = conv stack, fc.0 and fc.3 on two fp16 terms per operand with per-window scales (the fp32 tolerance, no guard needed)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
