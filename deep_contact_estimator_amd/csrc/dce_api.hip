@@ -66,7 +66,7 @@ const TuneKey kTuneKeys[] = {
     TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
     TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_fc3, 'b'), TK(h2_min_tiles, 'i'),
     TKX(bf16_k32, 'b'), TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
-    TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(h2_ksplit, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
+    TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(h2_ksplit, 'b'), TKX(bf16_fc3_ksplit, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
 };
 #undef TK
 #undef TKX
@@ -340,7 +340,7 @@ struct GateScope {
 //                 > 12288                        (as above)                        (as above)                fc_h2_256x128 (h2 fp32) + tail
 enum class Conv { WinoF32, WinoBf16, WinoPlanes, X3Planes, X3F32, X2Bf16, PairPlanes, PairBf16, H2, H2F32, H2Bf16 };
 enum class Fc0 { F32, Gemv, X3, Bf16, H2 };
-enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16, FusedH2, H2 };
+enum class Fc3 { F32, Gemv, Fused, FusedX3, Bf16, FusedBf16, FusedBf16K, FusedH2, H2 };
 struct Plan {
     Conv conv; int permk;                 // permk: features (and fc.0's weights) in the K order t' * 128 + c; 2: from persistent workgroups (experiments)
     Fc0 fc0; bool split3;                 // split3: fp32 features split by a kernel of their own in front of fc_gemm_x3 (taps, x3_unfused)
@@ -365,7 +365,7 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
             p.conv = Conv::H2Bf16; p.permk = 1;                       // conv results of fp32 grade from two fp16 terms with per-window scales (conv_h2.hip): configs[4] as written
         }
         p.fc0 = Fc0::Bf16;
-        p.fc3 = fc23_fused_ok(n, 1) ? Fc3::FusedBf16 : Fc3::Bf16;
+        p.fc3 = fc23_fused_ok(n, 1) ? (DCE_EXPERIMENTS && tu.bf16_fc3_ksplit && n + 128 <= 2 * c->max_batch ? Fc3::FusedBf16K : Fc3::FusedBf16) : Fc3::Bf16;
         p.fused_rows = n;
         return p;
     }
@@ -478,6 +478,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
       case Fc3::FusedX3: HIP_TRY(c, launch_fc23_fused_x3(c->h1p, c->fc2w_x3, c->fc2b, c->fc3w, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
       case Fc3::H2: HIP_TRY(c, launch_fc_gemm_h2(c->h1h, c->h1_scale, c->fc2w_h2, c->fc2_sw, c->fc2b, c->h2, n, FC2, FC1, 1, st)); break;
       case Fc3::FusedH2: HIP_TRY(c, launch_fc23_fused_h2(c->h1h, c->h1_scale, c->fc2w_h2, c->fc2_sw, c->fc2b, c->fc3w, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
+      case Fc3::FusedBf16K: HIP_TRY(c, launch_fc23_fused_bf16k(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
       case Fc3::FusedBf16: HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w_bf16, c->fc2b, c->fc3w, 1, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, n, st)); break;
       case Fc3::Fused:
           HIP_TRY(c, launch_fc23_fused(c->h1, c->fc2w, c->fc2b, c->fc3w, 0, c->part, c->max_batch, c->want_h2 ? c->h2 : nullptr, nf, st));
@@ -485,7 +486,7 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
           break;
       } }
     { Timer t(c, 3);
-      if (p.fc3 == Fc3::Fused || p.fc3 == Fc3::FusedX3 || p.fc3 == Fc3::FusedBf16 || p.fc3 == Fc3::FusedH2) {
+      if (p.fc3 == Fc3::Fused || p.fc3 == Fc3::FusedX3 || p.fc3 == Fc3::FusedBf16 || p.fc3 == Fc3::FusedBf16K || p.fc3 == Fc3::FusedH2) {
           HIP_TRY(c, launch_fc6_combine(c->part, c->max_batch, c->fc3b, nf, logits, pred, contacts, st, packed));
           if (nf < n) HIP_TRY(c, launch_fc3_tail(c->h2 + nf * FC2, c->fc3w, c->fc3b, n - nf, logits ? logits + nf * NCLS : nullptr, pred ? pred + nf : nullptr,
                                                  contacts ? contacts + nf * 4 : nullptr, st, nullptr, 0, nullptr, packed ? packed + nf * PACKED_ROW : nullptr));

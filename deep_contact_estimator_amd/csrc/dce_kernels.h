@@ -67,6 +67,7 @@ struct Tuning {
     bool x3_persist = false, x3_pair = false;
     long long x3_persist_min = 1024, x3_pair_min = 1024;
     bool conv_direct = false;                               // the direct-form conv stack of round 1 (conv_stack.hip)
+    bool bf16_fc3_ksplit = false;                           // DCE_BF16_FC: the fused fc.3 + fc.6 on fc_gemm_h2k_kernel<H2KFc3, FUSE6, BF16> (K-tiles dealt out between the wave groups, 128-k phases) instead of fc_gemm_phased.hip's 128x64 tile (round 5: measured no faster, 17.5 against 17.8 us)
     bool h2_ksplit = false;                                 // DCE_FP32_F16X2: fc.0's K-tiles dealt out between the two wave groups (fc_gemm_h2k_kernel: 64 x 128 wave tiles, 48-MFMA phases, three LDS buffers; round 5: measured 5 % slower)
     bool one_per_cu = false, trace_wino1 = false;           // trace builds
 };
@@ -249,6 +250,8 @@ hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, con
                              int64_t M, int N, int K, int relu, hipStream_t st, unsigned short* H1 = nullptr, int* h1_scale = nullptr, int eW = 0, int eB = 0);
 // fc.3 + fc.6 chunk sums on two-term fp16 operands (the 128 x 64 tile of the K-split kernel with the fused fc.6 epilogue)
 bool       fc23_h2_ok(int64_t M);
+//   ... and the bf16-FC mode's fc.3 on the same kernel, one bf16 term per operand (h1, W2 row-major bf16)
+hipError_t launch_fc23_fused_bf16k(const void* h1, const void* W2, const float* b2, const float* W3, float* part, int64_t part_rows, float* h2_out, int64_t M, hipStream_t st);
 hipError_t launch_fc23_fused_h2(const unsigned short* h1, const int* h1_scale, const unsigned short* W2p, int sw, const float* b2, const float* W3,
                                 float* part, int64_t part_rows, float* h2_out, int64_t M, hipStream_t st);
 

@@ -22,6 +22,7 @@ namespace dce {
 
 typedef float h2_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h2_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 h2_bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef H2_TRACE
 #define H2_TRACE 0
@@ -286,7 +287,9 @@ template <int BM_, int BN_, int AB_, int BB_, int NSUB_> struct H2KCfg {
 using H2KFc0 = H2KCfg<256, 128, 2, 4, 1>;
 using H2KFc3 = H2KCfg<128, 64, 1, 2, 2>;
 
-template <class Cfg, bool FUSE6>
+//   BF16 (the bf16-FC mode's fc.3, option bf16_fc3_ksplit): ONE bf16 term per operand -- a row's 128 bytes are 64 k of it, a phase is NSUB x 64 k,
+//   one MFMA per fragment pair, no scales -- on the same schedule; h1 and W2 are the mode's row-major bf16 arrays
+template <class Cfg, bool FUSE6, bool BF16 = false>
 __global__ __launch_bounds__(512, 2)
 void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __restrict__ row_scale, const unsigned short* __restrict__ W2, int sw,
                         const float* __restrict__ bias, float* __restrict__ C,
@@ -315,7 +318,7 @@ void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __rest
 
     // (pieces: ONE per-lane offset for the A panel and one for the W panel -- a piece's 8 rows start 32 rows behind the previous one's, which moves
     //  the wave-uniform base, not the lanes; rows past M are READ (the operand's buffer is padded by a tile of rows) and never stored)
-    const size_t rowb = (size_t)K * 4;
+    const size_t rowb = (size_t)K * (BF16 ? 2 : 4);
     unsigned voffA, voffW;
     {
         const int lr = lane >> 3, slot = lane & 7, w4 = wid & 3;
@@ -339,16 +342,14 @@ void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __rest
     };
 
     const int swz = h2_swz(i);
-    unsigned fa[2][2], fb[2][2];                                          // [term][kq]: byte offsets of block 0, sub-tile 0, buffer 0
+    unsigned fa[4], fb[4];                                                // byte offsets of block 0, sub-tile 0, buffer 0, for slot pair c = 2 term + kq (two fp16 terms) / c = kq of 64 k (BF16): logical column 2 c + h
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int kq = 0; kq < 2; ++kq) {
-            const int o = 16 * ((4 * p + 2 * kq + h) ^ swz);
-            fa[p][kq] = (wm + i) * ROWB + o;
-            fb[p][kq] = (BM + i) * ROWB + o;
-            asm volatile("" : "+v"(fa[p][kq]), "+v"(fb[p][kq]));
-        }
+    for (int c = 0; c < 4; ++c) {
+        const int o = 16 * ((2 * c + h) ^ swz);
+        fa[c] = (wm + i) * ROWB + o;
+        fb[c] = (BM + i) * ROWB + o;
+        asm volatile("" : "+v"(fa[c]), "+v"(fb[c]));
+    }
 
     h2_f32x16 acc[AB][BB];
 #pragma unroll
@@ -358,37 +359,48 @@ void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 af[NSUB][2][2][AB], bf[NSUB][2][2][BB];                        // [sub-tile][kq][term][block]
+    float4 af[NSUB][4][AB], bf[NSUB][4][BB];                              // [sub-tile][slot pair c][block]
     auto load_frags = [&](unsigned bo) {                                  // bo: the buffer's byte offset
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-            for (int kq = 0; kq < 2; ++kq)
+            for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int blk = 0; blk < AB; ++blk) af[sub][c][blk] = *reinterpret_cast<const float4*>(h2_smem + (fa[c] + bo) + sub * SUBT + blk * 32 * ROWB);
 #pragma unroll
-                    for (int blk = 0; blk < AB; ++blk) af[sub][kq][p][blk] = *reinterpret_cast<const float4*>(h2_smem + (fa[p][kq] + bo) + sub * SUBT + blk * 32 * ROWB);
-#pragma unroll
-                    for (int blk = 0; blk < BB; ++blk) bf[sub][kq][p][blk] = *reinterpret_cast<const float4*>(h2_smem + (fb[p][kq] + bo) + sub * SUBT + blk * 32 * ROWB);
-                }
+                for (int blk = 0; blk < BB; ++blk) bf[sub][c][blk] = *reinterpret_cast<const float4*>(h2_smem + (fb[c] + bo) + sub * SUBT + blk * 32 * ROWB);
+            }
     };
     auto math = [&]() {
-        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+        if constexpr (BF16) {
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
+            for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-            for (int kq = 0; kq < 2; ++kq)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int a = 0; a < AB; ++a)
 #pragma unroll
                         for (int b = 0; b < BB; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                __builtin_bit_cast(h2_f16x8, af[sub][kq][TA[t]][a]), __builtin_bit_cast(h2_f16x8, bf[sub][kq][TB[t]][b]), acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(h2_bf16x8, af[sub][c][a]), __builtin_bit_cast(h2_bf16x8, bf[sub][c][b]), acc[a][b], 0, 0, 0);
+        } else {
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+                for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int a = 0; a < AB; ++a)
+#pragma unroll
+                            for (int b = 0; b < BB; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    __builtin_bit_cast(h2_f16x8, af[sub][2 * TA[t] + kq][a]), __builtin_bit_cast(h2_f16x8, bf[sub][2 * TB[t] + kq][b]), acc[a][b], 0, 0, 0);
+        }
     };
 
-    const int KT = K / Cfg::KP;                                           // even, >= 4 (checked by the launchers)
+    const int KT = K / (BF16 ? 2 * Cfg::KP : Cfg::KP);                    // even, >= 4 (checked by the launchers); a BF16 phase holds twice the k
     constexpr size_t KSTEP = (size_t)ROWB * NSUB;
     // Phase p = 0 .. KT: group p & 1 issues tile p + 2 and reads tile p's fragments, the other group multiplies tile p - 1.
     //   WAR: the buffer of tile p + 2 held tile p - 1, read in phase p - 1, which ended with lgkmcnt(0) + barrier;
@@ -450,7 +462,7 @@ void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __rest
             for (int r = 0; r < 16; ++r) {
                 const int row_l = wm + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int row = m0 + row_l < M ? m0 + row_l : M - 1;
-                float v = __builtin_ldexpf(acc[0][G][r], -(row_scale[row] + sw)) + bv;
+                float v = (BF16 ? acc[0][G][r] : __builtin_ldexpf(acc[0][G][r], -(row_scale[row] + sw))) + bv;
                 v = v < 0.f ? 0.f : v;                       // fc.3's ReLU; keeps NaN like torch
                 ht[row_l * HLD + col_l] = v;
                 if (C && m0 + row_l < M) C[(size_t)(m0 + row_l) * N + n0 + col_l] = v;
@@ -471,7 +483,7 @@ void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __rest
                     for (int r = 0; r < 16; ++r) {
                         int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
                         if (!decltype(full)::value && row >= M) row = M - 1;
-                        ex[r] = -(row_scale[row] + sw);
+                        ex[r] = BF16 ? 0 : -(row_scale[row] + sw);
                     }
 #pragma unroll
                     for (int b = 0; b < HB; ++b) {
@@ -503,6 +515,7 @@ hipError_t init_fc_gemm_h2()
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel<H2KFc3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2KFc3::LDS)) != hipSuccess) return e;
 #if DCE_EXPERIMENTS
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel<H2KFc0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, H2KFc0::LDS)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel<H2KFc3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2KFc3::LDS)) != hipSuccess) return e;
 #endif
     return hipSuccess;
 }
@@ -563,6 +576,29 @@ hipError_t launch_fc23_fused_h2(const unsigned short* h1, const int* h1_scale, c
     hipLaunchKernelGGL((fc_gemm_h2k_kernel<H2KFc3, true>), dim3(grid), dim3(512), H2KFc3::LDS, st, h1, h1_scale, W2p, sw, b2, h2_out,
                        (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
     return hipGetLastError();
+}
+
+// (experiments build, option bf16_fc3_ksplit=1: measured NO faster than fc_gemm_phased.hip's fused 128 x 64 tile -- 17.5 against 17.8 us per 4096
+// windows, tools/ab_bf16_fc3.sh: 3.4 us of MFMAs under ~14 us of per-tile chain, first-tile latency, fc.6 epilogue and launch, whatever the schedule)
+// the bf16-FC mode's fc.3 + fc.6 chunk sums on the same kernel (one bf16 term per operand): h1 (M + pad, 2048) and W2 (512, 2048)
+// row-major bf16; rows of h1 past M are read (the mode's h1 buffer is fp32-sized: twice what its bf16 rows need) and never used
+hipError_t launch_fc23_fused_bf16k(const void* h1, const void* W2, const float* b2, const float* W3, float* part, int64_t part_rows, float* h2_out, int64_t M, hipStream_t st)
+{
+    static_assert(FC1 % (4 * H2KFc3::KP) == 0 && FC1 / (2 * H2KFc3::KP) >= 4, "an even number of 128-k phases");
+    if (M <= 0) return hipSuccess;
+    const int mtiles = (int)((M + H2KFc3::BM - 1) / H2KFc3::BM), ntiles = FC2 / H2KFc3::BN;
+    const int sn_log2 = 2, sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
+    const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
+    const int grid = ((nsuper + 7) / 8) * 8 * 32;
+#if DCE_EXPERIMENTS
+    plan_note("fc23_fused_bf16k_128x64");
+    hipLaunchKernelGGL((fc_gemm_h2k_kernel<H2KFc3, true, true>), dim3(grid), dim3(512), H2KFc3::LDS, st, static_cast<const unsigned short*>(h1), nullptr,
+                       static_cast<const unsigned short*>(W2), 0, b2, h2_out, (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
+    return hipGetLastError();
+#else
+    (void)h1; (void)W2; (void)b2; (void)W3; (void)part; (void)part_rows; (void)h2_out; (void)st; (void)grid;
+    return hipErrorInvalidValue;
+#endif
 }
 
 }  // namespace dce

@@ -379,3 +379,23 @@ def test_h1_row_scale_bound_is_safe_where_it_is_tight(kind, orc):
     tol_ok(out["logits"][rows], ref["logits"], kind)
     _argmax_ok(out["pred"][rows], ref["logits"], ref["pred"])
     m.close()
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("n", [3072, 4100])
+def test_bf16_fc3_with_the_k_tiles_dealt_out_between_the_wave_groups(n):
+    """(experiments build: measured no faster.)  The bf16-FC mode's fused fc.3 + fc.6 on fc_gemm_h2k_kernel<H2KFc3, FUSE6, BF16> against
+    fc_gemm_phased.hip's fused 128 x 64 tile: the same bf16 products in another fp32 association -- fp32 rounding apart, a NaN window contained."""
+    from deep_contact_estimator_amd import contact_cnn, synth
+    sd = synth.make_state_dict(1, "uniform")
+    a = contact_cnn(device=0, max_batch=8192, precision="bf16_fc"); a.load_state_dict(sd).eval()
+    b = contact_cnn(device=0, max_batch=8192, precision="bf16_fc", tune={"bf16_fc3_ksplit": 1}); b.load_state_dict(sd).eval()
+    x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
+    x[n - 1, 3, 3] = np.nan
+    ra, rb = a.predict(x), b.predict(x)
+    assert "fc23_fused_bf16k_128x64" in b.last_plan() and "fc23_fused_bf16k_128x64" not in a.last_plan(), (a.last_plan(), b.last_plan())
+    assert np.isnan(rb["logits"][n - 1]).all() and rb["pred"][n - 1] == 0
+    scale = np.abs(ra["logits"][:n - 1]).max()
+    assert np.abs(ra["logits"][:n - 1] - rb["logits"][:n - 1]).max() < 2e-5 * scale
+    assert (ra["pred"] != rb["pred"]).sum() <= 1
+    a.close(); b.close()
