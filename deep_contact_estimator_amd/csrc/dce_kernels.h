@@ -68,7 +68,6 @@ struct Tuning {
     long long x3_persist_min = 1024, x3_pair_min = 1024;
     bool conv_direct = false;                               // the direct-form conv stack of round 1 (conv_stack.hip)
     bool bf16_fc3_ksplit = false;                           // DCE_BF16_FC: the fused fc.3 + fc.6 on fc_gemm_h2k_kernel<H2KFc3, FUSE6, BF16> (K-tiles dealt out between the wave groups, 128-k phases) instead of fc_gemm_phased.hip's 128x64 tile (round 5: measured no faster, 17.5 against 17.8 us)
-    bool h2_ksplit = false;                                 // DCE_FP32_F16X2: fc.0's K-tiles dealt out between the two wave groups (fc_gemm_h2k_kernel: 64 x 128 wave tiles, 48-MFMA phases, three LDS buffers; round 5: measured 5 % slower)
     bool one_per_cu = false, trace_wino1 = false;           // trace builds
 };
 // parses "key=value,..." over `t`; false + message on an unknown key or a malformed value

@@ -275,8 +275,10 @@ void fc_gemm_h2_kernel(const unsigned short* __restrict__ A2, const int* __restr
 //   * fc.3 + fc.6's chunk sums (H2Fc3: 128 x 64 tile = one chunk of fc.6's summation tree, 256 tiles at 4096 windows, 64 k per phase as two 32-k
 //     sub-tiles, 32 x 64 wave tiles: 24 MFMAs against 24 fragment reads per wave and phase -- with an N split between the groups a wave's 32 x 32
 //     would read 8 fragments for 6 MFMAs), epilogue as fc_gemm_phased.hip's FUSE6: h2 tile -> LDS -> fc6_chunk_mfma -> `part`;
-//   * (experiments build, option h2_ksplit=1) fc.0 on 64 x 128 wave tiles, 48 MFMAs against 24 reads per phase: measured 5 % SLOWER than the N-split
-//     kernel above (203.7 against 194.1 us per 4096 windows, profiles/r5q_f16x2_ksplit_ab.txt).
+//   * (round 5, REMOVED) fc.0 on 64 x 128 wave tiles (H2KCfg<256, 128, 2, 4, 1>), 48 MFMAs against 24 reads per phase: no faster than the N-split kernel above
+//     (174.0 against 176.9 us per 4096 windows with both schedules fenced, profiles/r5q_f16x2_ksplit_ab.txt), 256 VGPRs with 27 spills in its final
+//     exchange -- and, in one run out of ten, a GPU memory fault that was not traced before the round ended.  The instantiation is gone; the
+//     record stays.
 template <int BM_, int BN_, int AB_, int BB_, int NSUB_> struct H2KCfg {
     static constexpr int BM = BM_, BN = BN_, AB = AB_, BB = BB_, NSUB = NSUB_;
     static constexpr int R = BM + BN, SUBT = R * H2_ROWB, TILE = NSUB * SUBT, LDS = 3 * TILE;
@@ -284,7 +286,6 @@ template <int BM_, int BN_, int AB_, int BB_, int NSUB_> struct H2KCfg {
     static constexpr int KP = H2_KT * NSUB;                                      // k per phase
     static_assert(BM == 4 * 32 * AB && BN == 32 * BB && BB % 2 == 0 && TILE == 48 * 1024 && NCH == 12, "four waves of a group cover BM; a 48 KB tile");
 };
-using H2KFc0 = H2KCfg<256, 128, 2, 4, 1>;
 using H2KFc3 = H2KCfg<128, 64, 1, 2, 2>;
 
 //   BF16 (the bf16-FC mode's fc.3, option bf16_fc3_ksplit): ONE bf16 term per operand -- a row's 128 bytes are 64 k of it, a phase is NSUB x 64 k,
@@ -514,7 +515,6 @@ hipError_t init_fc_gemm_h2()
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel<H2KFc3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2KFc3::LDS)) != hipSuccess) return e;
 #if DCE_EXPERIMENTS
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel<H2KFc0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, H2KFc0::LDS)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel<H2KFc3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2KFc3::LDS)) != hipSuccess) return e;
 #endif
     return hipSuccess;
@@ -544,13 +544,6 @@ hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, con
     const int sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
-#if DCE_EXPERIMENTS
-    if (!H1 && tune().h2_ksplit && (K / H2_KT) % 2 == 0 && K / H2_KT >= 4) {
-        plan_note("fc_h2k_256x128");
-        hipLaunchKernelGGL((fc_gemm_h2k_kernel<H2KFc0, false>), dim3(grid), dim3(512), H2KFc0::LDS, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
-        return hipGetLastError();
-    }
-#endif
     plan_note(H1 ? "fc_h2_256x128_out2" : "fc_h2_256x128");
     if (H1) hipLaunchKernelGGL((fc_gemm_h2_kernel<true>), dim3(grid), dim3(512), H2_LDS, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, H1, h1_scale, eW, eB);
     else    hipLaunchKernelGGL((fc_gemm_h2_kernel<false>), dim3(grid), dim3(512), H2_LDS, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);

@@ -49,7 +49,7 @@ def _argmax_ok(got_pred, ref_logits, ref_pred):
 
 
 def _is_h2(plan):
-    return plan[0] == "conv_h2" and any(k in plan for k in ("fc_h2_256x128", "fc_h2_256x128_out2", "fc_h2k_256x128"))
+    return plan[0] == "conv_h2" and any(k in plan for k in ("fc_h2_256x128", "fc_h2_256x128_out2"))
 
 
 @pytest.mark.parametrize("n", [1281, 2049, 3072, 4096, 4100, 8192])
@@ -279,30 +279,6 @@ def test_non_finite_checkpoint_runs_the_fp32_kernels(pair):
     assert m.last_plan()[0] == "f16x2_refused" and not any(k.startswith(("conv_h2", "fc_h2")) for k in m.last_plan()), m.last_plan()
     assert np.array_equal(o["logits"], r["logits"], equal_nan=True) and np.array_equal(o["pred"], r["pred"])
     m.close(); a.close()
-
-
-@pytest.mark.experiments
-@pytest.mark.parametrize("n", [3072, 4100, 8192])
-def test_fc0_with_the_k_tiles_dealt_out_between_the_wave_groups(n, pair, orc):
-    """(experiments build: measured 5 % slower than the N-split kernel.)  Option h2_ksplit (fc_gemm_h2k_kernel: 64 x 128 wave tiles, each wave group every other K-tile, three LDS buffers, the groups' sums added
-    at the end): another association of the same fp32 accumulation -- the contract against the oracle, a ragged last tile (4100: it reads
-    the padding rows of the feature buffer), and fp32 rounding away from the N-split kernel's result."""
-    from deep_contact_estimator_amd import synth
-    sd, a, b = pair
-    m = _model(sd, 8192, tune={"h2_ksplit": 1, "h2_fc3": 0})
-    x = np.random.default_rng(7 + n).standard_normal((n, 150, 54), dtype=np.float32)
-    x[n - 1, 5, 5] = np.nan                                  # the last row of a ragged tile
-    out, base = m.predict(x), b.predict(x)
-    assert "fc_h2k_256x128" in m.last_plan() and _is_h2(b.last_plan()), (m.last_plan(), b.last_plan())
-    assert np.isnan(out["logits"][n - 1]).all()
-    rows = np.r_[0:160, n - 97:n - 1]
-    ref = orc.Oracle(sd).forward_windows(x[rows])
-    tol_ok(out["logits"][rows], ref["logits"], f"h2_ksplit, {n} windows")
-    _argmax_ok(out["pred"][rows], ref["logits"], ref["pred"])
-    assert np.abs(out["logits"][:n - 1].astype(np.float64) - base["logits"][:n - 1]).max() < 2e-5 * np.abs(ref["logits"]).max()
-    again = m.predict(x)
-    assert np.array_equal(out["logits"], again["logits"], equal_nan=True)          # deterministic
-    m.close()
 
 
 @pytest.mark.parametrize("n", [3072, 4096, 4100, 8192])
