@@ -50,6 +50,8 @@ SYMBOLS = {
     "dce_debug_split3": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dce_debug_split_h2": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dce_debug_latency_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dce_debug_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dce_debug_free": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 BUILD_EXPERIMENTS, BUILD_TRACE, BUILD_ASAN = 1, 2, 4

@@ -29,6 +29,9 @@ using namespace dce;
 #endif
 
 namespace { int lat_service_stop(dce_ctx* c); }
+// guard placement of the context's buffer group `bit` (option guard_mask: a bisecting aid of tools/guard_stress.py; default: every group)
+static int guard_of(const dce_ctx* c, int bit) { return ((c->tuning.guard_mask >> bit) & 1) ? c->tuning.guard_alloc : 0; }
+
 
 namespace {
 
@@ -64,9 +67,9 @@ const TuneKey kTuneKeys[] = {
     TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
     TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'), TK(bf16_conv_h2, 'b'), TK(bf16_conv_h2_min, 'l'),
     TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
-    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_fc3, 'b'), TK(h2_min_tiles, 'i'),
+    TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_fc3, 'b'), TK(h2_min_tiles, 'i'), TK(guard_alloc, 'i'), TK(guard_mask, 'i'),
     TKX(bf16_k32, 'b'), TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
-    TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(bf16_fc3_ksplit, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
+    TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(h2_ksplit, 'b'), TKX(bf16_fc3_ksplit, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
 };
 #undef TK
 #undef TKX
@@ -415,7 +418,7 @@ int ensure_fc1w_x3(dce_ctx* c)
     const auto& v = c->host_w[8];
     std::vector<unsigned short> planes(3 * v.size());
     split3_host(v.data(), FC1, FEAT, planes.data());
-    HIP_TRY(c, hipMalloc(&c->fc1w_x3_own, planes.size() * sizeof(unsigned short)));
+    HIP_TRY(c, dev_alloc(&c->fc1w_x3_own, guard_of(c, 0), planes.size() * sizeof(unsigned short)));
     HIP_TRY(c, hipMemcpy(c->fc1w_x3_own, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     c->fc1w_x3 = c->fc1w_x3_own;
     return DCE_OK;
@@ -517,11 +520,18 @@ int run_chunk(dce_ctx* c, const float* src, int zscore, int64_t n,
     return rc;
 }
 
+// feat3 serves DCE_FP32_SPLIT (three bf16 planes of max_batch + 1 rows) and DCE_FP32_F16X2 (two fp16 terms, padded by a tile of rows that ragged
+// K-split tiles read: fc_gemm_h2_pad_rows): ONE size, so that a context re-finalized in the other precision never finds it short
+size_t feat3_halfs(int64_t max_batch)
+{
+    return std::max((size_t)(max_batch + 1) * FEAT * 3, (size_t)(max_batch + fc_gemm_h2_pad_rows()) * FEAT * 2);
+}
+
 int ensure_in(dce_ctx* c, size_t bytes)
 {
     if (c->d_in_bytes >= bytes) return DCE_OK;
-    if (c->d_in) { HIP_TRY(c, hipFree(c->d_in)); c->d_in = nullptr; c->d_in_bytes = 0; }
-    HIP_TRY(c, hipMalloc(&c->d_in, bytes));
+    if (c->d_in) { HIP_TRY(c, dev_free(c->d_in)); c->d_in = nullptr; c->d_in_bytes = 0; }
+    HIP_TRY(c, dev_alloc(&c->d_in, guard_of(c, 5), bytes));
     c->d_in_bytes = bytes;
     return DCE_OK;
 }
@@ -530,14 +540,14 @@ int ensure_out(dce_ctx* c, size_t rows)
 {
     if (c->d_out_rows >= rows) return DCE_OK;
     c->d_out_rows = 0;
-    if (c->d_logits)   { HIP_TRY(c, hipFree(c->d_logits));   c->d_logits = nullptr; }
-    if (c->d_pred)     { HIP_TRY(c, hipFree(c->d_pred));     c->d_pred = nullptr; }
-    if (c->d_contacts) { HIP_TRY(c, hipFree(c->d_contacts)); c->d_contacts = nullptr; }
-    if (c->d_packed)   { HIP_TRY(c, hipFree(c->d_packed));   c->d_packed = nullptr; }
-    HIP_TRY(c, hipMalloc(&c->d_packed, rows * PACKED_ROW));
-    HIP_TRY(c, hipMalloc(&c->d_logits, rows * NCLS * sizeof(float)));
-    HIP_TRY(c, hipMalloc(&c->d_pred, rows * sizeof(int32_t)));
-    HIP_TRY(c, hipMalloc(&c->d_contacts, rows * 4));
+    if (c->d_logits)   { HIP_TRY(c, dev_free(c->d_logits));   c->d_logits = nullptr; }
+    if (c->d_pred)     { HIP_TRY(c, dev_free(c->d_pred));     c->d_pred = nullptr; }
+    if (c->d_contacts) { HIP_TRY(c, dev_free(c->d_contacts)); c->d_contacts = nullptr; }
+    if (c->d_packed)   { HIP_TRY(c, dev_free(c->d_packed));   c->d_packed = nullptr; }
+    HIP_TRY(c, dev_alloc(&c->d_packed, guard_of(c, 6), rows * PACKED_ROW));
+    HIP_TRY(c, dev_alloc(&c->d_logits, guard_of(c, 6), rows * NCLS * sizeof(float)));
+    HIP_TRY(c, dev_alloc(&c->d_pred, guard_of(c, 6), rows * sizeof(int32_t)));
+    HIP_TRY(c, dev_alloc(&c->d_contacts, guard_of(c, 6), rows * 4));
     c->d_out_rows = rows;
     return DCE_OK;
 }
@@ -726,11 +736,11 @@ int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* o
     CREATE_TRY(init_conv_h2());
     CREATE_TRY(init_fc_gemm_h2());
     CREATE_TRY(init_conv_x3p());
-    CREATE_TRY(hipMalloc(&c->feat, (size_t)max_batch * FEAT * sizeof(float)));
-    CREATE_TRY(hipMalloc(&c->h1, (size_t)max_batch * FC1 * sizeof(float)));
-    CREATE_TRY(hipMalloc(&c->h2, (size_t)max_batch * FC2 * sizeof(float)));
-    CREATE_TRY(hipMalloc(&c->part, (size_t)max_batch * 8 * NCLS * sizeof(float)));
-    CREATE_TRY(hipMalloc(&c->d_guard, 4 * sizeof(unsigned)));
+    CREATE_TRY(dev_alloc(&c->feat, guard_of(c, 1), (size_t)max_batch * FEAT * sizeof(float)));
+    CREATE_TRY(dev_alloc(&c->h1, guard_of(c, 2), (size_t)max_batch * FC1 * sizeof(float)));
+    CREATE_TRY(dev_alloc(&c->h2, guard_of(c, 3), (size_t)max_batch * FC2 * sizeof(float)));
+    CREATE_TRY(dev_alloc(&c->part, guard_of(c, 4), (size_t)max_batch * 8 * NCLS * sizeof(float)));
+    CREATE_TRY(dev_alloc(&c->d_guard, guard_of(c, 9), 4 * sizeof(unsigned)));
     CREATE_TRY(hipMemset(c->d_guard, 0, 4 * sizeof(unsigned)));
     if (c->tuning.latency) {
         // the latency mode's kernel is ONE grid of co-resident workgroups, one per CU: it needs a device with that many CUs to itself
@@ -750,8 +760,8 @@ int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* o
             CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->lat_trace), 16 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
             memset(c->lat_trace, 0, 16 * sizeof(unsigned long long));
         }
-        CREATE_TRY(hipMalloc(&c->lat_hist, WIN * CH * sizeof(float)));
-        CREATE_TRY(hipMalloc(&c->lat_hist_state, 2 * sizeof(int)));
+        CREATE_TRY(dev_alloc(&c->lat_hist, guard_of(c, 9), WIN * CH * sizeof(float)));
+        CREATE_TRY(dev_alloc(&c->lat_hist_state, guard_of(c, 9), 2 * sizeof(int)));
         CREATE_TRY(hipMemset(c->lat_hist_state, 0, 2 * sizeof(int)));
         CREATE_TRY(hipMemset(c->lat_hist, 0, WIN * CH * sizeof(float)));
         CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->lat_mbox), sizeof(LatMailbox), hipHostMallocMapped | hipHostMallocCoherent));
@@ -770,7 +780,7 @@ void dce_destroy(dce_ctx* c)
     (void)lat_service_stop(c);
     if (c->lat_stream) hipStreamDestroy(c->lat_stream);
     if (c->lat_mbox) hipHostFree(c->lat_mbox);
-    hipFree(c->lat_x); hipFree(c->lat_hist); hipFree(c->lat_hist_state);
+    dev_free(c->lat_x); dev_free(c->lat_hist); dev_free(c->lat_hist_state);
     if (c->lat_trace) hipHostFree(c->lat_trace);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     if (c->stream != c->own_stream) hipStreamSynchronize(c->stream);   // scratch may still be in use there
@@ -783,11 +793,11 @@ void dce_destroy(dce_ctx* c)
     if (c->xstream_ev) hipEventDestroy(c->xstream_ev);
     if (c->xfer_stream) { hipStreamSynchronize(c->xfer_stream); hipStreamDestroy(c->xfer_stream); }
     for (auto& slot : c->ring_ev) for (auto e : slot) if (e) hipEventDestroy(e);
-    hipFree(c->d_weights); hipFree(c->feat); hipFree(c->feat3); hipFree(c->h1); hipFree(c->h2); hipFree(c->part);
-    hipFree(c->feat_scale); hipFree(c->h1h); hipFree(c->h1_scale); hipFree(c->d_guard); hipFree(c->fc1w_x3_own); hipFree(c->h1p); hipFree(c->d_in); hipFree(c->d_logits); hipFree(c->d_pred); hipFree(c->d_contacts); hipFree(c->d_packed);
+    dev_free(c->d_weights); dev_free(c->feat); dev_free(c->feat3); dev_free(c->h1); dev_free(c->h2); dev_free(c->part);
+    dev_free(c->feat_scale); dev_free(c->h1h); dev_free(c->h1_scale); dev_free(c->d_guard); dev_free(c->fc1w_x3_own); dev_free(c->h1p); dev_free(c->d_in); dev_free(c->d_logits); dev_free(c->d_pred); dev_free(c->d_contacts); dev_free(c->d_packed);
     if (c->online_exec) hipGraphExecDestroy(c->online_exec);
     if (c->online_graph) hipGraphDestroy(c->online_graph);
-    hipFree(c->d_ring); hipFree(c->d_online_state);
+    dev_free(c->d_ring); dev_free(c->d_online_state);
     if (c->h_online_pin) hipHostFree(c->h_online_pin);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -906,12 +916,12 @@ int dce_finalize_weights(dce_ctx* c, int precision)
             off_x3p = reserve((3 * v.size() + 1) / 2);
             split3_host(w1p.data(), FC1, FEAT, reinterpret_cast<unsigned short*>(img.data() + off_x3p));
         }
-        if (!c->feat3) HIP_TRY(c, hipMalloc(&c->feat3, (size_t)(c->max_batch + 1) * FEAT * 3 * sizeof(unsigned short)));
+        if (!c->feat3) HIP_TRY(c, dev_alloc(&c->feat3, guard_of(c, 7), feat3_halfs(c->max_batch) * sizeof(unsigned short)));
         if (c->tuning.x3_fc3) {                           // fc.3 on three-term operands: its weights as three row-major planes, h1 as three planes out of fc.0
             const auto& v2 = c->host_w[10];
             off_x3b = reserve((3 * v2.size() + 1) / 2);
             split3_rows_host(v2.data(), FC2, FC1, reinterpret_cast<unsigned short*>(img.data() + off_x3b));
-            if (!c->h1p) HIP_TRY(c, hipMalloc(&c->h1p, (size_t)(c->max_batch + 1) * FC1 * 3 * sizeof(unsigned short)));
+            if (!c->h1p) HIP_TRY(c, dev_alloc(&c->h1p, guard_of(c, 8), (size_t)(c->max_batch + 1) * FC1 * 3 * sizeof(unsigned short)));
         }
     }
     // DCE_FP32_F16X2: conv1..4 and fc.0 as two fp16 terms of w * 2^sw (conv_h2.hip has the arithmetic); a non-finite weight or bias refuses the precision
@@ -956,19 +966,19 @@ int dce_finalize_weights(dce_ctx* c, int precision)
                 h2_eW = cw > 0.0 ? std::ilogb(cw) + 1 : -300;
                 h2_eB = bm > 0.f ? std::ilogb(bm) + 1 : -300;
                 const size_t rows = (size_t)c->max_batch + fc_gemm_h2_pad_rows();
-                if (!c->h1h) { HIP_TRY(c, hipMalloc(&c->h1h, rows * FC1 * 2 * sizeof(unsigned short))); HIP_TRY(c, hipMemset(c->h1h, 0, rows * FC1 * 2 * sizeof(unsigned short))); }
-                if (!c->h1_scale) { HIP_TRY(c, hipMalloc(&c->h1_scale, rows * sizeof(int))); HIP_TRY(c, hipMemset(c->h1_scale, 0, rows * sizeof(int))); }
+                if (!c->h1h) { HIP_TRY(c, dev_alloc(&c->h1h, guard_of(c, 8), rows * FC1 * 2 * sizeof(unsigned short))); HIP_TRY(c, hipMemset(c->h1h, 0, rows * FC1 * 2 * sizeof(unsigned short))); }
+                if (!c->h1_scale) { HIP_TRY(c, dev_alloc(&c->h1_scale, guard_of(c, 8), rows * sizeof(int))); HIP_TRY(c, hipMemset(c->h1_scale, 0, rows * sizeof(int))); }
             }
             if (!c->feat3 && !h2_conv_only) {                         // two fp16 terms per feature, padded by a tile of rows (fc_gemm_h2_pad_rows)
-                const size_t halfs = std::max((size_t)(c->max_batch + 1) * FEAT * 3, (size_t)(c->max_batch + fc_gemm_h2_pad_rows()) * FEAT * 2);
-                HIP_TRY(c, hipMalloc(&c->feat3, halfs * sizeof(unsigned short)));
+                const size_t halfs = feat3_halfs(c->max_batch);
+                HIP_TRY(c, dev_alloc(&c->feat3, guard_of(c, 7), halfs * sizeof(unsigned short)));
                 HIP_TRY(c, hipMemset(c->feat3, 0, halfs * sizeof(unsigned short)));
             }
-            if (!c->feat_scale && !h2_conv_only) HIP_TRY(c, hipMalloc(&c->feat_scale, (size_t)(c->max_batch + 1) * sizeof(int)));
+            if (!c->feat_scale && !h2_conv_only) HIP_TRY(c, dev_alloc(&c->feat_scale, guard_of(c, 8), (size_t)(c->max_batch + 1) * sizeof(int)));
         }
     }
-    if (c->d_weights) { HIP_TRY(c, hipFree(c->d_weights)); c->d_weights = nullptr; }
-    HIP_TRY(c, hipMalloc(&c->d_weights, img.size() * sizeof(float)));
+    if (c->d_weights) { HIP_TRY(c, dev_free(c->d_weights)); c->d_weights = nullptr; }
+    HIP_TRY(c, dev_alloc(&c->d_weights, guard_of(c, 0), img.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
     for (int l = 0; l < 4; ++l) {
         c->pk.w[l] = DCE_EXPERIMENTS ? c->d_weights + off_w[l] : nullptr; c->pk.ww[l] = c->d_weights + off_ww[l];
@@ -984,7 +994,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
         c->pkx3.w[l] = want_cx ? reinterpret_cast<const unsigned short*>(c->d_weights + off_cx[l]) : nullptr;
         c->pkx3.b[l] = c->pk.b[l];
     }
-    if (c->fc1w_x3_own) { HIP_TRY(c, hipFree(c->fc1w_x3_own)); c->fc1w_x3_own = nullptr; }
+    if (c->fc1w_x3_own) { HIP_TRY(c, dev_free(c->fc1w_x3_own)); c->fc1w_x3_own = nullptr; }
     c->fc1w_x3 = precision == DCE_FP32_SPLIT && !want_pair ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3) : nullptr;
     c->fc2w_x3 = precision == DCE_FP32_SPLIT && c->tuning.x3_fc3 ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3b) : nullptr;
     c->fc1w_x3p = precision == DCE_FP32_SPLIT && want_pair ? reinterpret_cast<const unsigned short*>(c->d_weights + off_x3p) : nullptr;
@@ -1340,8 +1350,8 @@ int dce_online_push(dce_ctx* c, const float* sample, float* logits, int32_t* pre
     if (!sample) return fail(c, DCE_ERR_ARG, "dce_online_push: NULL sample");
     if (c->tuning.latency && c->precision == DCE_FP32) return lat_push(c, sample, logits, pred, contacts);
     if (!c->d_ring) {
-        HIP_TRY(c, hipMalloc(&c->d_ring, (size_t)ONLINE_ROWS * CH * sizeof(float)));
-        HIP_TRY(c, hipMalloc(&c->d_online_state, sizeof(OnlineState)));
+        HIP_TRY(c, dev_alloc(&c->d_ring, guard_of(c, 10), (size_t)ONLINE_ROWS * CH * sizeof(float)));
+        HIP_TRY(c, dev_alloc(&c->d_online_state, guard_of(c, 10), sizeof(OnlineState)));
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_online_pin), PIN_FLOATS * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));   // polled by the host while a kernel writes it: must be coherent (fine-grained), whatever the defaults / HIP_HOST_COHERENT say
         memset(c->h_online_pin, 0, PIN_FLOATS * sizeof(float));
         // constant-parameter (graph) form needs the Winograd kernels' indirect window start
@@ -1464,6 +1474,22 @@ int dce_debug_latency_trace(dce_ctx* c, unsigned long long out[16])
 {
     if (!c || !out || !c->lat_trace) return DCE_ERR_STATE;
     for (int i = 0; i < 16; ++i) out[i] = __atomic_load_n(&c->lat_trace[i], __ATOMIC_RELAXED);
+    return DCE_OK;
+}
+
+int dce_debug_alloc(dce_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out) return DCE_ERR_ARG;
+    DEVICE_GUARD(c);
+    HIP_TRY(c, dev_alloc_raw(out, bytes, c->tuning.guard_alloc));
+    return DCE_OK;
+}
+
+int dce_debug_free(dce_ctx* c, void* p)
+{
+    if (!c) return DCE_ERR_ARG;
+    DEVICE_GUARD(c);
+    HIP_TRY(c, dev_free_raw(p));
     return DCE_OK;
 }
 

@@ -235,8 +235,8 @@ int dce_allreduce_counts(dce_ctx* c, int64_t* counts, int on_device)
     int64_t* d = counts;
     if (!on_device) {
         if (c->d_in_bytes < 256 * sizeof(int64_t)) {
-            if (c->d_in) { HIP_TRY(c, hipFree(c->d_in)); c->d_in = nullptr; c->d_in_bytes = 0; }
-            HIP_TRY(c, hipMalloc(&c->d_in, 4096));
+            if (c->d_in) { HIP_TRY(c, dce::dev_free(c->d_in)); c->d_in = nullptr; c->d_in_bytes = 0; }
+            HIP_TRY(c, dce::dev_alloc(&c->d_in, c->tuning.guard_alloc, 4096));
             c->d_in_bytes = 4096;
         }
         d = reinterpret_cast<int64_t*>(c->d_in);

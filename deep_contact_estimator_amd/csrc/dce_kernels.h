@@ -68,7 +68,11 @@ struct Tuning {
     long long x3_persist_min = 1024, x3_pair_min = 1024;
     bool conv_direct = false;                               // the direct-form conv stack of round 1 (conv_stack.hip)
     bool bf16_fc3_ksplit = false;                           // DCE_BF16_FC: the fused fc.3 + fc.6 on fc_gemm_h2k_kernel<H2KFc3, FUSE6, BF16> (K-tiles dealt out between the wave groups, 128-k phases) instead of fc_gemm_phased.hip's 128x64 tile (round 5: measured no faster, 17.5 against 17.8 us)
+    bool h2_ksplit = false;                                 // DCE_FP32_F16X2: fc.0's K-tiles dealt out between the two wave groups (fc_gemm_h2k_kernel<H2KFc0>: 64 x 128 wave tiles, three LDS buffers; round 5: no faster, and the variant whose intermittent fault round 6 traced)
     bool one_per_cu = false, trace_wino1 = false;           // trace builds
+    // -- memory-safety tests (dev_alloc.hip)
+    int guard_mask = -1;                                    // ... which buffer groups (bit 0 weights, 1 feat, 2 h1, 3 h2, 4 part, 5 staged input, 6 staged results, 7 feat3, 8 two-/three-term h1 + scales, 9 small state, 10 online ring)
+    int guard_alloc = 0;                                    // 1 / 2: every device buffer of the context in a mapping of its own whose last / first byte abuts an unmapped page
 };
 // parses "key=value,..." over `t`; false + message on an unknown key or a malformed value
 bool tuning_parse(const char* spec, Tuning& t, char* err, int err_len);
@@ -90,6 +94,12 @@ struct GuardArgs { unsigned* word = nullptr; unsigned gen = 0; float x_hi = 0.f,
 struct Gate { const unsigned* word = nullptr; unsigned gen = 0; unsigned* taken = nullptr; };
 extern thread_local Gate t_gate;                             // set around the gated fallback sequence; {} = no gate
 __device__ __forceinline__ bool gate_closed(const Gate& g) { return g.word != nullptr && *g.word != g.gen; }
+
+// ---- device buffers of a context (dev_alloc.hip): hipMalloc / hipFree, or -- guard != 0 -- a mapping per buffer that ends (1) / starts (2) at an unmapped page
+hipError_t dev_alloc_raw(void** out, size_t bytes, int guard);
+hipError_t dev_free_raw(void* p);
+template <class T> inline hipError_t dev_alloc(T** out, int guard, size_t bytes) { return dev_alloc_raw(reinterpret_cast<void**>(out), bytes, guard); }
+template <class T> inline hipError_t dev_free(const T* p) { return dev_free_raw(const_cast<void*>(static_cast<const void*>(p))); }
 
 // ---- which kernels a call ran: every launcher notes the kernel family it picked; dce_last_plan returns the notes of
 // the ctx's most recent kernel sequence (tests assert that an A/B switch or a batch size really selected the kernel

@@ -287,6 +287,9 @@ template <int BM_, int BN_, int AB_, int BB_, int NSUB_> struct H2KCfg {
     static_assert(BM == 4 * 32 * AB && BN == 32 * BB && BB % 2 == 0 && TILE == 48 * 1024 && NCH == 12, "four waves of a group cover BM; a 48 KB tile");
 };
 using H2KFc3 = H2KCfg<128, 64, 1, 2, 2>;
+#if DCE_EXPERIMENTS
+using H2KFc0 = H2KCfg<256, 128, 2, 4, 1>;                                 // round 6: back in the experiments build, to trace round 5's intermittent fault
+#endif
 
 //   BF16 (the bf16-FC mode's fc.3, option bf16_fc3_ksplit): ONE bf16 term per operand -- a row's 128 bytes are 64 k of it, a phase is NSUB x 64 k,
 //   one MFMA per fragment pair, no scales -- on the same schedule; h1 and W2 are the mode's row-major bf16 arrays
@@ -515,6 +518,7 @@ hipError_t init_fc_gemm_h2()
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel<H2KFc3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2KFc3::LDS)) != hipSuccess) return e;
 #if DCE_EXPERIMENTS
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel<H2KFc0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, H2KFc0::LDS)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_h2k_kernel<H2KFc3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H2KFc3::LDS)) != hipSuccess) return e;
 #endif
     return hipSuccess;
@@ -544,6 +548,13 @@ hipError_t launch_fc_gemm_h2(const unsigned short* A2, const int* row_scale, con
     const int sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
     const int grid = ((nsuper + 7) / 8) * 8 * 32;
+#if DCE_EXPERIMENTS
+    if (!H1 && tune().h2_ksplit && (K / H2_KT) % 2 == 0 && K / H2_KT >= 4) {
+        plan_note("fc_h2k_256x128");
+        hipLaunchKernelGGL((fc_gemm_h2k_kernel<H2KFc0, false>), dim3(grid), dim3(512), H2KFc0::LDS, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
+        return hipGetLastError();
+    }
+#endif
     plan_note(H1 ? "fc_h2_256x128_out2" : "fc_h2_256x128");
     if (H1) hipLaunchKernelGGL((fc_gemm_h2_kernel<true>), dim3(grid), dim3(512), H2_LDS, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2, H1, h1_scale, eW, eB);
     else    hipLaunchKernelGGL((fc_gemm_h2_kernel<false>), dim3(grid), dim3(512), H2_LDS, st, A2, row_scale, W2, sw, bias, C, (int)M, N, K, relu, mtiles, ntiles, sn_log2);

@@ -962,7 +962,9 @@ static hipError_t launch_phased_cfg(const void* A, const void* W, const float* b
         }
     }
 #endif
-    plan_note(use_lockstep(BF16) ? (T == 2 ? "fc_lockstep256x128" : "fc_lockstep128x64") : (T == 3 ? "fc_phased256x128_k32" : T == 2 ? "fc_phased256x128" : "fc_phased128x64"));
+    // (the note names the operand type too: bench.py prices a stage against the pipe its kernel family runs on)
+    if (BF16) plan_note(use_lockstep(BF16) ? (T == 2 ? "fc_lockstep256x128_bf16" : "fc_lockstep128x64_bf16") : (T == 3 ? "fc_phased256x128_k32_bf16" : T == 2 ? "fc_phased256x128_bf16" : "fc_phased128x64_bf16"));
+    else plan_note(use_lockstep(BF16) ? (T == 2 ? "fc_lockstep256x128" : "fc_lockstep128x64") : (T == 2 ? "fc_phased256x128" : "fc_phased128x64"));
 #if DCE_EXPERIMENTS
     if (use_lockstep(BF16))
         hipLaunchKernelGGL((fc_gemm_phased_kernel<BF16, OUT_BF16, P::TM, P::TN, P::ROWB, false, true>), dim3(grid), dim3(512), Cfg::LDS, st,
@@ -1019,7 +1021,8 @@ hipError_t launch_fc23_fused(const void* h1, const void* W2, const float* b2, co
     const long long pr = (long long)part_rows;
 #define FC23_LAUNCH(BF, LS) hipLaunchKernelGGL((fc_gemm_phased_kernel<BF, false, 1, 1, 256, true, LS>), dim3(grid), dim3(512), Cfg::LDS, st, \
                                                h1, W2, b2, h2v, (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, pr, t_gate)
-    plan_note(use_lockstep(false) ? "fc23_fused_lockstep128x64" : "fc23_fused_phased128x64");
+    if (bf16) plan_note(use_lockstep(false) ? "fc23_fused_lockstep128x64_bf16" : "fc23_fused_phased128x64_bf16");
+    else plan_note(use_lockstep(false) ? "fc23_fused_lockstep128x64" : "fc23_fused_phased128x64");
 #if DCE_EXPERIMENTS
     if (use_lockstep(bf16)) { if (bf16) FC23_LAUNCH(true, true); else FC23_LAUNCH(false, true); }
     else

@@ -329,6 +329,13 @@ int  dce_debug_split_h2(const float* x, size_t n, unsigned short* terms);
  * seen by fc workgroup 0, [5] its fc.0 rows done, [6] h1 complete, [7] its fc.3 rows done, [8] h2 complete, [9]/[10] results written. */
 int  dce_debug_latency_trace(dce_ctx* ctx, unsigned long long stamps[16]);
 
+/* Test hooks of the memory-safety tests (csrc/dev_alloc.hip; option guard_alloc=1 | 2 of dce_create_ex): a context created with the option keeps EVERY
+ * device buffer it owns in a mapping of its own whose last (1) / first (2) byte abuts an unmapped page, so that a kernel access one element outside any
+ * buffer is a GPU page fault at that access.  These two give a CALLER-owned device buffer (windows, sequences, results passed with on_device = 1) the same
+ * placement (the placement of `ctx`; a plain hipMalloc for a context without the option).  tests/test_guard_alloc_gpu.py, tools/guard_stress.py. */
+int  dce_debug_alloc(dce_ctx* ctx, size_t bytes, void** device_ptr);
+int  dce_debug_free(dce_ctx* ctx, void* device_ptr);
+
 #ifdef __cplusplus
 }
 #endif

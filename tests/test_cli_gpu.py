@@ -340,3 +340,18 @@ def test_bench_default_line_contract():
     assert "bf16 MFMA" in fs["kernels"]["fc1_gemm"]["pipe"] and "bf16 MFMA" in fs["kernels"]["conv_stack"]["pipe"]
     sb = ex["small_batches"]["batches"]
     assert set(sb) >= {"1", "30"} and 0 < sb["1"]["us_per_call"] < sb["30"]["us_per_call"] < 500
+    # every roofline fraction of the line is a fraction: a stage priced against the wrong pipe (round 5: fp32_f16x2's fc.3, an fp16-pipe kernel,
+    # against the fp32 peak -> 1.65) must not come back.  bench.py checks itself; the walk below checks bench.py.
+    assert j["self_check"]["roofline_fractions_above_one"] == [], j["self_check"]
+
+    def fractions(o, path="line"):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k in ("frac", "path_frac_of_roof", "frac_of_roof") and isinstance(v, (int, float)):
+                    yield f"{path}.{k}", v
+                yield from fractions(v, f"{path}.{k}")
+    fr = dict(fractions(j))
+    assert len(fr) >= 12 and all(0.0 < v <= 1.0 for v in fr.values()), {k: v for k, v in fr.items() if not 0.0 < v <= 1.0}
+    fx = ex["fp32_f16x2"]                                    # fc.3 of this precision runs on the fp16 pipe, three MFMAs per product
+    assert "fp16 MFMA" in fx["kernels"]["fc2_gemm"]["pipe"] and fx["kernels"]["fc2_gemm"]["kernel_family"].startswith("fc23_fused_h2"), fx["kernels"]["fc2_gemm"]
+    assert 0.3 < fx["path_frac_of_roof"] < 0.7

@@ -39,7 +39,7 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs, or
         flips = out["pred"] != g["pred"]
         assert err < 2e-2 * scale, (err, scale)
         assert flips.mean() < 0.02 and (g["margin"][flips] < 4 * err + 1e-6).all()
-        assert plan[0] == "conv_h2_bf16_permk" and "fc_phased256x128" in plan, plan         # conv results of fp32 grade (two fp16 terms, per-window scales), bf16 FC
+        assert plan[0] == "conv_h2_bf16_permk" and "fc_phased256x128_bf16" in plan, plan         # conv results of fp32 grade (two fp16 terms, per-window scales), bf16 FC
     else:
         # Against the fp64-statistics evaluation (the oracle) on the same rows: the contract as stated, every logit.  Against the
         # reference's own numbers: the reference z-scores in fp32 and on this sequence sits up to 1.15 bounds from that evaluation
@@ -114,7 +114,7 @@ def test_k_tiles_dealt_out_between_the_wave_groups():
     for n in (4096, 8192):
         x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
         ra, rb = a.predict(x), b.predict(x)
-        assert "fc_ki256x128" in a.last_plan() and "fc_phased256x128" in b.last_plan(), (a.last_plan(), b.last_plan())
+        assert "fc_ki256x128" in a.last_plan() and "fc_phased256x128_bf16" in b.last_plan(), (a.last_plan(), b.last_plan())
         assert np.abs(ra["logits"] - rb["logits"]).max() <= 2e-3 * np.abs(rb["logits"]).max()
         for _ in range(10):
             assert np.array_equal(a.predict(x)["logits"], ra["logits"])
@@ -132,7 +132,7 @@ def test_barrier_free_bf16_gemm_equals_the_phased_kernel():
     for n in (4096, 8192):
         x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
         ra, rb = a.predict(x), b.predict(x)
-        assert "fc_pipe256x128" in a.last_plan() and "fc_phased256x128" in b.last_plan(), (a.last_plan(), b.last_plan())
+        assert "fc_pipe256x128" in a.last_plan() and "fc_phased256x128_bf16" in b.last_plan(), (a.last_plan(), b.last_plan())
         assert np.array_equal(ra["logits"], rb["logits"])
         for _ in range(20):
             assert np.array_equal(a.predict(x)["logits"], ra["logits"])

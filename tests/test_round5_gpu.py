@@ -186,7 +186,7 @@ def test_bf16_gemm_k32_two_workgroups_per_cu_bit_identical():
         rb = b.predict(x)["logits"].clone()
         for rep in range(3):
             ra = a.predict(x)["logits"]
-            assert "fc_phased256x128_k32" in a.last_plan() and "fc_phased256x128_k32" not in b.last_plan(), (a.last_plan(), b.last_plan())
+            assert "fc_phased256x128_k32_bf16" in a.last_plan() and "fc_phased256x128_k32_bf16" not in b.last_plan(), (a.last_plan(), b.last_plan())
             assert torch.equal(ra, rb), (n, rep)
         a.close(); b.close()
 
