@@ -420,12 +420,79 @@ def extra_latency_mode(torch, contact_cnn, sd, dev, windows, seq_np, ref_logits)
     us = (time.perf_counter() - t0) / n * 1e6
     plan = m.last_plan()
     dl = float((o["logits"][0] - ref_logits[0]).abs().max().item())
+    # the reference's OTHER shipped batch size (config/test_params.yaml:9: 30) and its neighbours: 2 .. 32 windows as ONE kernel too (csrc/latency_mb.hip)
+    batches = {}
+    for b in (2, 8, 16, 30, 32):
+        xq = windows[:b].contiguous()
+        for _ in range(50):
+            ob = m.predict(xq)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ob = m.predict(xq)
+        torch.cuda.synchronize()
+        batches[str(b)] = {"us_per_call": (time.perf_counter() - t0) / n * 1e6, "plan": m.last_plan(),
+                           "max_abs_dlogit_vs_batch_path_same_windows": float((ob["logits"] - ref_logits[:b]).abs().max().item())}
     m.close()
+    cold = None
+    try:
+        cold = latency_cold_stream(torch, contact_cnn, sd, dev, windows)
+    except Exception as e:                                        # noqa: BLE001 -- a measurement beside the line, never a reason to lose it
+        cold = {"error": f"{type(e).__name__}: {e}"}
     push = extra_online(contact_cnn, sd, dev, seq_np, tune={"latency": 1})
     return {"workload": "option latency=1 (fp32): model.predict on ONE pre-normalised device-resident window, per call; dce_online_push per sample",
             "predict_1_us_per_call": us, "plan": plan, "max_abs_dlogit_vs_batch_path_same_window": dl,
             "online_push_us": push["us_per_push"], "online_pushes": push["pushes"],
+            "batches": {"workload": "model.predict on b pre-normalised device-resident windows, option latency=1: 2 .. 32 windows in ONE kernel (conv segments, fc.0 tiles "
+                                    "with register-resident weights on fp32 MFMAs, fc.3 + partial logits, ordered sum); stream-ordered calls back to back; compare "
+                                    "extra.small_batches (the batch path's four launches)", "per_batch": batches},
+            "cold_weights_30": cold,
             "note": "inside the fp32 tolerance of the CPU restatement (tests/test_round5_gpu.py), not the batch path's bits: K is folded over the lanes by a fixed tree"}
+
+
+def latency_cold_stream(torch, contact_cnn, sd, dev, windows, b=30, reps=12):
+    """The one place of this path where north_star's HBM metric binds: a 30-window call with fc.0's 38.8 MB of weights NOT in the 256 MB Infinity Cache.
+    Between calls 1 GB of other data is read (the cache holds none of the weights afterwards); the kernel's own stamps (DCE_LAT_TRACE: 100 MHz
+    wall clock, csrc/latency_mb.hip) give the earliest request and the latest landing of fc.0's rows over its 128 workgroups -- the stream that runs under
+    the conv role -- and the call's device time."""
+    import ctypes as C
+    had = os.environ.get("DCE_LAT_TRACE")
+    os.environ["DCE_LAT_TRACE"] = "1"
+    try:
+        m = contact_cnn(device=dev.index, max_batch=64, tune={"latency": 1})
+        m.load_state_dict(sd).eval()
+        m._finalize()                                             # (the context is made here: it reads DCE_LAT_TRACE when it is created)
+    finally:
+        if had is None:
+            del os.environ["DCE_LAT_TRACE"]
+    xq = windows[:b].contiguous()
+    junk = torch.zeros(256 << 20, dtype=torch.float32, device=dev)           # 1 GB
+    st = (C.c_ulonglong * 16)()
+    rows = {"cold": [], "warm": []}
+    for kind in ("warm", "cold"):
+        for _ in range(reps):
+            if kind == "cold":
+                junk.max()                                        # READ 1 GB: the caches are left full of clean lines of other data (after a write pass the
+                                                                  # kernel's reads would also have to push 256 MB of dirty lines out: 2.6 instead of the rate below)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m.predict(xq)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) * 1e6
+            assert m._lib.dce_debug_latency_trace(m._ctx, st) == 0
+            stream_us = (st[13] - st[12]) / 100.0
+            rows[kind].append({"stream_us": stream_us, "stream_TBs": 2048 * 4736 * 4 / stream_us / 1e6, "kernel_us": (st[11] - st[1]) / 100.0, "synced_call_us": wall})
+    m.close()
+    del junk
+    med = lambda k, f: statistics.median(r[f] for r in rows[k])
+    out = {"workload": f"option latency=1, {b} windows, one synchronised call at a time; cold: 1 GB of other data read between calls (fc.0's weights come from HBM), "
+                       "warm: nothing in between (they sit in the Infinity Cache); medians of %d calls" % reps}
+    for k in ("cold", "warm"):
+        out[k] = {"fc0_weight_stream_us": med(k, "stream_us"), "fc0_weight_stream_TBs": med(k, "stream_TBs"), "kernel_us": med(k, "kernel_us"),
+                  "synced_call_us": med(k, "synced_call_us")}
+    out["cold"]["frac_of_achievable_6.3TBs"] = out["cold"]["fc0_weight_stream_TBs"] / 6.3
+    out["cold"]["frac_of_8TBs"] = out["cold"]["fc0_weight_stream_TBs"] / 8.0
+    return out
 
 
 MODE_TEXT = {

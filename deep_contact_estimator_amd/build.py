@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdce.so")
-SOURCES = ["conv_stack.hip", "conv_wino.hip", "latency.hip", "conv_x3.hip", "conv_x3p.hip", "conv_h2.hip", "fc_gemm.hip", "fc_gemm_phased.hip", "fc_gemm_chain.hip", "fc_gemm_split.hip", "fc_gemm_x3.hip", "fc_gemm_h2.hip", "fc_gemv.hip", "fc_stream_bf16.hip", "dce_api.hip", "dce_comm.hip", "dev_alloc.hip"]
+SOURCES = ["conv_stack.hip", "conv_wino.hip", "latency.hip", "latency_mb.hip", "conv_x3.hip", "conv_x3p.hip", "conv_h2.hip", "fc_gemm.hip", "fc_gemm_phased.hip", "fc_gemm_chain.hip", "fc_gemm_split.hip", "fc_gemm_x3.hip", "fc_gemm_h2.hip", "fc_gemv.hip", "fc_stream_bf16.hip", "dce_api.hip", "dce_comm.hip", "dev_alloc.hip"]
 HEADERS = ["dce_kernels.h", "dce_ctx.h", "fc_tree.h", "conv_common.h", "conv_wino_dev.h", "conv_x3_common.h", "fc6_chain.h", os.path.join("..", "..", "include", "dce.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 OBJDIR = os.path.join(HERE, "build")

@@ -599,7 +599,9 @@ __device__ __forceinline__ void seg_stage1(float* __restrict__ act, const float*
 //   XREG = true : the caller holds this thread's RAW samples (rows t = 4 m + g of channel c, tid = 54 g + c < 216) in xin and the window
 //                 is z-scored here (ZS) -- the latency mode's service kernel keeps the last 150 samples in LDS (latency.hip).
 //   COHERENT    : the features are stored with agent-scope (write-through) stores: another workgroup of the SAME kernel reads them
-template <bool ZS, int NSEG, int NT1, int NT2, bool TAPS = false, bool XREG = false, bool COHERENT = false>
+//   XPOSE (> 0) : ... in the micro-batch latency kernel's layout (latency_mb.hip): feature k of window w at ((k >> 2) * XPOSE + w) * 4 + (k & 3) -- the
+//                 four k of an MFMA step side by side, XPOSE windows per 16-byte column -- instead of row w of a (windows, 4736) matrix
+template <bool ZS, int NSEG, int NT1, int NT2, bool TAPS = false, bool XREG = false, bool COHERENT = false, int XPOSE = 0>
 __device__ __forceinline__ void conv_seg_body(float* __restrict__ act, const float* __restrict__ src, int64_t win0, int sg, const ConvPack& pk,
                                               float* __restrict__ feat, const LayerTaps& taps, const float (*xin)[38] = nullptr, int chalf = -1)
 {   // chalf (latency mode): 0 / 1 = this workgroup finishes only output channels 64 chalf .. 64 chalf + 63 of conv4 (a second workgroup on the
@@ -712,7 +714,10 @@ __device__ __forceinline__ void conv_seg_body(float* __restrict__ act, const flo
                 for (int r = 0; r < 4; ++r) {
                     const float m0 = acc[0][nt][0][r], m1 = acc[0][nt][1][r], m2 = acc[0][nt][2][r], m3 = acc[0][nt][3][r];
                     const float v = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
-                    if constexpr (COHERENT) __hip_atomic_store(base + r * 37, nan0 ? nanv : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (XPOSE > 0) {
+                        const int k = (co2 + 4 * q + r) * 37 + m;
+                        __hip_atomic_store(feat + ((size_t)(k >> 2) * XPOSE + win0) * 4 + (k & 3), nan0 ? nanv : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else if constexpr (COHERENT) __hip_atomic_store(base + r * 37, nan0 ? nanv : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else base[r * 37] = nan0 ? nanv : v;
                     if constexpr (TAPS) {      // conv4 before the pool: pairs a4..b4 (t = 74, which the pool drops, is never computed here)
                         float* tp = taps.conv4 + (win0 * 128 + co2 + 4 * q + r) * 75 + 2 * m;

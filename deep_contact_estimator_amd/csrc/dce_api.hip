@@ -66,7 +66,7 @@ const TuneKey kTuneKeys[] = {
     TK(split_min, 'l'), TK(split_max, 'l'), TK(chain_min, 'l'), TK(chain_max, 'l'), TK(chain_max3, 'l'), TK(chain_bn16_max, 'l'),
     TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(wino1_w8, 'b'),
     TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TK(x3_bf16_terms, 'i'), TK(bf16_conv_h2, 'b'), TK(bf16_conv_h2_min, 'l'),
-    TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
+    TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_mb, 'b'), TK(latency_mb_chalf, 'i'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
     TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TK(x3_unfused, 'b'), TK(x3_permk, 'b'), TK(x3_fc3, 'b'), TK(split_guard, 'b'), TK(h2_fc3, 'b'), TK(h2_min_tiles, 'i'), TK(guard_alloc, 'i'), TK(guard_mask, 'i'),
     TKX(bf16_k32, 'b'), TKX(gemm_lockstep, 'b'), TKX(gemm_pipe, 'b'), TKX(gemm_ki, 'b'), TKX(conv4, 'i'), TKX(x3_persist, 'b'), TKX(x3_pair, 'b'),
     TKX(x3_persist_min, 'l'), TKX(x3_pair_min, 'l'), TKX(conv_direct, 'b'), TKX(h2_ksplit, 'b'), TKX(bf16_fc3_ksplit, 'b'), TKX(one_per_cu, 'b'), TKX(trace_wino1, 'b'),
@@ -250,6 +250,8 @@ LatArgs lat_args(dce_ctx* c)
     a.fc_delay_ticks = (unsigned long long)(c->tuning.latency_fc_delay > 0 ? c->tuning.latency_fc_delay : 0);
     a.deadline_ticks = 5000000ull;                                    // 50 ms of the 100 MHz wall clock: far beyond any hand-over of a healthy launch
     a.idle_ticks = (unsigned long long)(c->tuning.latency_idle_ms > 0 ? c->tuning.latency_idle_ms : 1) * 100000ull;
+    a.mb_w1 = c->lat_mb_w1; a.mb_w2 = c->lat_mb_w2;
+    a.mb_feat = c->lat_mb_feat; a.mb_h1 = c->lat_mb_h1; a.mb_plt = c->lat_mb_plt; a.mb_flags = c->lat_mb_flags;
     return a;
 }
 
@@ -350,6 +352,7 @@ struct Plan {
     Fc3 fc3; int64_t fused_rows;          // rows the fused fc.3 + fc.6 kernel takes (whole rounds); the rest goes to the chain kernel + tail
     bool guarded;                         // DCE_FP32_SPLIT on pre-normalised windows: the conv kernel checks every window's range (SplitGuard)
     bool latency;                         // latency mode, one window: the whole path in ONE kernel of 256 co-resident workgroups (latency.hip)
+    bool latency_mb;                      // latency mode, 2 .. 32 windows: the same on MFMA tiles (latency_mb.hip)
 };
 
 Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
@@ -357,8 +360,12 @@ Plan choose_plan(const dce_ctx* c, int zscore, int64_t n)
     const Tuning& tu = tune();                                        // (bound by run_chunk: the context's switches, or their gated form)
     const bool wino = !(DCE_EXPERIMENTS && tu.conv_direct);
     const bool online = c->src_row_dev != nullptr;                    // the online graph: the window start lives in device memory
-    Plan p{Conv::WinoF32, 0, Fc0::F32, false, Fc3::F32, 0, false, false};
-    if (tu.latency && c->precision == DCE_FP32 && n == 1 && !online && !c->done_flag && !c->want_feat && !c->want_h2 && !c->gate_on) { p.latency = true; return p; }
+    Plan p{Conv::WinoF32, 0, Fc0::F32, false, Fc3::F32, 0, false, false, false};
+    // the latency plans serve WHOLE calls only (call_total == n): the last window of a call of k max_batch + 1 windows stays on the batch kernels,
+    // so that DCE_FP32's "a window's bits do not depend on the size of the call" holds inside a call also for latency=1 contexts
+    const bool lat = tu.latency && c->precision == DCE_FP32 && c->call_total == n && !online && !c->done_flag && !c->want_feat && !c->want_h1 && !c->want_h2 && !c->gate_on;
+    if (lat && n == 1) { p.latency = true; return p; }
+    if (lat && tu.latency_mb && n >= 2 && n <= LATMB_MAX_N && c->lat_mb_flags && c->lat_mb_w1) { p.latency_mb = true; return p; }
     if (c->precision == DCE_BF16_FC) {
         const bool x3c = tu.x3_conv && wino && n >= tu.x3_bf16_min && (!online || zscore);
         const bool pair = DCE_EXPERIMENTS && tu.x3_conv && tu.x3_pair && wino && !online && !c->want_feat && n >= tu.x3_pair_min;
@@ -436,6 +443,15 @@ int run_plan(dce_ctx* c, const Plan& p, const float* src, int zscore, int64_t n,
         a.seq = ++c->lat_seq;
         a.src = src; a.logits = logits; a.pred = pred; a.contacts = contacts; a.packed = packed;
         HIP_TRY(c, launch_latency(zscore ? 1 : 0, a, st));
+        return DCE_OK;
+    }
+    if (p.latency_mb) {
+        Timer t(c, 0);
+        LatArgs a = lat_args(c);
+        a.seq = ++c->lat_mb_seq;
+        a.mb_n = (int)n; a.mb_chalf = n <= c->tuning.latency_mb_chalf && n <= LATMB_MAX_N / 2 ? 1 : 0;
+        a.src = src; a.logits = logits; a.pred = pred; a.contacts = contacts; a.packed = packed;
+        HIP_TRY(c, launch_latency_mb(zscore, a, st));
         return DCE_OK;
     }
     unsigned short* featb = reinterpret_cast<unsigned short*>(c->feat);
@@ -578,6 +594,7 @@ int run_all(dce_ctx* c, const float* src, int zscore, int64_t n, int64_t src_flo
             float* logits, int32_t* pred, uint8_t* contacts, uint8_t* packed = nullptr)
 {
     const int64_t row_floats = zscore ? CH : (int64_t)WIN * CH;
+    c->call_total = n;
     const int64_t nchunks = (n + c->max_batch - 1) / c->max_batch;
     auto chunk_rows = [&](int64_t i) { const int64_t i0 = i * c->max_batch; return (n - i0) < c->max_batch ? (n - i0) : c->max_batch; };
     if (on_device) {
@@ -767,6 +784,16 @@ int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* o
         CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->lat_mbox), sizeof(LatMailbox), hipHostMallocMapped | hipHostMallocCoherent));
         memset(c->lat_mbox, 0, sizeof(LatMailbox));
         CREATE_TRY(hipStreamCreateWithFlags(&c->lat_stream, hipStreamNonBlocking));
+        // the micro-batch form: data in ordinary device memory (read through L2 with agent-scope loads), one 64-bit flag per producer in fine-grained memory
+        CREATE_TRY(init_latency_mb());
+        CREATE_TRY(dev_alloc(&c->lat_mb_feat, guard_of(c, 9), (size_t)LATMB_MAX_N * FEAT * sizeof(float)));
+        CREATE_TRY(hipMemset(c->lat_mb_feat, 0, (size_t)LATMB_MAX_N * FEAT * sizeof(float)));
+        CREATE_TRY(dev_alloc(&c->lat_mb_h1, guard_of(c, 9), (size_t)LATMB_MAX_N * FC1 * sizeof(float)));
+        CREATE_TRY(hipMemset(c->lat_mb_h1, 0, (size_t)LATMB_MAX_N * FC1 * sizeof(float)));
+        CREATE_TRY(dev_alloc(&c->lat_mb_plt, guard_of(c, 9), (size_t)32 * LATMB_MAX_N * NCLS * sizeof(float)));
+        CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->lat_mb_flags), 576 * sizeof(unsigned long long), hipDeviceMallocFinegrained));
+        CREATE_TRY(hipMemset(c->lat_mb_flags, 0, 576 * sizeof(unsigned long long)));
+        CREATE_TRY(hipDeviceSynchronize());
     }
 #undef CREATE_TRY
     *out = c;
@@ -781,6 +808,7 @@ void dce_destroy(dce_ctx* c)
     if (c->lat_stream) hipStreamDestroy(c->lat_stream);
     if (c->lat_mbox) hipHostFree(c->lat_mbox);
     dev_free(c->lat_x); dev_free(c->lat_hist); dev_free(c->lat_hist_state);
+    dev_free(c->lat_mb_feat); dev_free(c->lat_mb_h1); dev_free(c->lat_mb_plt); dev_free(c->lat_mb_flags);
     if (c->lat_trace) hipHostFree(c->lat_trace);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     if (c->stream != c->own_stream) hipStreamSynchronize(c->stream);   // scratch may still be in use there
@@ -882,6 +910,13 @@ int dce_finalize_weights(dce_ctx* c, int precision)
                                                      : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
         }
     };
+    // latency mode's micro-batch kernel (latency_mb.hip): fc.0 and fc.3 once more, in the order its lanes hold them
+    size_t off_mb1 = 0, off_mb2 = 0;
+    const bool want_mb = c->tuning.latency && c->tuning.latency_mb && precision == DCE_FP32;
+    if (want_mb) {
+        off_mb1 = reserve(latmb_pack_floats(FC1, FEAT)); latmb_pack_host(c->host_w[8].data(), FC1, FEAT, img.data() + off_mb1);
+        off_mb2 = reserve(latmb_pack_floats(FC2, FC1));  latmb_pack_host(c->host_w[10].data(), FC2, FC1, img.data() + off_mb2);
+    }
     const bool want_cx = precision == DCE_FP32_SPLIT || (precision == DCE_BF16_FC && c->tuning.x3_conv);
     const bool want_pair = (want_cx && (c->tuning.x3_pair || c->tuning.x3_permk)) || precision == DCE_FP32_F16X2;      // fc.0's weights once more, K axis in the conv kernels' feature order t' * 128 + c
     std::vector<float> w1p;
@@ -987,6 +1022,7 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     c->fc1w = c->d_weights + off_fc[0]; c->fc1b = c->d_weights + off_fc[1];
     c->fc2w = c->d_weights + off_fc[2]; c->fc2b = c->d_weights + off_fc[3];
     c->fc3w = c->d_weights + off_fc[4]; c->fc3b = c->d_weights + off_fc[5];
+    c->lat_mb_w1 = want_mb ? c->d_weights + off_mb1 : nullptr; c->lat_mb_w2 = want_mb ? c->d_weights + off_mb2 : nullptr;
     c->fc1w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[0] : nullptr;
     c->fc2w_bf16 = precision == DCE_BF16_FC ? c->d_weights + off_bf[1] : nullptr;
     c->fc1w_bf16p = precision == DCE_BF16_FC && want_pair ? c->d_weights + off_bfp : nullptr;
@@ -1474,6 +1510,16 @@ int dce_debug_latency_trace(dce_ctx* c, unsigned long long out[16])
 {
     if (!c || !out || !c->lat_trace) return DCE_ERR_STATE;
     for (int i = 0; i < 16; ++i) out[i] = __atomic_load_n(&c->lat_trace[i], __ATOMIC_RELAXED);
+    if (c->lat_mb_flags) {
+        // the micro-batch kernel's fc.0 weight stream: [12] the earliest request, [13] the latest landing over its 128 tiles (38.8 MB between the two)
+        DEVICE_GUARD(c);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        unsigned long long st[256];
+        HIP_TRY(c, hipMemcpy(st, c->lat_mb_flags + 320, sizeof st, hipMemcpyDeviceToHost));
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int i = 0; i < 128; ++i) { if (st[i] < lo) lo = st[i]; if (st[128 + i] > hi) hi = st[128 + i]; }
+        out[12] = lo; out[13] = hi;
+    }
     return DCE_OK;
 }
 

@@ -103,6 +103,11 @@ struct dce_ctx {
     unsigned long long lat_seq = 0;        // estimates requested since the counters were last zeroed
     unsigned lat_req = 0;                  // mailbox request number
     int lat_count = 0;                     // samples in the history (host mirror)
+    float *lat_mb_feat = nullptr, *lat_mb_h1 = nullptr, *lat_mb_plt = nullptr;   // micro-batch form (latency_mb.hip): features, h1, partial logits of up to 32 windows
+    unsigned long long* lat_mb_flags = nullptr;                                  // ... its producer flags (fine-grained device memory)
+    const float *lat_mb_w1 = nullptr, *lat_mb_w2 = nullptr;                      // ... fc.0 / fc.3 in its per-lane order (inside d_weights; latency contexts of DCE_FP32)
+    unsigned long long lat_mb_seq = 0;     // ... requests so far
+    int64_t call_total = 0;                // windows of the API call being served (latency plans serve whole calls only: a window's bits must not depend on where a chunk boundary fell)
 
     // multi-GPU (dce_comm.hip): one RCCL communicator per ctx, collectives on comm_stream behind the ctx stream
     void* comm = nullptr;                  // ncclComm_t

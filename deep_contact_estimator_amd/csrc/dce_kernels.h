@@ -42,6 +42,8 @@ struct Tuning {
     bool online_graph = false, online_direct = false;       // online pushes as ONE captured hipGraph launch / as plain launches with per-push parameters
     bool latency = false;                                   // 1: the LATENCY MODE (latency.hip; DCE_FP32 only): one-window calls as one kernel of 256 co-resident workgroups, online pushes served by a resident kernel that polls a mailbox in pinned memory.  Inside the fp32 tolerance, NOT the batch path's bits
     int latency_fc_delay = 100;                             // 10 ns ticks by which the fc.0 role starts its 38.8 MB weight stream behind the conv role (one-window calls: 30.1 us with 0, 28.0 with 1 us, 28.6 / 28.9 with 3 / 6 us -- the conv role's first weight fragments would queue behind the stream; profiles/r5h_latency_ab.txt)
+    bool latency_mb = true;                                 // ... calls of 2 .. 32 windows as ONE kernel too (latency_mb.hip: conv segments, fc.0 with register-resident weights on MFMA tiles, fc.3 + fc.6 on the conv workgroups); 0: the batch path's four launches
+    int latency_mb_chalf = 16;                              // ... up to this many windows two conv workgroups share a quarter segment (each half of conv4's output channels)
     int latency_idle_ms = 250;                              // ... how long the resident kernel waits for the next sample before it leaves by itself
     // -- DCE_BF16_FC
     bool bf16_stream = true;                                // 0: fc.0 / fc.3 at <= 256 windows on the 64x64 tile GEMM instead of fc_stream_bf16.hip
@@ -342,7 +344,17 @@ struct LatArgs {
     unsigned req_base, done_base;                                              // mailbox numbers at launch (requests posted / estimates delivered so far)
     unsigned long long fc_delay_ticks;                                         // (A/B) the fc.0 role starts its weight stream this much later
     unsigned long long* trace;                                                 // NULL, or 16 wall-clock stamps of the last request (tools/latency_mode.py)
+    // micro-batch form (latency_mb.hip): 2 .. LATMB_MAX_N windows in one launch
+    int mb_n, mb_chalf;                                                        // windows; 1: two conv workgroups per quarter segment (n <= 16)
+    const float *mb_w1, *mb_w2;                                                // fc.0 / fc.3 packed per (tile, wave, granule, lane) (latmb_pack_host)
+    float *mb_feat, *mb_h1, *mb_plt;                                           // device memory: features [4736 / 4][32][4], h1 [2048 / 4][32][4] (latency_mb.hip's quad layout), partial logits [32 tiles][32][16]
+    unsigned long long* mb_flags;                                              // fine-grained device memory: [128] conv + [128] fc.0 + [64] fc.3 producer flags (the request's number)
 };
+constexpr int LATMB_MAX_N = 32;
+size_t     latmb_pack_floats(int rows, int K);
+void       latmb_pack_host(const float* W, int rows, int K, float* out);
+hipError_t init_latency_mb();
+hipError_t launch_latency_mb(int zscore, const LatArgs& a, hipStream_t st);
 hipError_t init_latency();
 int        latency_grid();                                                     // workgroups = CUs the mode needs
 hipError_t launch_latency(int mode /* 0 one window, pre-normalised; 1 raw rows (z-score fused); 2 service */, const LatArgs& a, hipStream_t st);

@@ -10,6 +10,7 @@
 // the question "is every prefetch, ragged tile and padded row inside its buffer" gets a deterministic answer (round 6: the intermittent fault of round
 // 5's fc.0 K-split variant).
 #include "dce_kernels.h"
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -22,10 +23,16 @@ std::mutex g_mu;
 std::unordered_map<void*, GuardRec> g_recs;
 }  // namespace
 
+static bool guard_log() { static const bool on = [] { const char* v = getenv("DCE_GUARD_LOG"); return v && atoi(v) != 0; }(); return on; }
+
 hipError_t dev_alloc_raw(void** out, size_t bytes, int guard)
 {
     *out = nullptr;
-    if (guard <= 0) return hipMalloc(out, bytes ? bytes : 1);
+    if (guard <= 0) {
+        const hipError_t e0 = hipMalloc(out, bytes ? bytes : 1);
+        if (guard_log()) fprintf(stderr, "dev_alloc plain  %p .. %p (%zu bytes)\n", *out, static_cast<char*>(*out) + bytes, bytes);
+        return e0;
+    }
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -56,6 +63,7 @@ hipError_t dev_alloc_raw(void** out, size_t bytes, int guard)
     }
     void* p = guard == 2 ? r.map : r.map + (r.mapped - need);
     { std::lock_guard<std::mutex> lk(g_mu); g_recs[p] = r; }
+    if (guard_log()) fprintf(stderr, "dev_alloc guard%d %p .. %p (%zu bytes; mapping %p .. %p)\n", guard, p, static_cast<char*>(p) + need, bytes, (void*)r.map, (void*)(r.map + r.mapped));
     *out = p;
     return hipSuccess;
 }

@@ -326,7 +326,11 @@ int  dce_debug_split_h2(const float* x, size_t n, unsigned short* terms);
 
 /* Debug hook of the latency mode (option latency=1, contexts created with DCE_LAT_TRACE set): 16 stamps of the device's 100 MHz wall
  * clock taken by the last request -- [0] request seen, [1] window ready, [2] conv segment 0 done, [3] its arrival posted, [4] features
- * seen by fc workgroup 0, [5] its fc.0 rows done, [6] h1 complete, [7] its fc.3 rows done, [8] h2 complete, [9]/[10] results written. */
+ * seen by fc workgroup 0, [5] its fc.0 rows done, [6] h1 complete, [7] its fc.3 rows done, [8] h2 complete, [9]/[10] results written.
+ * After a call of 2 .. 32 windows (the micro-batch kernel, csrc/latency_mb.hip): [1] conv workgroup 0 starts, [2] its segment done, [3] its flag posted,
+ * [4] fc.0 tile 0 has requested its weights, [5] they have landed, [6] it has seen every conv flag, [7] its columns of h1 posted, [8] fc.3 tile 0 has seen
+ * every fc.0 flag, [9] workgroup 0 waits for the partial logits, [10] has them, [11] results written; [12] / [13] the earliest request and the latest
+ * landing of fc.0's weights over the 128 tiles (the 38.8 MB stream that runs under the conv role). */
 int  dce_debug_latency_trace(dce_ctx* ctx, unsigned long long stamps[16]);
 
 /* Test hooks of the memory-safety tests (csrc/dev_alloc.hip; option guard_alloc=1 | 2 of dce_create_ex): a context created with the option keeps EVERY

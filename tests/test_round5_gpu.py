@@ -228,8 +228,11 @@ def test_latency_mode_one_window_calls_vs_oracle(orc):
     assert np.array_equal(pk[0, :64].view(np.float32), got[3]) and np.array_equal(pk[0, 64:], orc.decimal2binary(pred[3:4])[0])
     # the batch path is within the tolerance of it too, and is what two or more windows run
     tol_ok(got, b.predict(zw)["logits"], "latency mode vs the batch path")
-    two = m.predict(zw[:2])
-    assert "latency_one" not in m.last_plan() and np.array_equal(two["logits"], b.predict(zw[:2])["logits"])
+    two = m.predict(zw[:2])                                         # (round 6: two .. 32 windows have a one-kernel form of their own, tests/test_round6_gpu.py)
+    assert m.last_plan() == ["latency_mb"], m.last_plan()
+    tol_ok(two["logits"], ref["logits"][:2], "latency mode, two windows")
+    many = m.predict(zw[:40])
+    assert not any(k.startswith("latency") for k in m.last_plan()) and np.array_equal(many["logits"], b.predict(zw[:40])["logits"])
     bad = zw[5:6].copy(); bad[0, 17, 3] = np.nan
     r = m.predict(bad)
     assert np.isnan(r["logits"]).all() and r["pred"][0] == 0
