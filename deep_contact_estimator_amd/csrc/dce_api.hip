@@ -715,8 +715,21 @@ int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* o
     Tuning parsed;
     {   // the A/B switches: the option string, else DCE_TUNE, over the defaults (one table: kTuneKeys) -- checked before anything else, so
         // that a misspelt option is reported as what it is also on a box without a device
+        // DCE_TUNE first, the option string on top of it: a context made with options -- also the empty string a binding passes for "none" -- keeps
+        // whatever the user's environment switches that the options do not name
         char msg[256];
-        if (!tuning_parse(options ? options : getenv("DCE_TUNE"), parsed, msg, (int)sizeof msg)) return fail(nullptr, DCE_ERR_ARG, "dce_create: %s", msg);
+        if (!tuning_parse(getenv("DCE_TUNE"), parsed, msg, (int)sizeof msg)) return fail(nullptr, DCE_ERR_ARG, "dce_create: DCE_TUNE: %s", msg);
+        if (!tuning_parse(options, parsed, msg, (int)sizeof msg)) return fail(nullptr, DCE_ERR_ARG, "dce_create: %s", msg);
+        // the A/B switches were environment variables of their own until round 4 (DCE_GEMM=lockstep, DCE_CONV4=1, ..): a script that still sets one
+        // would silently measure the defaults -- say so, once
+        static const bool warned = [] {
+            for (const char* k : {"DCE_GEMM", "DCE_CONV", "DCE_CONV4", "DCE_X3_PAIR", "DCE_X3_CONV", "DCE_X3_PERSIST", "DCE_X3_PERMK", "DCE_X3_UNFUSED", "DCE_ONLINE_GRAPH",
+                                  "DCE_ONLINE_DIRECT", "DCE_FC23", "DCE_GEMV", "DCE_PHASED_MIN_TILES", "DCE_WINO1_MAX", "DCE_BF16_STREAM"})
+                if (getenv(k)) fprintf(stderr, "libdce: the environment variable %s is no longer read -- the A/B switches are options of dce_create_ex / keys of DCE_TUNE "
+                                               "(\"key=value,key=value\"; the table is kTuneKeys in csrc/dce_api.hip, DESIGN.md appendix)\n", k);
+            return true;
+        }();
+        (void)warned;
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1111,6 +1124,7 @@ int dce_unpack_results(dce_ctx* c, const uint8_t* packed, int64_t n, int on_devi
     if (n == 0) return DCE_OK;
     if (on_device) {
         DEVICE_GUARD(c);
+        { const int rc = lat_quiesce(c); if (rc) return rc; }       // (every device-touching entry point: the latency mode's resident kernel leaves first)
         HIP_TRY(c, launch_unpack_results(packed, n, logits, pred, contacts, c->stream));
         return DCE_OK;
     }
@@ -1133,6 +1147,7 @@ int dce_zscore_windows(dce_ctx* c, const float* seq, int64_t T, int64_t first, i
         return fail(c, DCE_ERR_ARG, "dce_zscore_windows: windows [%lld,%lld) out of range for T=%lld",
                     (long long)first, (long long)(first + n), (long long)T);
     if (n == 0) return DCE_OK;
+    { const int rc = lat_quiesce(c); if (rc) return rc; }
     if (on_device) {
         HIP_TRY(c, launch_zscore_windows(seq + first * CH, n, windows_out, c->stream));
         return DCE_OK;
@@ -1232,6 +1247,7 @@ int dce_confusion_counts(dce_ctx* c, const int32_t* pred, const int64_t* labels,
     if (n < 0 || !counts || (n > 0 && (!pred || !labels))) return fail(c, DCE_ERR_ARG, "dce_confusion_counts: bad argument");
     DEVICE_GUARD(c);
     if (n == 0) return DCE_OK;
+    { const int rc = lat_quiesce(c); if (rc) return rc; }
     if (on_device) {
         HIP_TRY(c, launch_confusion16(pred, labels, n, reinterpret_cast<unsigned long long*>(counts), c->stream));
         return DCE_OK;
@@ -1522,6 +1538,11 @@ int dce_debug_latency_trace(dce_ctx* c, unsigned long long out[16])
     }
     return DCE_OK;
 }
+
+}  // extern "C"
+// (for dce_comm.hip: the exchange entry points quiesce the latency mode's resident kernel like every other device-touching call)
+int dce_internal_quiesce(dce_ctx* c) { return lat_quiesce(c); }
+extern "C" {
 
 int dce_debug_alloc(dce_ctx* c, size_t bytes, void** out)
 {

@@ -159,6 +159,7 @@ int dce_gather_results(dce_ctx* c, const uint8_t* packed_local, int64_t n_local,
 {
     int rc = need_comm(c, "dce_gather_results");
     if (rc) return rc;
+    if ((rc = dce_internal_quiesce(c))) return rc;
     Rccl* r = rccl(c);
     if (!r) return DCE_ERR_COMM;
     const int W = c->comm_world, me = c->comm_rank;
@@ -228,6 +229,7 @@ int dce_allreduce_counts(dce_ctx* c, int64_t* counts, int on_device)
 {
     int rc = need_comm(c, "dce_allreduce_counts");
     if (rc) return rc;
+    if ((rc = dce_internal_quiesce(c))) return rc;
     if (!counts) return fail(c, DCE_ERR_ARG, "dce_allreduce_counts: NULL counts");
     Rccl* r = rccl(c);
     if (!r) return DCE_ERR_COMM;

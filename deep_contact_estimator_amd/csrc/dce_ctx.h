@@ -128,6 +128,8 @@ struct dce_ctx {
     int64_t prof_n[DCE_PROFILE_SLOTS] = {};
 };
 
+int dce_internal_quiesce(dce_ctx* c);     // dce_api.hip: the latency mode's resident kernel, if any, leaves (and a deadline error of it is reported)
+
 inline int fail(dce_ctx* c, int code, const char* fmt, ...)
 {
     char buf[512];

@@ -313,7 +313,7 @@ constexpr int ONLINE_ROWS = 4096;     // rows of the sample buffer; the last 149
 hipError_t launch_online_append_state(float* ring, OnlineState* state, const float* sample_host, hipStream_t st);
 
 // ---- latency mode (latency.hip; option latency=1): one window through the whole net in ONE kernel of 256 co-resident workgroups
-struct LatSync { unsigned long long feat; unsigned quit, pad; };               // fine-grained device memory: arrivals of the conv workgroups (monotonic: request s waits for 8 s), the service's quit word
+struct LatSync { unsigned long long feat; unsigned quit, started; };           // fine-grained device memory: arrivals of the conv workgroups (monotonic: request s waits for 8 s), the service's quit word, conv workgroups of the service that hold their snapshot of the history (zeroed with the rest before every start)
 struct LatMailbox {                                                            // pinned host memory, device-visible, coherent
     unsigned req;              // host -> device: number of the newest request (written LAST, release)
     unsigned kind;             //   0 append the sample, 1 append + estimate, 2 quit

@@ -183,7 +183,21 @@ void latency_kernel(LatArgs a)
             LatMailbox* const mb = a.mbox;
             int head = a.hist_state[0], count = a.hist_state[1];
             for (int i = tid; i < LAT_HIST; i += 512) hist[i] = a.hist[i];
-            if (lead && tid == 0) __hip_atomic_store(&mb->alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // The host posts its first request once `alive` is up, and the lead then advances the device copy of the history (a.hist, a.hist_state).
+            // A conv workgroup that was dispatched late -- another stream held its CU -- must not find that copy already advanced: it would apply the
+            // request it then sees a second time and keep a history one row off for the life of the service.  So every conv workgroup ARRIVES on a start
+            // counter once its snapshot is in its registers / LDS, and the lead raises `alive` only when all eight have (round 5's advice).
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(&sy->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lead && tid == 0) {
+                const unsigned long long t0 = wall_clock64();
+                bool up = true;
+                while (__hip_atomic_load(&sy->started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)LAT_CONV) {
+                    if (wall_clock64() - t0 > 500000000ull) { up = false; break; }      // 5 s: the host's own limit for the start (it then reports the failure)
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (up) __hip_atomic_store(&mb->alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             __syncthreads();
             unsigned last = a.req_base;
             for (;;) {

@@ -109,9 +109,11 @@ def id_file_rendezvous(path: str, rank: int, make_id, timeout: float = 120.0) ->
     <16-byte nonce><128-byte id>, the nonce comes from DCE_COMM_NONCE (the launcher draws one per job; tools/launch_ranks.sh);
     rank 0 removes a left-over, writes a temporary file and renames it; the others accept only a file with THEIR nonce -- a
     stale id would otherwise send ncclCommInitRank waiting for peers that will never come -- and give up after `timeout`.
-    Without DCE_COMM_NONCE the nonce is DERIVED from what the ranks of one job share and two jobs on a node do not: the launcher's
-    rendezvous endpoint (MASTER_ADDR:MASTER_PORT, TORCHELASTIC_RUN_ID), else the parent process id (the ranks of a launcher are
-    siblings).  Ranks started by hand from different shells with neither have to set DCE_COMM_NONCE."""
+    Without DCE_COMM_NONCE the nonce is DERIVED from what the ranks of one job share and two jobs on a node -- or two runs of the same job,
+    one after the other on the default port -- do not: the launcher's rendezvous endpoint (MASTER_ADDR:MASTER_PORT, TORCHELASTIC_RUN_ID)
+    AND the parent process id (the ranks of one launcher are siblings; a relaunch has another launcher process).  Ranks that are not
+    siblings -- started by hand from different shells, or next to tests/c/abi_ranks.c, whose nonce is all zeros when the variable is unset --
+    have to set DCE_COMM_NONCE to the same value everywhere."""
     import hashlib
     import os
     import time
@@ -119,9 +121,7 @@ def id_file_rendezvous(path: str, rank: int, make_id, timeout: float = 120.0) ->
     if explicit:
         nonce = explicit.encode()[:ID_FILE_NONCE].ljust(ID_FILE_NONCE, b"\0")
     else:
-        shared = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
-        if not shared.strip("|"):
-            shared = f"ppid:{os.getppid()}"
+        shared = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")) + f"|ppid:{os.getppid()}"
         nonce = hashlib.sha256(shared.encode()).digest()[:ID_FILE_NONCE]
     if rank == 0:
         try:
@@ -144,7 +144,9 @@ def id_file_rendezvous(path: str, rank: int, make_id, timeout: float = 120.0) ->
         except FileNotFoundError:
             pass
         time.sleep(0.01)
-    raise RuntimeError(f"no ncclUniqueId of this job (DCE_COMM_NONCE) appeared at {path} within {timeout:.0f} s")
+    raise RuntimeError(f"no ncclUniqueId of this job appeared at {path} within {timeout:.0f} s: rank 0 did not write one, or wrote it under another nonce -- "
+                       "DCE_COMM_NONCE must be the SAME on every rank (unset, it is derived from MASTER_ADDR / MASTER_PORT / TORCHELASTIC_RUN_ID and the "
+                       "parent process id, so ranks that are not children of one launcher have to set it)")
 
 
 _bootstraps = 0

@@ -230,11 +230,14 @@ int  dce_confusion_counts(dce_ctx* ctx, const int32_t* pred, const int64_t* labe
  * kernel from pinned host memory, the estimate is written by the last kernel to pinned host memory
  * followed by a sequence number the call polls (~60 us per push on MI355X). */
 /* LATENCY MODE (option "latency=1" of dce_create_ex; DCE_FP32 contexts; csrc/latency.hip) -- the reference ships batch_size 1
- * (config/inference_one_seq_params.yaml:10).  A ONE-window dce_forward_windows / dce_infer_sequence (and their _packed forms) is then ONE
- * kernel of 256 co-resident workgroups (stream-ordered like any launch; 26 us instead of 43), and dce_online_push is served by the same
+ * (config/inference_one_seq_params.yaml:10) and 30 (config/test_params.yaml:9).  A dce_forward_windows / dce_infer_sequence call (and their _packed
+ * forms) of ONE window is then ONE kernel of 256 co-resident workgroups (stream-ordered like any launch; 26 us instead of 43), a call of 2 .. 32
+ * windows likewise (csrc/latency_mb.hip: 32 us up to 16 windows, 39.5 us at 30 instead of 43 / 51; option latency_mb=0 keeps those on the batch path's
+ * four launches).  Only WHOLE calls take these kernels: a call cut into chunks (more windows than max_batch) runs the batch kernels for every chunk, so
+ * that a window's bits never depend on where a chunk boundary fell.  dce_online_push is served by the one-window
  * kernel in RESIDENT form: started by the first push on a stream of its own, it takes every sample from a mailbox in pinned host memory
  * and answers through it (no launch, copy or stream operation per push: ~30 us per push from C instead of ~57).  It leaves when any other
- * entry point of the context is called, on dce_online_reset / dce_destroy, or by itself after latency_idle_ms (250) without a sample; the
+ * device-touching entry point of the context is called (forward / sequence / taps / z-score / unpack / confusion counts / the exchange calls), on dce_online_reset / dce_destroy, or by itself after latency_idle_ms (250) without a sample; the
  * next push restarts it with the sample history intact.  Results: inside the fp32 tolerance of the reference, deterministic, NOT the bits of
  * the batch path (another summation order).  The mode needs the whole device -- one workgroup per CU, 256 CUs, dce_create_ex refuses a
  * smaller one; other work on the device waits while a launch or the resident kernel runs; one latency-mode stream per device.  Every

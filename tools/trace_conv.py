@@ -20,7 +20,7 @@ torch.cuda.synchronize()
 lib = _lib.load()
 nb = B // 2
 buf = np.zeros((nb, 16), np.uint64)
-reader = lib.dce_debug_trace_read if os.environ.get('DCE_CONV') == 'direct' else lib.dce_debug_trace_read_wino
+reader = lib.dce_debug_trace_read if 'conv_direct=1' in os.environ.get('DCE_TUNE', '') else lib.dce_debug_trace_read_wino      # (the direct-form stack: DCE_TUNE=conv_direct=1, experiments build)
 rc = reader(buf.ctypes.data_as(C.c_void_p), nb)
 assert rc == 0
 t = buf[:, :10].astype(np.int64)
