@@ -101,7 +101,7 @@ PIPES = [   # (prefix of the plan note, pipe, MFMAs issued per fp32-grade produc
 def plan_stages(plan):
     """dce_last_plan's notes -> {stage: note of the kernel family that ran it} (a stage's first launch names it: a fused fc.3 launch may be followed
     by a small remainder launch of another family)."""
-    plan = [n for n in (plan or []) if n not in ("split3", "gated_fp32_fallback", "split_guard_refused", "f16x2_refused")]
+    plan = [n for n in (plan or []) if n not in ("split3", "gated_fp32_fallback", "split_guard_refused", "f16x2_refused", "fp32_split_is_fp32_f16x2")]
     conv = next((n for n in plan if n.startswith("conv_")), None)
     fcs = [n for n in plan if n.startswith("fc") and n not in ("fc6_combine", "fc3_tail")]
     tail = next((n for n in plan if n in ("fc6_combine", "fc3_tail")), None)
@@ -498,7 +498,7 @@ def latency_cold_stream(torch, contact_cnn, sd, dev, windows, b=30, reps=12):
 MODE_TEXT = {
     "bf16_fc": "BASELINE configs[4]: the bench step ({B} windows) with fc.0/fc.3 on bf16 MFMA, fp32 accumulate; conv stack with results of fp32 grade "
                "(two fp16 terms per operand with per-window scales, three MFMAs per product, conv_h2.hip; options: bf16_conv_h2=0: two bf16 terms, ~17 bits; "
-               "x3_bf16_terms=3: three bf16 terms, six MFMAs per product; x3_conv=0: the fp32 Winograd kernel), features rounded to bf16, fc.6 fp32",
+               "x3_conv=0: the fp32 Winograd kernel), features rounded to bf16, fc.6 fp32",
     "fp32_split": "the bench step ({B} windows) with the conv stack and fc.0 on the bf16 matrix pipe, every fp32 operand as three bf16 terms "
                   "(six MFMAs per product, fp32 accumulate: fp32 results, not the fp32 path's bits -- opt-in, include/dce.h DCE_FP32_SPLIT); "
                   "fc.3 and fc.6 fp32 MFMA",
@@ -560,8 +560,8 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
     m.close()
     if precision == "bf16_fc" and (plan or [""])[0].startswith("conv_h2"):
         # The mode as it ships runs its conv stack on two FP16 terms with per-window scales (conv_h2.hip: results of fp32 grade -- BASELINE
-        # configs[4] as it is written).  The same step with the two other conv stacks the mode has had, so that the line shows what each costs
-        # and changes: TWO bf16 terms (~17 bits; rounds 4-5, option bf16_conv_h2=0) and THREE bf16 terms (fp32-grade at six MFMAs per product; round 3)
+        # configs[4] as it is written).  The same step with the conv stack the mode had in rounds 4-5, so that the line shows what the change costs
+        # and buys: TWO bf16 terms (~17 bits; option bf16_conv_h2=0).  (Round 3's three-term stack lives in the experiments build.)
         def variant(tune):
             mv = contact_cnn(device=dev.index, max_batch=B, precision=precision, tune=tune)
             mv.load_state_dict(sd).eval()
@@ -578,7 +578,6 @@ def extra_bf16(torch, contact_cnn, sd, dev, windows, ref_out, B, steps, settle_s
             return r
         res["conv_stack"] = "two fp16 terms per operand with per-window scales (conv_h2.hip): conv results of fp32 grade in front of the bf16 FC layers = BASELINE configs[4] as written"
         res["two_term_bf16_conv_stack"] = dict(variant({"bf16_conv_h2": 0}), note="conv stack on two bf16 terms (~17 significant bits) at every size: the mode's default in rounds 4-5")
-        res["three_term_conv_stack"] = dict(variant({"x3_bf16_terms": 3}), note="conv stack on three bf16 terms (fp32 operands, six MFMAs per product): the mode's form in round 3")
     # BASELINE configs[2] in this precision too: the 1e6-window sequence, HBM-resident, max_batch 32768 (median of 3 after a warm call)
     ms = contact_cnn(device=dev.index, max_batch=32768, precision=precision)
     ms.load_state_dict(sd).eval()
@@ -636,19 +635,47 @@ def extra_sharded(torch, dist, contact_cnn, sd, dev, rank, world, backend, n_per
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    res = infer_sequence_sharded(m.infer_sequence, rows, dst=0, n_windows=n_total, row_lo=r0, model=m)
+    phases = {"compute_ms": None, "gather_ms": None}
+    if getattr(m, "comm_world", 0):
+        # the product path, its two phases timed apart on every rank (a first multi-GPU record must explain itself: which rank computed how long,
+        # how long the one gather took behind it): this rank's fused pass -> packed rows, then ONE ncclGather of all ranks' rows to rank 0
+        from deep_contact_estimator_amd.distributed import shard_sizes
+        sizes = shard_sizes(n_total, world)
+        packed = m.infer_sequence_packed(rows)
+        torch.cuda.synchronize()
+        phases["compute_ms"] = (time.perf_counter() - t0) * 1e3
+        tg = time.perf_counter()
+        got = m.gather_results(packed, sizes, root=0)
+        m.comm_sync()
+        torch.cuda.synchronize()
+        phases["gather_ms"] = (time.perf_counter() - tg) * 1e3
+        res = m.unpack_results(got) if rank == 0 else None
+        sent = int(packed.shape[0]) * 68
+    else:
+        res = infer_sequence_sharded(m.infer_sequence, rows, dst=0, n_windows=n_total, row_lo=r0, model=m)
+        sent = max(int(rows.shape[0]) - 149, 0) * 68
     torch.cuda.synchronize()
     dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # every rank's own numbers, collected on all (one small all-reduce of a (world, 4) table)
+    tab = torch.zeros((world, 4), dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    tab[rank] = torch.tensor([max(rows.shape[0] - 149, 0), phases["compute_ms"] or -1.0, phases["gather_ms"] or -1.0, sent], dtype=torch.float64)
+    dist.all_reduce(tab, op=dist.ReduceOp.SUM)
     m.close()
     if rank != 0:
         return None
+    per_rank = [{"rank": r, "windows": int(tab[r, 0].item()), "compute_ms": round(tab[r, 1].item(), 3) if tab[r, 1].item() >= 0 else None,
+                 "gather_ms": round(tab[r, 2].item(), 3) if tab[r, 2].item() >= 0 else None, "sent_bytes": int(tab[r, 3].item())} for r in range(world)]
     assert res["logits"].shape == (n_total, 16) and res["contacts"].shape == (n_total, 4)
     return {"workload": f"BASELINE configs[3]: {world} x {n_per_rank:g} windows, halo-sharded, one gather of the packed "
                         "logits+contacts (68 B/window) to rank 0",
             "windows": n_total, "windows_per_s_incl_gather": n_total / float(t.item()), "ms": float(t.item()) * 1e3,
             "gathered_MB": n_total * 68 / 1e6,
+            "per_rank": per_rank,
+            "per_rank_note": "compute_ms: this rank's fused pass over its shard (z-score + conv stack + FC + tail -> packed rows), host clock to the end of its kernels; "
+                             "gather_ms: the ONE gather behind it (on the root: until every rank's rows have arrived; elsewhere: until this rank's send has left); "
+                             "`ms` above = barrier to barrier, max over ranks; None: the torch.distributed fallback transport has no separate phases",
             "transport": "dce_gather_results (ncclGather issued by libdce.so)" if backend == "nccl" and use_rccl else f"torch.distributed {backend}"}
 
 
@@ -677,7 +704,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the profiled pass (no roofline block)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16_fc", "fp32_split", "fp32_f16x2"],
                     help="fp32 = the headline (exact fp32 MFMA); bf16_fc = BASELINE configs[4] as the main workload; "
-                         "fp32_split = conv stack and fc.0 on three-term bf16 operands (fp32 results on the bf16 matrix pipe, range-guarded); "
+                         "fp32_split = retired from the product library in round 6: runs fp32_f16x2 (the three-term bf16 kernels live in the experiments build); "
                          "fp32_f16x2 = conv stack, fc.0 and fc.3 on two fp16 terms per operand with per-window scales (the fp32 tolerance, no guard needed)")
     args = ap.parse_args()
 
@@ -949,7 +976,6 @@ def main():
                 "online_push": extra_online(contact_cnn, sd, dev, seq_np),
                 "streaming_1e6": extra_streaming(torch, contact_cnn, sd, dev),
                 "bf16_fc": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s),
-                "fp32_split": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s, precision="fp32_split"),
                 "fp32_f16x2": extra_bf16(torch, contact_cnn, sd, dev, windows, out, B, args.steps, args.settle_s, precision="fp32_f16x2"),
             }
             res["extra"]["bf16_fc"]["online_push"] = extra_online(contact_cnn, sd, dev, seq_np, pushes=1000, precision="bf16_fc")
@@ -957,7 +983,6 @@ def main():
             # the same step in every precision of the library, side by side (`value` above is the first: the reference's arithmetic)
             res["precisions"] = {
                 "fp32": {"windows_per_s": res["value"], "contract": "fp32 tolerance (|d| <= 1e-5 max|ref| + 1e-4 |ref|), argmax exact outside the noise margin", "operands": "fp32 (fp32 MFMA)"},
-                "fp32_split": {"windows_per_s": res["extra"]["fp32_split"]["windows_per_s"], "contract": "the same", "operands": "fp32 as three bf16 terms (six bf16 MFMAs per product), range-guarded"},
                 "fp32_f16x2": {"windows_per_s": res["extra"]["fp32_f16x2"]["windows_per_s"], "contract": "the same", "operands": "two fp16 terms of the value times a per-window power of two (22 bits; three fp16 MFMAs per product)"},
                 "bf16_fc": {"windows_per_s": res["extra"]["bf16_fc"]["windows_per_s"], "contract": "logits within 6e-3 of the largest logit (BASELINE configs[4])", "operands": "bf16 on fc.0 / fc.3; conv stack of fp32 grade (two fp16 terms, per-window scales)"},
             }

@@ -32,6 +32,9 @@
 #ifndef CX_ILV
 #define CX_ILV 1
 #endif
+#if defined(H2_EXP) && !DCE_EXPERIMENTS
+#error "H2_EXP is a timing probe: build with -DDCE_EXPERIMENTS=1"
+#endif
 #include "conv_x3_common.h"
 
 namespace dce {
@@ -196,7 +199,14 @@ __device__ __forceinline__ void hx_store(char* __restrict__ lds, const cx_f32x4 
         for (int ct = 0; ct < CX_NT; ++ct) {
             const int t = 16 * (ct0 + ct) + j;
             float v[4] = {acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};      // the (scaled) bias is the accumulators' initial value
+#if defined(H2_EXP) && (H2_EXP & 1)
+            // timing probe (WRONG results; experiments build): the un-pooled layers' write-back from lanes j < 8 only -- the sixteen rows a ds_write_b64
+            // group of sixteen lanes touches fall on eight 16-byte slots, a two-way bank conflict; eight rows do not conflict.  Same instructions, no replays:
+            // what the replays cost (profiles/r6j_conv_h2_bank_conflicts.txt)
+            const bool ok = POOL ? ((j & 1) == 0 && (t >> 1) < T / 2) : (t < T && j < 8);
+#else
             const bool ok = POOL ? ((j & 1) == 0 && (t >> 1) < T / 2) : t < T;
+#endif
             const int row = (POOL ? (t >> 1) : t) + 1;
             if constexpr (TAPS) {
                 if (t < T)

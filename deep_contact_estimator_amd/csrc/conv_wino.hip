@@ -775,10 +775,13 @@ hipError_t init_conv_wino()
     if ((e = grant_wino_lds<false, float>()) != hipSuccess) return e;
     if ((e = grant_wino_lds<true, unsigned short>()) != hipSuccess) return e;
     if ((e = grant_wino_lds<false, unsigned short>()) != hipSuccess) return e;
+#if DCE_EXPERIMENTS      // (DCE_FP32_SPLIT's three-plane feature store and the four-wave predecessor of the one-window kernel: experiments build since round 6)
     if ((e = grant_wino_lds<true, Feat3>()) != hipSuccess) return e;
     if ((e = grant_wino_lds<false, Feat3>()) != hipSuccess) return e;
-    for (const void* k : {reinterpret_cast<const void*>(&conv_wino1_kernel<true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false>),
-                          reinterpret_cast<const void*>(&conv_wino1x8_kernel<true>), reinterpret_cast<const void*>(&conv_wino1x8_kernel<false>)})
+    for (const void* k : {reinterpret_cast<const void*>(&conv_wino1_kernel<true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false>), reinterpret_cast<const void*>(&conv_wino1_kernel<false, true>)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
+#endif
+    for (const void* k : {reinterpret_cast<const void*>(&conv_wino1x8_kernel<true>), reinterpret_cast<const void*>(&conv_wino1x8_kernel<false>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     for (const void* k : {reinterpret_cast<const void*>(&conv_wino_seg_kernel<true, 2, 3, 2>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 2, 3, 2>),
                           reinterpret_cast<const void*>(&conv_wino_seg_kernel<true, 4, 2, 1>), reinterpret_cast<const void*>(&conv_wino_seg_kernel<false, 4, 2, 1>),
@@ -791,8 +794,7 @@ hipError_t init_conv_wino()
                           reinterpret_cast<const void*>(&conv_wino_rt4_kernel<false, float, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, DCE_TRACE ? 100 * 1024 : WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
 #endif
-    for (const void* k : {reinterpret_cast<const void*>(&conv_wino_kernel<false, float, true>), reinterpret_cast<const void*>(&conv_wino1_kernel<false, true>),
-                          reinterpret_cast<const void*>(&conv_wino1x8_kernel<false, true>)})
+    for (const void* k : {reinterpret_cast<const void*>(&conv_wino_kernel<false, float, true>), reinterpret_cast<const void*>(&conv_wino1x8_kernel<false, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_FLOATS * (int)sizeof(float))) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -813,8 +815,8 @@ hipError_t launch_conv_wino_taps(int kernel, const float* src, int64_t n, const 
     case 3: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1, true>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, none, taps); break;
 #if DCE_EXPERIMENTS
     case 6: hipLaunchKernelGGL((conv_wino_rt4_kernel<false, float, true>), dim3((unsigned)((n + NW - 1) / NW)), dim3(256), lds, st, src, n, pk, f, none, taps); break;
-#endif
     case 5: hipLaunchKernelGGL((conv_wino1_kernel<false, true>), dim3((unsigned)n), dim3(256), lds, st, src, n, pk, f, none, taps); break;
+#endif
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -861,16 +863,17 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
             else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{});
             return hipGetLastError();
         }
-        const bool w8 = tu.wino1_w8;
-        if (w8) {
-            plan_note("conv_wino1x8");
-            if (zscore) hipLaunchKernelGGL((conv_wino1x8_kernel<true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row, LayerTaps{});
-            else        hipLaunchKernelGGL((conv_wino1x8_kernel<false>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row, LayerTaps{});
+#if DCE_EXPERIMENTS
+        if (!tu.wino1_w8) {                              // the four-wave predecessor of the one-window kernel (A/B)
+            plan_note("conv_wino1x4");
+            if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+            else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
             return hipGetLastError();
         }
-        plan_note("conv_wino1x4");
-        if (zscore) hipLaunchKernelGGL((conv_wino1_kernel<true>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
-        else        hipLaunchKernelGGL((conv_wino1_kernel<false>), dim3((unsigned)n), block, lds, st, src, n, pk, f, src_row, LayerTaps{});
+#endif
+        plan_note("conv_wino1x8");
+        if (zscore) hipLaunchKernelGGL((conv_wino1x8_kernel<true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row, LayerTaps{});
+        else        hipLaunchKernelGGL((conv_wino1x8_kernel<false>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, src_row, LayerTaps{});
         return hipGetLastError();
     }
 #if DCE_EXPERIMENTS
@@ -888,12 +891,16 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
         return hipGetLastError();
     }
 #endif
-    if (feat_bf16 == 2) {                                // DCE_FP32_SPLIT: the features leave as three bf16 planes (conv_common.h put_feat3)
+    if (feat_bf16 == 2) {                                // DCE_FP32_SPLIT (experiments build): the features leave as three bf16 planes (conv_common.h put_feat3)
+#if DCE_EXPERIMENTS
         plan_note("conv_wino2_feat3");
         Feat3* f = static_cast<Feat3*>(feat);
         if (zscore) hipLaunchKernelGGL((conv_wino_kernel<true, Feat3>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
         else        hipLaunchKernelGGL((conv_wino_kernel<false, Feat3>), grid, block, lds, st, src, n, pk, f, src_row, LayerTaps{});
         return hipGetLastError();
+#else
+        return hipErrorInvalidValue;
+#endif
     }
     plan_note("conv_wino2");
     if (feat_bf16) {

@@ -391,29 +391,24 @@ static unsigned persist_grid(int64_t n)
 
 hipError_t init_conv_x3()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
-    if (e != hipSuccess) return e;
-    for (const void* k : {reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 0, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 0, true>),
-                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true>),
-                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, false, false, 2>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, false, false, 2>),
+    // Product library (round 6): the TWO-term bf16 form alone (DCE_BF16_FC at up to 256 windows per launch, taps, online pushes).  The three-term forms
+    // -- DCE_FP32_SPLIT's conv stack and the bf16-FC mode's round-3 stack -- live in the experiments build: fp32_f16x2 (conv_h2.hip) holds the same
+    // contract at 1.13 - 2.0 x their speed at every size (profiles/r6h_retire_split_sweep.txt).
+    hipError_t e = hipSuccess;
+    for (const void* k : {reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, false, false, 2>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, false, false, 2>),
                           reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true, false, 2>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true, false, 2>),
 #if DCE_EXPERIMENTS
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true>), reinterpret_cast<const void*>(&conv_x3_kernel<false>), reinterpret_cast<const void*>(&conv_x3_kernel<false, true>),
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 1>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 1>),
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2>),
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 0, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 0, true>),
+                          reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true>),
                           reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 0, true, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 0, true, true>),
                           reinterpret_cast<const void*>(&conv_x3_kernel<true, false, 2, true, true>), reinterpret_cast<const void*>(&conv_x3_kernel<false, false, 2, true, true>),
 #endif
                           })
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS)) != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);
+    return e;
 }
 
 // dce_conv_layer_taps, kernel 7: pre-normalised windows through conv_x3_kernel with every layer's output (and the fp32
@@ -422,19 +417,29 @@ hipError_t launch_conv_x3_taps(const float* windows, int64_t n, const ConvPackX3
                                const LayerTaps& taps, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
+#if DCE_EXPERIMENTS
     const size_t plane_elems = (size_t)((n + 1) & ~(int64_t)1) * FEAT;
     hipLaunchKernelGGL((conv_x3_kernel<false, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, windows, n, pk, feat3, plane_elems, taps, feat32);
     return hipGetLastError();
+#else
+    (void)windows; (void)pk; (void)feat3; (void)feat32; (void)taps; (void)st;
+    return hipErrorInvalidValue;                       // (the three-term stack: experiments build)
+#endif
 }
 
 // the same stack with (n, 4736) fp32 features out: DCE_FP32_SPLIT at batches below the split-bf16 fc.0 kernel's threshold
 hipError_t launch_conv_x3_f32(const float* src, int zscore, int64_t n, const ConvPackX3& pk, float* feat, hipStream_t st, const GuardArgs& guard)
 {
     if (n <= 0) return hipSuccess;
+#if DCE_EXPERIMENTS
     plan_note("conv_x3_f32");
     if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 1>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat);
     else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 1>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, nullptr, (size_t)0, LayerTaps{}, feat, nullptr, guard);
     return hipGetLastError();
+#else
+    (void)src; (void)zscore; (void)pk; (void)feat; (void)st; (void)guard;
+    return hipErrorInvalidValue;
+#endif
 }
 
 // ... with (n, 4736) bf16 features out: the DCE_BF16_FC precision
@@ -454,14 +459,15 @@ hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const Co
         }
         return hipGetLastError();
     }
-#if DCE_EXPERIMENTS
+#if !DCE_EXPERIMENTS
+    return hipErrorInvalidValue;                       // (three-term bf16 stack: experiments build)
+#else
     if (permk == 2) {                                  // ... from persistent workgroups (measured 2-4 % slower: profiles/r4h_ab_conv_x3_persist.txt)
         plan_note("conv_x3_bf16_permk_persist");
         if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
         else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2, true, true>), dim3(persist_grid(n)), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
         return hipGetLastError();
     }
-#endif
     if (permk) {                                       // features in the K order t' * 128 + c, straight from the accumulators
         plan_note("conv_x3_bf16_permk");
         if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2, true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
@@ -472,10 +478,15 @@ hipError_t launch_conv_x3_bf16(const float* src, int zscore, int64_t n, const Co
     if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
     else        hipLaunchKernelGGL((conv_x3_kernel<false, false, 2>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat, (size_t)0, LayerTaps{}, nullptr, src_row);
     return hipGetLastError();
+#endif
 }
 
 hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPackX3& pk, unsigned short* feat3, hipStream_t st, int permk, const GuardArgs& guard)
 {
+#if !DCE_EXPERIMENTS
+    (void)src; (void)zscore; (void)n; (void)pk; (void)feat3; (void)st; (void)permk; (void)guard;
+    return hipErrorInvalidValue;                       // (DCE_FP32_SPLIT's conv stack: experiments build)
+#else
     if (n <= 0) return hipSuccess;
     const size_t plane_elems = (size_t)((n + 1) & ~(int64_t)1) * FEAT;
 #if DCE_EXPERIMENTS
@@ -496,6 +507,7 @@ hipError_t launch_conv_x3(const float* src, int zscore, int64_t n, const ConvPac
     if (zscore) hipLaunchKernelGGL((conv_x3_kernel<true>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr);
     else        hipLaunchKernelGGL((conv_x3_kernel<false>), dim3((unsigned)n), dim3(256), CX_LDS, st, src, n, pk, feat3, plane_elems, LayerTaps{}, nullptr, nullptr, guard);
     return hipGetLastError();
+#endif
 }
 
 }  // namespace dce

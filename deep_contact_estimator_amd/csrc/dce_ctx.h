@@ -25,6 +25,7 @@ struct dce_ctx {
     bool have[14] = {};
     bool finalized = false;
     int precision = DCE_FP32;
+    bool split_alias = false;              // product library: the context was finalized as DCE_FP32_SPLIT and runs DCE_FP32_F16X2 (dce_last_plan says so)
     std::vector<const char*> plan;         // kernel families launched by the most recent kernel sequence (dce_last_plan)
     dce::Tuning tuning;                    // the A/B switches: dce_create_ex's option string, else DCE_TUNE, over the defaults
     dce::Tuning gate_tuning;               // ... the same without the small-batch kernel families and row cuts: what a gated DCE_FP32 fallback sequence runs

@@ -93,9 +93,17 @@ struct TuningScope {                                         // RAII: entry poin
 // saw a window outside [x_lo, x_hi] writes its generation to word[0]; the DCE_FP32 kernel sequence enqueued behind it is GATED on that
 // word: every workgroup of it reads the word first and returns unless it holds this launch's generation.
 struct GuardArgs { unsigned* word = nullptr; unsigned gen = 0; float x_hi = 0.f, x_lo = 0.f; };
+#if DCE_EXPERIMENTS
 struct Gate { const unsigned* word = nullptr; unsigned gen = 0; unsigned* taken = nullptr; };
 extern thread_local Gate t_gate;                             // set around the gated fallback sequence; {} = no gate
 __device__ __forceinline__ bool gate_closed(const Gate& g) { return g.word != nullptr && *g.word != g.gen; }
+#else
+// (product library, round 6: no gated launch exists -- DCE_FP32_SPLIT lives in the experiments build.  The fp32 kernels keep the parameter as an EMPTY
+//  type, so that one source serves both builds; the test below folds to false and leaves no instruction behind.)
+struct Gate {};
+extern thread_local Gate t_gate;
+__device__ __forceinline__ constexpr bool gate_closed(const Gate&) { return false; }
+#endif
 
 // ---- device buffers of a context (dev_alloc.hip): hipMalloc / hipFree, or -- guard != 0 -- a mapping per buffer that ends (1) / starts (2) at an unmapped page
 hipError_t dev_alloc_raw(void** out, size_t bytes, int guard);

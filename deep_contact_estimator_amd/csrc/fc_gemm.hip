@@ -533,7 +533,9 @@ void fc3_tail_kernel(const float* __restrict__ h2, const float* __restrict__ W3,
                      uint8_t* __restrict__ packed, Gate gate)
 {
     if (gate_closed(gate)) return;                       // DCE_FP32_SPLIT's fallback sequence (dce_kernels.h Gate)
+#if DCE_EXPERIMENTS
     if (gate.taken && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(gate.taken, 1u);     // ... ran: counted (dce_split_guard_info)
+#endif
     // dynamic LDS (43 KB): the 16 h2 rows of the current window tile [16][516] | chunk sums [8][16][16] | logits [16][16]
     extern __shared__ __attribute__((aligned(16))) float tsm[];
     float* h2s = tsm;
@@ -617,7 +619,9 @@ void fc6_combine_kernel(const float* __restrict__ part, int64_t part_rows, const
 {
     __shared__ float lg[16][NCLS];
     if (gate_closed(gate)) return;                       // DCE_FP32_SPLIT's fallback sequence (dce_kernels.h Gate)
+#if DCE_EXPERIMENTS
     if (gate.taken && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(gate.taken, 1u);
+#endif
     const int tid = threadIdx.x, cls = tid & 15, wl = tid >> 4;
     const int64_t base = (int64_t)blockIdx.x * 16, win = base + wl;
     const int64_t row = win < n ? win : n - 1;

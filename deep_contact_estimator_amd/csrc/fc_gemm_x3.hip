@@ -148,6 +148,7 @@ __device__ __forceinline__ void x3_m0_end(unsigned keep)
 }  // namespace
 
 // fp32 (rows, cols) -> three bf16 planes [3][rows][cols]; eight elements per thread
+#if DCE_EXPERIMENTS
 __global__ __launch_bounds__(256)
 void split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes, size_t n8, size_t plane_elems, int cols)
 {
@@ -172,6 +173,8 @@ void split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ pla
 // fc.3 that takes three-term operands) instead of fp32.  FUSE6 (X3Fc3 only): the block's 64 output columns are one chunk of fc.6's
 // summation tree (fc6_chain.h), finished in the epilogue exactly as fc_gemm_phased.hip's FUSE6 does -- chunk sums to `part`, h2 itself to
 // C only when C != NULL (taps).
+#endif
+
 template <class Cfg, bool OUT3, bool FUSE6>
 __global__ __launch_bounds__(512, 2)
 void fc_gemm_x3_kernel(const unsigned short* __restrict__ A3, const unsigned short* __restrict__ W3,
@@ -438,18 +441,25 @@ void fc_gemm_x3_kernel(const unsigned short* __restrict__ A3, const unsigned sho
     else store_tile(std::false_type{});
 }
 
+// Round 6: DCE_FP32_SPLIT left the product library (fp32_f16x2 holds the same contract at 1.13 - 2.0 x its speed at every size, profiles/r6h_retire_split_sweep.txt):
+// the kernels of this file are instantiated in the experiments build only; the product's launchers refuse.
 hipError_t init_fc_gemm_x3()
 {
+#if !DCE_EXPERIMENTS
+    return hipSuccess;
+#else
     hipError_t e;
     for (const void* k : {reinterpret_cast<const void*>(&fc_gemm_x3_kernel<X3Fc0, false, false>), reinterpret_cast<const void*>(&fc_gemm_x3_kernel<X3Fc0, true, false>),
                           reinterpret_cast<const void*>(&fc_gemm_x3_kernel<X3Fc3, false, true>)})
         if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS + (X3_TRACE ? 8192 : 0))) != hipSuccess) return e;
     return hipSuccess;
+#endif
 }
 
 // 256 x 128 tiles must fill the chip (as the phased fp32 kernel asks of its large tile)
 bool fc_gemm_x3_ok(int64_t M, int N, int K)
 {
+    if (!DCE_EXPERIMENTS) return false;
     if (N % X3_BN || K % X3_KT || K < 2 * X3_KT || M <= 0) return false;
     const int nt = N / X3_BN;
     if ((nt & (nt - 1)) != 0) return false;
@@ -460,7 +470,7 @@ bool fc_gemm_x3_ok(int64_t M, int N, int K)
 // fc.3 + fc.6 chunk sums on three-term operands: where the fp32 path fuses them (one round of 128 x 64 tiles) and the planes' offsets fit
 bool fc23_x3_ok(int64_t M)
 {
-    return tune().x3_fc3 && fc23_fused_ok(M, 0) && 3ull * (size_t)((M + 1) & ~(int64_t)1) * FC1 * 2 < (1ull << 32);
+    return DCE_EXPERIMENTS && tune().x3_fc3 && fc23_fused_ok(M, 0) && 3ull * (size_t)((M + 1) & ~(int64_t)1) * FC1 * 2 < (1ull << 32);
 }
 
 // rows x cols fp32 -> three ROW-MAJOR planes [3][rows][cols] (fc.3's weights: its 64-k K-tiles are whole 128-byte lines as they are)
@@ -485,18 +495,27 @@ hipError_t launch_split3(const float* x, unsigned short* planes, int64_t rows, i
 {
     const size_t n = (size_t)rows * cols;
     if (n == 0) return hipSuccess;
+#if DCE_EXPERIMENTS
     if (cols % 32) return hipErrorInvalidValue;
     plan_note("split3");
     // plane stride = an even number of rows (the kernel pads M to even)
     hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, x, planes, n / 8,
                        (size_t)((rows + 1) & ~(int64_t)1) * cols, cols);
     return hipGetLastError();
+#else
+    (void)x; (void)planes; (void)st;
+    return hipErrorInvalidValue;
+#endif
 }
 
 hipError_t launch_fc_gemm_x3(const unsigned short* A3, const unsigned short* W3, const float* bias, void* C,
                              int64_t M, int N, int K, int relu, hipStream_t st, int out_planes)
 {
     if (!fc_gemm_x3_ok(M, N, K)) return hipErrorInvalidValue;
+#if !DCE_EXPERIMENTS
+    (void)A3; (void)W3; (void)bias; (void)C; (void)relu; (void)st; (void)out_planes;
+    return hipErrorInvalidValue;
+#else
     const int mtiles = (int)((M + X3_BM - 1) / X3_BM), ntiles = N / X3_BN;
     int sn_log2 = tune().phased_sn;
     while ((1 << sn_log2) > ntiles) --sn_log2;
@@ -508,6 +527,7 @@ hipError_t launch_fc_gemm_x3(const unsigned short* A3, const unsigned short* W3,
     if (out_planes) hipLaunchKernelGGL((fc_gemm_x3_kernel<X3Fc0, true, false>), dim3(grid), dim3(512), X3_LDS + (X3_TRACE ? 8192 : 0), st, A3, W3, bias, Cf, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
     else            hipLaunchKernelGGL((fc_gemm_x3_kernel<X3Fc0, false, false>), dim3(grid), dim3(512), X3_LDS + (X3_TRACE ? 8192 : 0), st, A3, W3, bias, Cf, (int)M, N, K, relu, mtiles, ntiles, sn_log2);
     return hipGetLastError();
+#endif
 }
 
 // fc.3 (+ReLU) on three-term operands with fc.6's chunk sums finished in the epilogue: h1p = three row-major bf16 planes [3][M even][2048]
@@ -517,6 +537,10 @@ hipError_t launch_fc23_fused_x3(const unsigned short* h1p, const unsigned short*
 {
     static_assert(X3Fc3::BN == FC6_CHUNK && FC2 / X3Fc3::BN == FC6_NCHUNK && FC1 % X3Fc3::KT == 0, "one column tile of fc.3 = one chunk of fc.6");
     if (M <= 0) return hipSuccess;
+#if !DCE_EXPERIMENTS
+    (void)h1p; (void)W2p; (void)b2; (void)W3; (void)part; (void)part_rows; (void)h2_out; (void)st;
+    return hipErrorInvalidValue;
+#else
     const int mtiles = (int)((M + X3Fc3::BM - 1) / X3Fc3::BM), ntiles = FC2 / X3Fc3::BN;
     const int sn_log2 = 2, sm = 32 >> sn_log2, nsn = ntiles >> sn_log2;
     const int nsuper = ((mtiles + sm - 1) / sm) * nsn;
@@ -525,6 +549,7 @@ hipError_t launch_fc23_fused_x3(const unsigned short* h1p, const unsigned short*
     hipLaunchKernelGGL((fc_gemm_x3_kernel<X3Fc3, false, true>), dim3(grid), dim3(512), X3Fc3::LDS + (X3_TRACE ? 8192 : 0), st, h1p, W2p, b2, h2_out,
                        (int)M, FC2, FC1, 1, mtiles, ntiles, sn_log2, W3, part, (long long)part_rows);
     return hipGetLastError();
+#endif
 }
 
 }  // namespace dce

@@ -68,24 +68,20 @@ typedef enum dce_precision {
                                   see DCE_FP32_F16X2); up to 256 windows (one-window calls, online pushes) and in the taps on two bf16 terms
                                   (~17 bits; csrc/conv_x3.hip, NT = 2), whose results do not depend on the size of the launch -- the mode's
                                   error against an fp64 evaluation is that of its bf16 FC operands either way (profiles/r4h_bf16_terms_audit.json).
-                                  Options: bf16_conv_h2=0 (two bf16 terms at every size: the default of rounds 4-5), x3_bf16_terms=3 (three
-                                  bf16 terms, six MFMAs per product: round 3).  CONTRACT of the mode: logits within 6e-3 of the largest logit
+                                  Option: bf16_conv_h2=0 (two bf16 terms at every size: the default of rounds 4-5; round 3's three-term stack
+                                  is an experiments-build option).  CONTRACT of the mode: logits within 6e-3 of the largest logit
                                   of an fp32 / fp64 evaluation (the price of 8-bit operands on fc.0 / fc.3), and as close to the CPU
                                   restatement of the mode (oracle_forward_windows_bf16fc: the two differ where a value sits on a bf16
                                   rounding boundary -- <= 3e-3 on every fixture and fuzz set, 4.2e-3 worst over 1e6 logits with the two-term
                                   bf16 stack, <= 2e-3 with the fp32-grade ones); argmax equal wherever the top-2 margin exceeds 1e-2 of the
-                                  largest logit; bench.py reports the step with all three conv stacks */
-    DCE_FP32_SPLIT      = 2,   /* fp32 results with the conv stack and fc.0 of chip-filling batches on the bf16 matrix pipe: every fp32
-                                  operand enters as three bf16 terms (a = a1 + a2 + a3 exactly), six bf16 MFMAs per product, fp32
-                                  accumulate.  Same tolerance against the reference as DCE_FP32, NOT the same bits; the conv stack from 128
-                                  windows per call, fc.0 from 2817; below that the DCE_FP32 kernels.  Opt-in (csrc/conv_x3.hip, csrc/fc_gemm_x3.hip).
-                                  RANGE GUARD (dce_split_guard_info): bf16's largest finite number is below fp32's and its subnormal range
-                                  starts 2^16 above where a value's third term lies, so the mode runs only where no operand can leave the
-                                  range in which a three-term split is exact -- decided statically from the checkpoint at
-                                  dce_finalize_weights (per-layer activation bounds; a checkpoint that fails runs the DCE_FP32 kernels) and,
-                                  for pre-normalised windows, per window in the conv kernel's load stage: a launch holding a window outside
-                                  [x_lo, x_hi] is recomputed by the DCE_FP32 kernel sequence queued behind it (gated on the device, no host
-                                  round trip).  z-scored windows (dce_infer_sequence) are inside the range by construction */
+                                  largest logit; bench.py reports the step with both conv stacks */
+    DCE_FP32_SPLIT      = 2,   /* RETIRED from the product library in round 6: libdce.so runs DCE_FP32_F16X2 for this value (same contract against
+                                  the reference, 1.13 - 2.0 x the speed at every launch size, no range guard needed; profiles/r6h_retire_split_sweep.txt)
+                                  and dce_last_plan begins with "fp32_split_is_fp32_f16x2".  The precision itself -- fp32 results with the conv stack
+                                  and fc.0 on the bf16 matrix pipe, every fp32 operand as three bf16 terms (a = a1 + a2 + a3 exactly), six MFMAs per
+                                  product, behind a RANGE GUARD (static per-layer bounds at dce_finalize_weights, a per-window check in the conv
+                                  kernel and a gated DCE_FP32 kernel sequence behind every guarded launch; dce_split_guard_info) -- lives on in the
+                                  experiments build (libdce_experiments.so: csrc/conv_x3.hip, csrc/fc_gemm_x3.hip), with its tests */
     DCE_FP32_F16X2      = 3    /* fp32-TOLERANCE results with the conv stack (from 128 windows per launch), fc.0 and fc.3 (from 1281; below
                                   that the DCE_FP32 kernels) on the fp16 matrix pipe: every operand is scaled by a power of two and
                                   enters as TWO fp16 terms (11 + 11 significand bits), three MFMAs per product, fp32 accumulate
@@ -97,10 +93,9 @@ typedef enum dce_precision {
                                   window alone.  A checkpoint with a non-finite weight runs the DCE_FP32 kernels.  Opt-in */
 } dce_precision;
 /* Batch-size regimes.  DCE_FP32 gives a window the same bits whatever the size of the call it arrives in (one fixed summation tree in
- * every kernel family).  The two other precisions pick kernels by the number of windows in a launch (a call of more than max_batch
- * windows is several launches: the last one may fall into another regime).  DCE_FP32_SPLIT: below 128 windows the DCE_FP32 kernels, from
- * 128 the three-term conv stack, from 2817 the split fc.0 -- the same window may differ in its last bits between a small and a large call
- * (both within the fp32 tolerance of the reference, <= 2e-5 of the largest logit apart).  DCE_BF16_FC: one conv kernel up to 256 windows, another above (both far inside the mode's band), FC
+ * every kernel family; latency=1 contexts: whole calls of up to 32 windows take one-kernel forms with another summation order, see below).  The two
+ * other precisions pick kernels by the number of windows in a launch (a call of more than max_batch windows is several launches: the last one may
+ * fall into another regime); the table is kPlanRows in csrc/dce_api.hip.  DCE_BF16_FC: one conv kernel up to 256 windows, another above (both far inside the mode's band), FC
  * kernels by size -- up to 256 windows per launch one weight-streaming kernel whose results do not depend on the number of windows (an
  * online push gives the bits of a sequence call in launches of <= 256), above that tile / phased GEMMs with other fp32 summation orders:
  * an h1 value at a bf16 rounding boundary may round the other way, <= 2e-2 of the largest logit.  DCE_FP32_F16X2: below 128 windows the

@@ -625,7 +625,7 @@ def test_direct_form_conv_kernel(monkeypatch, golden, case_inputs, orc):
     wino.close(); direct.close()
 
 
-@pytest.mark.parametrize("conv", ["winograd", pytest.param("direct", marks=needs_experiments), "fp32_split_guarded", "fp32_f16x2"])
+@pytest.mark.parametrize("conv", ["winograd", pytest.param("direct", marks=needs_experiments), pytest.param("fp32_split_guarded", marks=needs_experiments), "fp32_f16x2"])
 def test_forward_windows_bench_batch(conv, monkeypatch, orc):
     """BASELINE configs[1] exactly as bench.py runs it: the 4096 pre-normalised windows of the bench
     step (synthetic sequence seed 2, z-scored by the library, checkpoint seed 1) through

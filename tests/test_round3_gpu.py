@@ -10,7 +10,7 @@
 import numpy as np
 import pytest
 
-from conftest import tol_ok
+from conftest import needs_experiments, tol_ok
 
 pytestmark = pytest.mark.gpu
 
@@ -50,8 +50,8 @@ def test_conv_layer_taps_vs_reference_hooks(kernel, name, golden, case_inputs, m
     block2[1], block2[3]) for EVERY conv kernel family, and the oracle's taps for the other windows of the launch
     (so that both windows of a two-window workgroup and every segment of a cut window are covered)."""
     from conftest import has_experiments
-    if kernel in ("wino2rt4", "direct") and not has_experiments():
-        pytest.skip("the four-row-tile workgroup and the direct-form kernel live in the experiments build (tests/test_experiments_gpu.py runs them there)")
+    if kernel in ("wino2rt4", "direct", "wino1x4") and not has_experiments():
+        pytest.skip("the four-row-tile workgroup, the four-wave one-window kernel and the direct-form kernel live in the experiments build (tests/test_experiments_gpu.py runs them there)")
     g = golden(name)
     sd, _ = case_inputs(g)
     m = model_of(int(g["wseed"]), str(g["bias"]))
@@ -87,7 +87,7 @@ def test_conv_layer_taps_bit_identical_across_winograd_families(golden, model_of
     x = g["zwin"][:3]
     base = m.conv_layer_taps(x, "wino2")
     from conftest import has_experiments
-    for kernel in (("wino2rt4",) if has_experiments() else ()) + ("wino1x8", "wino1x4", "half", "quarter"):
+    for kernel in (("wino2rt4", "wino1x4") if has_experiments() else ()) + ("wino1x8", "half", "quarter"):
         t = m.conv_layer_taps(x, kernel)
         for k in LAYERS + ("feat",):
             a, b = base[k], t[k]
@@ -102,7 +102,7 @@ def test_tapped_kernels_produce_the_product_features(model_of):
     x = np.random.default_rng(3).standard_normal((5, 150, 54), dtype=np.float32)
     feat = m.forward_taps(x)["feat"]
     from conftest import has_experiments
-    for kernel in (("wino2rt4",) if has_experiments() else ()) + ("wino2", "wino1x8", "half", "quarter", "wino1x4"):
+    for kernel in (("wino2rt4", "wino1x4") if has_experiments() else ()) + ("wino2", "wino1x8", "half", "quarter"):
         assert np.array_equal(m.conv_layer_taps(x, kernel)["feat"], feat), kernel
 
 
@@ -111,7 +111,7 @@ def test_tapped_kernels_produce_the_product_features(model_of):
 # ------------------------------------------------------------------------------------------------
 # batch sizes chosen per bf16 kernel: phased 256x128 + fused 128x64 (4096), phased 128x64 (3000 / 700), 64x64 tiles (300), the
 # weight-streaming kernel with one, two and four 64-window blocks (1 / 40, 100, 256), a ragged size past a round (4100)
-@pytest.mark.parametrize("terms", ["h2", 2, 3])                     # the mode as it ships (conv results of fp32 grade from two fp16 terms with per-window scales above 256 windows: BASELINE configs[4] as written) / two bf16 terms at every size (bf16_conv_h2=0) / three bf16 terms
+@pytest.mark.parametrize("terms", ["h2", 2, pytest.param(3, marks=needs_experiments)])                     # the mode as it ships (conv results of fp32 grade from two fp16 terms with per-window scales above 256 windows: BASELINE configs[4] as written) / two bf16 terms at every size (bf16_conv_h2=0) / three bf16 terms
 @pytest.mark.parametrize("n", [1, 40, 100, 256, 300, 700, 3000, 4096, 4100])
 def test_bf16_fc_vs_independent_restatement(n, terms, model_of, orc):
     """DCE_BF16_FC (BASELINE configs[4]: the reference's fc layers, src/contact_cnn.py:47-58, with fc.0 / fc.3 on bf16

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import tol_ok
+from conftest import needs_experiments, tol_ok
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +22,7 @@ def _model(precision, max_batch=8192, tune=None):
     return contact_cnn(device=0, max_batch=max_batch, precision=precision, tune=tune)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32_split", "fp32_f16x2", "bf16_fc"])
+@pytest.mark.parametrize("precision", ["fp32", pytest.param("fp32_split", marks=needs_experiments), "fp32_f16x2", "bf16_fc"])
 def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs, orc):
     """One 4096-window launch per precision against logits the reference itself produced: fp32, fp32_split and fp32_f16x2 within the
     fp32 tolerance and argmax-exact outside the noise margin, bf16_fc within its band (bf16 operands of fc.0 / fc.3)."""
@@ -60,6 +60,7 @@ def test_chip_filling_launch_vs_the_reference(precision, golden, case_inputs, or
     m.close()
 
 
+@pytest.mark.experiments                                        # (the three-term form it is compared with lives in the experiments build since round 6)
 @pytest.mark.parametrize("n", [128, 515, 4096, 4099])
 def test_bf16_fc_conv_stack_on_two_term_operands(n, orc):
     """DCE_BF16_FC's conv stack up to 256 windows per launch, in the online pushes and with the option bf16_conv_h2=0: conv_x3.hip with NT = 2 -- operands as two bf16 terms, a1 b1 + a1 b2 + a2 b1 (three MFMAs per
@@ -140,7 +141,7 @@ def test_barrier_free_bf16_gemm_equals_the_phased_kernel():
 
 
 @pytest.mark.experiments
-@pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
+@pytest.mark.parametrize("precision", [pytest.param("fp32_split", marks=needs_experiments), "bf16_fc"])
 def test_persistent_conv_stack_equals_one_workgroup_per_window(precision):
     """conv_x3.hip's persistent form (option x3_persist=1, experiments build: two workgroups per CU walk the windows, the next window's
     samples requested a layer ahead) runs the same arithmetic in the same order: the same BYTES as one workgroup per window, at
@@ -165,7 +166,7 @@ def test_persistent_conv_stack_equals_one_workgroup_per_window(precision):
 
 
 @pytest.mark.experiments
-@pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
+@pytest.mark.parametrize("precision", [pytest.param("fp32_split", marks=needs_experiments), "bf16_fc"])
 def test_paired_conv_stack_vs_one_window_kernel_and_oracle(precision, orc):
     """conv_x3p.hip (option x3_pair=1: one 8-wave workgroup per CU, two windows per wave, write-backs inside the other window's K
     loops, features in the K order t' * 128 + c with fc.0's weights permuted alike) against conv_x3.hip on the same windows:
@@ -203,7 +204,7 @@ def test_paired_conv_stack_vs_one_window_kernel_and_oracle(precision, orc):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
+@pytest.mark.parametrize("precision", [pytest.param("fp32_split", marks=needs_experiments), "bf16_fc"])
 def test_batch_size_regimes_stay_within_the_mode_tolerance(precision, orc):
     """The non-default precisions pick their conv / fc.0 kernels by the size of the launch (below 128 windows the fp32 kernels,
     from 128 the three-term conv stack, from 2817 the split fc.0): the same windows in a small and in a large launch may differ
@@ -256,7 +257,7 @@ def test_layer_taps_refuse_a_bf16_fc_context():
     m.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32_split", "bf16_fc"])
+@pytest.mark.parametrize("precision", [pytest.param("fp32_split", marks=needs_experiments), "bf16_fc"])
 def test_features_straight_from_the_accumulators_equal_the_staged_ones(precision):
     """conv_x3.hip writes its features straight from the accumulators in the K order t' * 128 + c (option x3_permk, default) with fc.0's
     weights permuted alike, or through LDS in the reference's flatten order (x3_permk=0): the same products, another order of the

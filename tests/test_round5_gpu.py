@@ -32,6 +32,7 @@ def _argmax_contract(pred, ref):
 # ------------------------------------------------------------------------------------------------
 # fp32_split: the static half of the guard
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.experiments
 def test_split_guard_static_bounds_of_a_checkpoint():
     """dce_finalize_weights bounds every layer's activations by sums of |w| (gain X + offs for |x| <= X) and derives the largest input
     the three-term split is safe for; the numbers are the ones numpy gets from the same checkpoint, and an ordinary checkpoint
@@ -57,6 +58,7 @@ def test_split_guard_static_bounds_of_a_checkpoint():
     m.close(); f.close()
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("case", ["tiny_conv1", "huge_fc0", "nan_weight", "huge_gain"])
 def test_split_guard_refuses_a_checkpoint_outside_the_range(case, orc):
     """A checkpoint whose weights leave the range in which a three-term split is exact -- a layer whose largest |w| is below 2^-40
@@ -110,6 +112,7 @@ def _adversarial(kind, n, rng):
 
 
 @pytest.mark.parametrize("n", [300, 4096])                        # conv_x3_f32 + fp32 FC kernels / conv_x3_permk + fc_x3
+@pytest.mark.experiments
 @pytest.mark.parametrize("kind", ["top_binade", "subnormal_terms", "one_window"])
 def test_split_guard_routes_out_of_range_windows_to_the_fp32_kernels(kind, n, orc):
     """Pre-normalised windows outside [x_lo, x_hi] -- where the first term of a split would round to Inf, or the third terms go
@@ -150,6 +153,7 @@ def test_split_guard_routes_out_of_range_windows_to_the_fp32_kernels(kind, n, or
     a.close(); b.close()
 
 
+@pytest.mark.experiments
 def test_split_guard_leaves_the_zscore_entry_alone_and_can_be_switched_off(orc):
     """z-scored windows are inside the range by construction: dce_infer_sequence carries no per-window check and no gated sequence;
     split_guard=0 restores the round-4 behaviour (A/B, the audit's 'no guard' rows)."""
@@ -283,6 +287,7 @@ def test_latency_mode_online_pushes_vs_oracle(orc):
 # ------------------------------------------------------------------------------------------------
 # fp32_split: fc.3 on three-term operands (csrc/fc_gemm_x3.hip, the 128 x 64 tile with the fused fc.6 epilogue)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.experiments
 @pytest.mark.parametrize("n", [4096, 4100, 8192])
 def test_split_mode_fc3_on_three_term_operands(n, orc):
     """Option x3_fc3=1: fp32_split at chip-filling batches with fc.3 on the bf16 matrix pipe too -- fc.0's epilogue writes h1 as three bf16

@@ -136,3 +136,48 @@ def test_latency_plans_serve_whole_calls_only(sd, orc):
         assert np.array_equal(g["logits"], r["logits"]) and np.array_equal(g["pred"], r["pred"])
     assert m.predict(x[:5])["logits"].shape == (5, 16) and m.last_plan() == ["latency_mb"]      # a whole call of five windows: the one kernel
     m.close(); b.close()
+
+
+def test_fp32_split_is_an_alias_of_fp32_f16x2_in_the_product_library(sd, orc):
+    """Round 6: DCE_FP32_SPLIT (three bf16 terms per operand, range-guarded) left the product library -- DCE_FP32_F16X2 holds the same contract at 1.13 - 2.0 x
+    its speed at every launch size (profiles/r6h_retire_split_sweep.txt).  A caller that asks for it gets fp32_f16x2's kernels and bits, dce_last_plan and
+    dce_split_guard_info say so; the three-term kernels and their tests run in the experiments build (tests/test_experiments_gpu.py)."""
+    from conftest import has_experiments
+    from deep_contact_estimator_amd import contact_cnn
+    if has_experiments():
+        pytest.skip("the experiments build runs the real three-term kernels")
+    a = contact_cnn(device=0, max_batch=4096, precision="fp32_split"); a.load_state_dict(sd).eval()
+    b = contact_cnn(device=0, max_batch=4096, precision="fp32_f16x2"); b.load_state_dict(sd).eval()
+    for n in (64, 700, 4096):
+        x = np.random.default_rng(n).standard_normal((n, 150, 54), dtype=np.float32)
+        ra, rb = a.predict(x), b.predict(x)
+        assert a.last_plan()[0] == "fp32_split_is_fp32_f16x2" and a.last_plan()[1:] == b.last_plan(), (a.last_plan(), b.last_plan())
+        assert np.array_equal(ra["logits"], rb["logits"]) and np.array_equal(ra["pred"], rb["pred"])
+        tol_ok(ra["logits"][:256], orc.Oracle(sd).forward_windows(x[:256])["logits"], f"fp32_split (alias), {n} windows")
+    g = a.split_guard()
+    assert not g["enabled"] and not g["refused"] and "DCE_FP32_F16X2" in g["reason"], g
+    a.close(); b.close()
+
+
+def test_the_plan_table_is_what_runs(sd):
+    """csrc/dce_api.hip kPlanRows (printed by tools/gen_options_table.py into DESIGN.md's appendix): for every precision of the product library, the kernel
+    families dce_last_plan reports on both sides of every row boundary."""
+    from conftest import has_experiments
+    from deep_contact_estimator_amd import contact_cnn
+    if has_experiments():
+        pytest.skip("the experiments build plans with round 5's predicate tree")
+    expect = {"fp32": {1: "conv_wino_quarter", 4096: "conv_wino2"},
+              "bf16_fc": {256: "conv_x2_bf16_permk", 257: "conv_h2_bf16_permk"},
+              "fp32_f16x2": {127: "conv_wino_half", 128: "conv_h2_f32", 1280: "conv_h2_f32", 1281: "conv_h2", 12288: "conv_h2", 12289: "conv_h2"}}
+    fcs = {("fp32_f16x2", 1280): "fc_phased128x64", ("fp32_f16x2", 1281): "fc_h2_256x128_out2", ("fp32_f16x2", 12288): "fc23_fused_h2_128x64",
+           ("fp32_f16x2", 12289): "fc_h2_256x128", ("fp32", 4096): "fc23_fused_phased128x64"}
+    x = np.random.default_rng(1).standard_normal((12289, 150, 54), dtype=np.float32)
+    for precision, rows in expect.items():
+        m = contact_cnn(device=0, max_batch=16384, precision=precision); m.load_state_dict(sd).eval()
+        for n, conv in rows.items():
+            m.predict(x[:n])
+            plan = m.last_plan()
+            assert plan[0] == conv, (precision, n, plan)
+            if (precision, n) in fcs:
+                assert fcs[(precision, n)] in plan, (precision, n, plan)
+        m.close()

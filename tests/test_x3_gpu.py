@@ -10,7 +10,7 @@ import pytest
 
 from conftest import tol_ok
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experiments]      # round 6: DCE_FP32_SPLIT's kernels live in the experiments build (tests/test_experiments_gpu.py runs this file there)
 
 
 @pytest.fixture(scope="module")

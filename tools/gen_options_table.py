@@ -17,6 +17,15 @@ for line in struct.split("\n"):
     for d in decls.split(","):
         name, _, dflt = d.strip().partition("=")
         info[name.strip()] = (dflt.strip() or "0", comment)
+# ---- the plan table (kPlanRows): precision x windows of the launch -> kernel families
+rows = api[api.index("constexpr PlanRow kPlanRows[]"):]
+rows = rows[:rows.index("};")]
+thr = {"T_ONE": "1", "T_CONV16": "`x3_conv_min` (128)", "T_H2FC": "first size with `h2_min_tiles` (96) 256 x 128 tiles of fc.0 (1281)", "T_BF16H2": "`bf16_conv_h2_min` (257)", "T_INF": "-"}
+print("| precision | windows from | below | conv stack | fc.0 family | fc.3 family | |\n|---|---|---|---|---|---|---|")
+for m in re.finditer(r"\{(DCE_\w+),\s*(T_\w+),\s*(T_\w+),\s*Conv::(\w+),\s*Fam::(\w+),\s*Fam::(\w+),\s*\"([^\"]*)\"\}", rows):
+    p, a, b, conv, f0, f3, what = m.groups()
+    print(f"| `{p}` | {thr[a]} | {thr[b]} | `{conv}` | {f0} | {f3} | {what} |")
+print()
 print("| option | default | build | effect |\n|---|---|---|---|")
 for k, exp in keys:
     d, c = info.get(k, ("?", ""))
