@@ -42,15 +42,19 @@ def main(argv=None):
                         help="arithmetic of the library (default fp32 = the reference's; the YAML may carry a `precision` key too): "
                              "bf16_fc = bf16 operands on fc.0 / fc.3; fp32_split = fp32 results on the bf16 matrix pipe (DESIGN.md 4.1x / 4.2x); "
                              "fp32_f16x2 = the fp32 tolerance from two fp16 terms per operand with per-window scales (DESIGN.md 4.6)")
+    parser.add_argument("--latency", action="store_true",
+                        help="the library's latency mode (fp32; option latency=1, a `latency: true` key in the YAML does the same): every batch of up to 32 windows "
+                             "-- the reference ships batch_size 1 and 30 -- is ONE kernel (DESIGN.md 4.5); needs the whole device")
     args = parser.parse_args(argv)
     config = yaml.safe_load(open(args.config_name))
+    tune = {"latency": 1} if (args.latency or config.get("latency")) else None
 
     test_data = contact_dataset(data_path=config["data_folder"] + "test.npy",
                                 label_path=config["data_folder"] + "test_label.npy",
                                 window_size=config["window_size"], device=device)
     test_dataloader = WindowLoader(test_data, batch_size=config["batch_size"])
     model = contact_cnn(device=local, max_batch=max(int(config["batch_size"]), 32768),
-                        precision=args.precision or config.get("precision", "fp32"))
+                        precision=args.precision or config.get("precision", "fp32"), tune=tune)
     model.load_state_dict(load_checkpoint(config["model_load_path"]))
     model = model.eval().to(device)
 

@@ -51,6 +51,12 @@ def test_entry_scripts_on_synthetic_config(tmp_path):
     assert "Test accuracy in terms of class is:" in r.stdout and "jaccard of class is:" in r.stdout
     i0 = next(k for k, l in enumerate(lines) if l.startswith("Test accuracy in terms of class is:"))
     assert len(lines) - i0 == 78 + 6                       # the reference's report: 46 labelled lines (6 matrices of 2 rows), 32 raw
+    # the reference's shipped batch_size 30 in the library's latency mode (round 6: one kernel per batch, csrc/latency_mb.hip): the same report
+    # (the loop's contact states are the reference's wherever its decision is not a toss-up; the synthetic set has none within fp32 noise)
+    rl = subprocess.run([sys.executable, "-m", "deep_contact_estimator_amd.test", "--config_name", str(tpath), "--latency"],
+                        env=env, capture_output=True, text=True)
+    assert rl.returncode == 0, rl.stderr[-2000:]
+    assert tcfg["batch_size"] == 30 and rl.stdout.splitlines()[i0:] == lines[i0:], "the latency mode's report differs from the batch path's"
 
 
 @pytest.mark.parametrize("nproc", [2, 8])
