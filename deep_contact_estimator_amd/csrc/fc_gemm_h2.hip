@@ -27,6 +27,9 @@ typedef __bf16 h2_bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef H2_TRACE
 #define H2_TRACE 0
 #endif
+#ifndef H2K_NOSPILL
+#define H2K_NOSPILL 0        // (experiments A/B, -DH2K_NOSPILL=1) the fc.0 K-split variant's final exchange one row block at a time: no scratch
+#endif
 
 namespace {
 
@@ -275,10 +278,13 @@ void fc_gemm_h2_kernel(const unsigned short* __restrict__ A2, const int* __restr
 //   * fc.3 + fc.6's chunk sums (H2Fc3: 128 x 64 tile = one chunk of fc.6's summation tree, 256 tiles at 4096 windows, 64 k per phase as two 32-k
 //     sub-tiles, 32 x 64 wave tiles: 24 MFMAs against 24 fragment reads per wave and phase -- with an N split between the groups a wave's 32 x 32
 //     would read 8 fragments for 6 MFMAs), epilogue as fc_gemm_phased.hip's FUSE6: h2 tile -> LDS -> fc6_chunk_mfma -> `part`;
-//   * (round 5, REMOVED) fc.0 on 64 x 128 wave tiles (H2KCfg<256, 128, 2, 4, 1>), 48 MFMAs against 24 reads per phase: no faster than the N-split kernel above
-//     (174.0 against 176.9 us per 4096 windows with both schedules fenced, profiles/r5q_f16x2_ksplit_ab.txt), 256 VGPRs with 27 spills in its final
-//     exchange -- and, in one run out of ten, a GPU memory fault that was not traced before the round ended.  The instantiation is gone; the
-//     record stays.
+//   * (experiments build only, option h2_ksplit) fc.0 on 64 x 128 wave tiles (H2KCfg<256, 128, 2, 4, 1>), 48 MFMAs against 24 reads per phase: no faster than the
+//     N-split kernel above (174.0 against 176.9 us per 4096 windows, profiles/r5q_f16x2_ksplit_ab.txt) -- and the ONE kernel of either build that needs scratch:
+//     128 accumulators + 96 fragment registers leave no room for its final exchange, 27 VGPRs spill.  Round 5 saw it abort with a GPU memory fault in one
+//     process of ten; round 6 traced the faulting addresses to the private-segment (scratch) aperture -- a 4 GB-aligned base plus a wave's scratch offset, ~4 GB
+//     away from every buffer of the context, with every operand buffer placed against an unmapped page (csrc/dev_alloc.hip) -- i.e. to its spill slots, in a
+//     process that creates and destroys contexts (profiles/r6d_ksplit_fault_trace.txt).  No operand extent of this template is involved, and
+//     H2KFc3 -- what ships -- has no scratch: tests/test_build.py keeps it so for every product kernel.
 template <int BM_, int BN_, int AB_, int BB_, int NSUB_> struct H2KCfg {
     static constexpr int BM = BM_, BN = BN_, AB = AB_, BB = BB_, NSUB = NSUB_;
     static constexpr int R = BM + BN, SUBT = R * H2_ROWB, TILE = NSUB * SUBT, LDS = 3 * TILE;
@@ -436,6 +442,34 @@ void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __rest
     auto finish = [&](auto gc) {
         constexpr int G = decltype(gc)::value, HB = BB / 2, XF = AB * HB * 16;      // floats per lane that cross
         float* const x = reinterpret_cast<float*>(h2_smem) + ((size_t)wid * XF * 64);      // this wave's area: [XF values][64 lanes]
+        const float* const y = reinterpret_cast<const float*>(h2_smem) + ((size_t)(wid ^ 4) * XF * 64);   // the partner wave (same rows, other group)
+        if constexpr (!FUSE6 && H2K_NOSPILL) {
+            // (round 6, experiments: the exchange and the store ONE row block at a time -- 32 values cross per step instead of 64 and their addresses die
+            //  before the next block's are formed: no spill, no scratch; the A/B that separates the kernel's arithmetic from its scratch accesses)
+#pragma unroll
+            for (int a = 0; a < AB; ++a) {
+#pragma unroll
+                for (int b = 0; b < HB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[((a * HB + b) * 16 + r) * 64 + lane] = acc[a][HB * (1 - G) + b][r];
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int b = 0; b < HB; ++b) {
+                    const int col = n0 + 32 * (HB * G + b) + i;
+                    const float bv = bias[col];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float mine = acc[a][HB * G + b][r], theirs = y[((a * HB + b) * 16 + r) * 64 + lane];
+                        const float sum = G == 0 ? mine + theirs : theirs + mine;
+                        float v = __builtin_ldexpf(sum, BF16 ? 0 : -(row_scale[row < M ? row : M - 1] + sw)) + bv;
+                        if (relu) v = v < 0.f ? 0.f : v;
+                        if (row < M) C[(size_t)row * N + col] = v;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < AB; ++a)
 #pragma unroll
@@ -443,7 +477,6 @@ void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __rest
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x[((a * HB + b) * 16 + r) * 64 + lane] = acc[a][HB * (1 - G) + b][r];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const float* const y = reinterpret_cast<const float*>(h2_smem) + ((size_t)(wid ^ 4) * XF * 64);   // the partner wave (same rows, other group)
 #pragma unroll
         for (int a = 0; a < AB; ++a)
 #pragma unroll

@@ -6,9 +6,9 @@
 // (one per CU, 84 KB of LDS each) carries a batch of n <= 32 windows through the same roles on MFMA tiles:
 //   * conv role, workgroups 0 .. NC-1: the quarter-window segments of conv_wino_dev.h, one per workgroup (NC = 4 n), or -- up to 16 windows -- two
 //     workgroups per segment, each finishing one half of conv4's output channels as in latency.hip (NC = 8 n <= 128).  Features -> HBM (write-through).
-//   * fc.0 role, workgroups NC .. NC+127: 16 neurons each.  A wave holds ITS 592 k of the 16 rows in registers -- 148 VGPRs, the B operands of 148
-//     v_mfma_f32_16x16x4_f32 -- requested before any feature exists: the 38.8 MB weight stream runs under the conv role.  Then the features of all n
-//     windows stream past (A operands, 16 windows per MFMA row tile), the eight waves' partial sums meet in LDS in a fixed order, bias + ReLU -> h1.
+//   * fc.0 role, workgroups NC .. NC+127: 16 neurons each.  A wave holds ITS 18 or 19 granules of 32 k of the 16 rows in registers -- 152 VGPRs, the B
+//     operands of v_mfma_f32_16x16x4_f32 -- requested before any feature exists: the 38.8 MB weight stream runs under the conv role.  Then the features of
+//     all n windows stream past (A operands, 16 windows per MFMA row tile), the eight waves' partial sums meet in LDS in a fixed order, bias + ReLU -> h1.
 //   * fc.3, on the conv workgroups once their segment is done (a tile = 16 neurons x 16 windows on workgroup t, t + NC, ..): the same scheme over K = 2048,
 //     then the tile's share of fc.6 -- partial logits over its 16 neurons for its windows.
 //   * the last step on workgroup 0: the 32 partial logits per (window, class) added in order + bias, torch.max(output, 1), decimal2binary.
@@ -17,7 +17,7 @@
 // loads (served by L2, never by a CU's L1); behind them one 64-bit FLAG per producer in fine-grained memory that takes the request's number once the
 // producer's stores are acknowledged (s_waitcnt vmcnt(0) + workgroup barrier).  A consumer's first wave polls the flags it needs; every wait has a
 // deadline, and a kernel that runs into one raises the mailbox's error word and leaves (as latency.hip).
-// Numerics: every sum is fp32 on the fp32 matrix pipe (exact fp32 fma chains) -- a wave's 592-k (256-k) chain, then eight partial sums in fixed order:
+// Numerics: every sum is fp32 on the fp32 matrix pipe (exact fp32 fma chains) -- a wave's 576 / 608-k (256-k) chain, then eight partial sums in fixed order:
 // deterministic, NOT the batch path's bits (its summation tree is another association); held to the fp32 tolerance against the CPU restatement.
 #include "conv_wino_dev.h"
 #include "fc6_chain.h"
@@ -41,12 +41,6 @@ typedef unsigned mb_u32x4 __attribute__((ext_vector_type(4)));
 #define MB_AUX 16                                                 // cache policy of the A-operand loads: 16 = sc1 (agent scope)
 #endif
 
-__device__ __forceinline__ float4 mb_ld4(const float* p)           // 16 bytes by two agent-scope (sc1) loads: L2-served, never from this CU's L1
-{
-    const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
-}
 __device__ __forceinline__ void mb_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // everything this workgroup stored has been acknowledged by the memory side before its flag takes the request's number
