@@ -74,7 +74,7 @@ struct Tuning {
     bool one_per_cu = false, trace_wino1 = false;           // trace builds
     // -- memory-safety tests (dev_alloc.hip)
     int guard_mask = -1;                                    // ... which buffer groups (bit 0 weights, 1 feat, 2 h1, 3 h2, 4 part, 5 staged input, 6 staged results, 7 feat3, 8 two-/three-term h1 + scales, 9 small state, 10 online ring)
-    int guard_alloc = 0;                                    // 1 / 2: every device buffer of the context in a mapping of its own whose last / first byte abuts an unmapped page
+    int guard_alloc = 0;                                    // 1 / 2: every device buffer of the context in a mapping of its own whose last / first byte abuts an unmapped page; 3: a 4 GB address line inside every buffer (csrc/dev_alloc.hip)
 };
 // parses "key=value,..." over `t`; false + message on an unknown key or a malformed value
 bool tuning_parse(const char* spec, Tuning& t, char* err, int err_len);

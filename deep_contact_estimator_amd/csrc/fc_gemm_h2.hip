@@ -28,7 +28,7 @@ typedef __bf16 h2_bf16x8 __attribute__((ext_vector_type(8)));
 #define H2_TRACE 0
 #endif
 #ifndef H2K_NOSPILL
-#define H2K_NOSPILL 0        // (experiments A/B, -DH2K_NOSPILL=1) the fc.0 K-split variant's final exchange one row block at a time: no scratch
+#define H2K_NOSPILL 0        // (experiments A/B, -DH2K_NOSPILL=1) the fc.0 K-split variant's final exchange one row block at a time: no scratch (it refuted the scratch reading of round 5's fault)
 #endif
 
 namespace {
@@ -54,9 +54,22 @@ __device__ __forceinline__ unsigned h2_m0_begin(unsigned lds)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1" : "=&s"(keep) : "s"(lds) : "memory");
     return keep;
 }
+// ("scc" in the clobber list is the fix of round 5's intermittent GPU memory fault: the s_add_u32 on m0 rewrites SCC, and without the clobber the scheduler
+//  was free to put this statement between the s_add_u32 and the s_addc_u32 that form the NEXT piece's 64-bit base -- the carry was lost, and a piece whose
+//  rows lie beyond a multiple of 4 GB that the operand buffer happens to cross was fetched from 4 GB below.  Seen in the assembly of all three K-split
+//  instantiations, the shipped fc.3 one among them; DESIGN.md 4.6, profiles/r6k_*.  -DH2_SCC_UNDECLARED=1: the old statement, for the A/B.)
+#ifndef H2_SCC_UNDECLARED
+#define H2_SCC_UNDECLARED 0
+#elif H2_SCC_UNDECLARED && !DCE_EXPERIMENTS
+#error "H2_SCC_UNDECLARED reproduces a bug: experiments builds only"
+#endif
 __device__ __forceinline__ void h2_piece(const char* base, unsigned v)
 {
+#if H2_SCC_UNDECLARED
     asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %1, %0\n\ts_add_u32 m0, m0, 0x1000" :: "s"(base), "v"(v) : "memory");
+#else
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %1, %0\n\ts_add_u32 m0, m0, 0x1000" :: "s"(base), "v"(v) : "memory", "scc");
+#endif
 }
 __device__ __forceinline__ void h2_m0_end(unsigned keep)
 {
@@ -280,11 +293,10 @@ void fc_gemm_h2_kernel(const unsigned short* __restrict__ A2, const int* __restr
 //     would read 8 fragments for 6 MFMAs), epilogue as fc_gemm_phased.hip's FUSE6: h2 tile -> LDS -> fc6_chunk_mfma -> `part`;
 //   * (experiments build only, option h2_ksplit) fc.0 on 64 x 128 wave tiles (H2KCfg<256, 128, 2, 4, 1>), 48 MFMAs against 24 reads per phase: no faster than the
 //     N-split kernel above (174.0 against 176.9 us per 4096 windows, profiles/r5q_f16x2_ksplit_ab.txt) -- and the ONE kernel of either build that needs scratch:
-//     128 accumulators + 96 fragment registers leave no room for its final exchange, 27 VGPRs spill.  Round 5 saw it abort with a GPU memory fault in one
-//     process of ten; round 6 traced the faulting addresses to the private-segment (scratch) aperture -- a 4 GB-aligned base plus a wave's scratch offset, ~4 GB
-//     away from every buffer of the context, with every operand buffer placed against an unmapped page (csrc/dev_alloc.hip) -- i.e. to its spill slots, in a
-//     process that creates and destroys contexts (profiles/r6d_ksplit_fault_trace.txt).  No operand extent of this template is involved, and
-//     H2KFc3 -- what ships -- has no scratch: tests/test_build.py keeps it so for every product kernel.
+//     128 accumulators + 96 fragment registers leave no room for its final exchange, 27 VGPRs spill (H2K_NOSPILL=1: the exchange one row block at a time, none).
+//     Round 5 saw it abort with a GPU memory fault in one process of ten.  Round 6: NOT the scratch (the no-spill build faults alike, profiles/r6k_*) -- the lost
+//     carry described at h2_piece, which every instantiation of this template had in its issue() (the bases of consecutive pieces are formed around the asm
+//     statements), the shipped fc.3 one included.  Fixed there; DESIGN.md 4.6.
 template <int BM_, int BN_, int AB_, int BB_, int NSUB_> struct H2KCfg {
     static constexpr int BM = BM_, BN = BN_, AB = AB_, BB = BB_, NSUB = NSUB_;
     static constexpr int R = BM + BN, SUBT = R * H2_ROWB, TILE = NSUB * SUBT, LDS = 3 * TILE;
@@ -445,7 +457,7 @@ void fc_gemm_h2k_kernel(const unsigned short* __restrict__ A2, const int* __rest
         const float* const y = reinterpret_cast<const float*>(h2_smem) + ((size_t)(wid ^ 4) * XF * 64);   // the partner wave (same rows, other group)
         if constexpr (!FUSE6 && H2K_NOSPILL) {
             // (round 6, experiments: the exchange and the store ONE row block at a time -- 32 values cross per step instead of 64 and their addresses die
-            //  before the next block's are formed: no spill, no scratch; the A/B that separates the kernel's arithmetic from its scratch accesses)
+            //  before the next block's are formed: no spill, no scratch; it faulted like the spilling build -- the fault was never the scratch)
 #pragma unroll
             for (int a = 0; a < AB; ++a) {
 #pragma unroll

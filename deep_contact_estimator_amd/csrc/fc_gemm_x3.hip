@@ -138,7 +138,7 @@ __device__ __forceinline__ unsigned x3_m0_begin(unsigned lds)
 }
 __device__ __forceinline__ void x3_piece(const char* base, unsigned v)
 {
-    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %1, %0\n\ts_add_u32 m0, m0, 0x1000" :: "s"(base), "v"(v) : "memory");
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %1, %0\n\ts_add_u32 m0, m0, 0x1000" :: "s"(base), "v"(v) : "memory", "scc");
 }
 __device__ __forceinline__ void x3_m0_end(unsigned keep)
 {
