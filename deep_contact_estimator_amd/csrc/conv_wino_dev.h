@@ -599,8 +599,10 @@ __device__ __forceinline__ void seg_stage1(float* __restrict__ act, const float*
 //   XREG = true : the caller holds this thread's RAW samples (rows t = 4 m + g of channel c, tid = 54 g + c < 216) in xin and the window
 //                 is z-scored here (ZS) -- the latency mode's service kernel keeps the last 150 samples in LDS (latency.hip).
 //   COHERENT    : the features are stored with agent-scope (write-through) stores: another workgroup of the SAME kernel reads them
-//   XPOSE (> 0) : ... in the micro-batch latency kernel's layout (latency_mb.hip): feature k of window w at ((k >> 2) * XPOSE + w) * 4 + (k & 3) -- the
-//                 four k of an MFMA step side by side, XPOSE windows per 16-byte column -- instead of row w of a (windows, 4736) matrix
+//   XPOSE (> 0) : ... in the micro-batch latency kernel's layout (latency_mb.hip): the features in the order k' = 128 t + channel (not torch's flatten
+//                 37 channel + t: the four channels an accumulator register quad holds are then neighbours, and the kernel's fc.0 weights are packed in
+//                 the same order), k' of window w at ((k' >> 2) * XPOSE + w) * 4 + (k' & 3) -- the four k' of an MFMA step side by side, XPOSE windows
+//                 per 16-byte column -- instead of row w of a (windows, 4736) matrix: one 16-byte store per lane and column tile
 template <bool ZS, int NSEG, int NT1, int NT2, bool TAPS = false, bool XREG = false, bool COHERENT = false, int XPOSE = 0>
 __device__ __forceinline__ void conv_seg_body(float* __restrict__ act, const float* __restrict__ src, int64_t win0, int sg, const ConvPack& pk,
                                               float* __restrict__ feat, const LayerTaps& taps, const float (*xin)[38] = nullptr, int chalf = -1)
@@ -710,14 +712,25 @@ __device__ __forceinline__ void conv_seg_body(float* __restrict__ act, const flo
             const int m = a4 + 16 * nt + j;
             if (m <= b4) {
                 float* base = feat + win0 * FEAT + (co2 + 4 * q) * 37 + m;
+                if constexpr (XPOSE > 0) {
+                    // k' = 128 m + channel: this lane's four channels are ONE quad -- one 16-byte agent-scope (sc1, write-through) store
+                    typedef unsigned xp_u32x4 __attribute__((ext_vector_type(4)));
+                    xp_u32x4 pk4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m0 = acc[0][nt][0][r], m1 = acc[0][nt][1][r], m2 = acc[0][nt][2][r], m3 = acc[0][nt][3][r];
+                        const float v = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
+                        pk4[r] = __float_as_uint(nan0 ? nanv : v);
+                    }
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(feat, 0, (FEAT / 4) * XPOSE * 16, 0x00027000);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk4, rs, (unsigned)(((m * 32 + (co2 >> 2) + q) * XPOSE + (int)win0) * 16), 0, 16);
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float m0 = acc[0][nt][0][r], m1 = acc[0][nt][1][r], m2 = acc[0][nt][2][r], m3 = acc[0][nt][3][r];
                     const float v = fmaxf(fmaxf((m0 + m1) + m2, (m1 - m2) - m3), 0.f);
-                    if constexpr (XPOSE > 0) {
-                        const int k = (co2 + 4 * q + r) * 37 + m;
-                        __hip_atomic_store(feat + ((size_t)(k >> 2) * XPOSE + win0) * 4 + (k & 3), nan0 ? nanv : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else if constexpr (COHERENT) __hip_atomic_store(base + r * 37, nan0 ? nanv : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (COHERENT) __hip_atomic_store(base + r * 37, nan0 ? nanv : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else base[r * 37] = nan0 ? nanv : v;
                     if constexpr (TAPS) {      // conv4 before the pool: pairs a4..b4 (t = 74, which the pool drops, is never computed here)
                         float* tp = taps.conv4 + (win0 * 128 + co2 + 4 * q + r) * 75 + 2 * m;

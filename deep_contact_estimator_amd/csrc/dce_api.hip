@@ -895,8 +895,8 @@ int dce_create_ex(dce_ctx** out, int device_id, int64_t max_batch, const char* o
         CREATE_TRY(dev_alloc(&c->lat_mb_h1, guard_of(c, 9), (size_t)LATMB_MAX_N * FC1 * sizeof(float)));
         CREATE_TRY(hipMemset(c->lat_mb_h1, 0, (size_t)LATMB_MAX_N * FC1 * sizeof(float)));
         CREATE_TRY(dev_alloc(&c->lat_mb_plt, guard_of(c, 9), (size_t)32 * LATMB_MAX_N * NCLS * sizeof(float)));
-        CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->lat_mb_flags), 576 * sizeof(unsigned long long), hipDeviceMallocFinegrained));
-        CREATE_TRY(hipMemset(c->lat_mb_flags, 0, 576 * sizeof(unsigned long long)));
+        CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->lat_mb_flags), 704 * sizeof(unsigned long long), hipDeviceMallocFinegrained));
+        CREATE_TRY(hipMemset(c->lat_mb_flags, 0, 704 * sizeof(unsigned long long)));
         CREATE_TRY(hipDeviceSynchronize());
     }
 #undef CREATE_TRY
@@ -1026,8 +1026,8 @@ int dce_finalize_weights(dce_ctx* c, int precision)
     size_t off_mb1 = 0, off_mb2 = 0;
     const bool want_mb = c->tuning.latency && c->tuning.latency_mb && precision == DCE_FP32;
     if (want_mb) {
-        off_mb1 = reserve(latmb_pack_floats(FC1, FEAT)); latmb_pack_host(c->host_w[8].data(), FC1, FEAT, img.data() + off_mb1);
-        off_mb2 = reserve(latmb_pack_floats(FC2, FC1));  latmb_pack_host(c->host_w[10].data(), FC2, FC1, img.data() + off_mb2);
+        off_mb1 = reserve(latmb_pack_floats(FC1, FEAT)); latmb_pack_host(c->host_w[8].data(), FC1, FEAT, img.data() + off_mb1, 128);
+        off_mb2 = reserve(latmb_pack_floats(FC2, FC1));  latmb_pack_host(c->host_w[10].data(), FC2, FC1, img.data() + off_mb2, 0);
     }
     const bool want_cx = precision == DCE_FP32_SPLIT || (precision == DCE_BF16_FC && c->tuning.x3_conv);
     const bool want_pair = (want_cx && (c->tuning.x3_pair || c->tuning.x3_permk)) || precision == DCE_FP32_F16X2;      // fc.0's weights once more, K axis in the conv kernels' feature order t' * 128 + c

@@ -356,11 +356,11 @@ struct LatArgs {
     int mb_n, mb_chalf;                                                        // windows; 1: two conv workgroups per quarter segment (n <= 16)
     const float *mb_w1, *mb_w2;                                                // fc.0 / fc.3 packed per (tile, wave, granule, lane) (latmb_pack_host)
     float *mb_feat, *mb_h1, *mb_plt;                                           // device memory: features [4736 / 4][32][4], h1 [2048 / 4][32][4] (latency_mb.hip's quad layout), partial logits [32 tiles][32][16]
-    unsigned long long* mb_flags;                                              // fine-grained device memory: [128] conv + [128] fc.0 + [64] fc.3 producer flags (the request's number)
+    unsigned long long* mb_flags;                                              // fine-grained device memory: [128] conv + [128] fc.0 + [64] fc.3 producer flags (the request's number), [320 .. 576) traced runs' stamps, [576 .. 704) fc.0's second row tile
 };
 constexpr int LATMB_MAX_N = 32;
 size_t     latmb_pack_floats(int rows, int K);
-void       latmb_pack_host(const float* W, int rows, int K, float* out);
+void       latmb_pack_host(const float* W, int rows, int K, float* out, int chan);      // chan > 0: columns re-ordered position-major (fc.0: 128)
 hipError_t init_latency_mb();
 hipError_t launch_latency_mb(int zscore, const LatArgs& a, hipStream_t st);
 hipError_t init_latency();

@@ -8,11 +8,15 @@
 //     workgroups per segment, each finishing one half of conv4's output channels as in latency.hip (NC = 8 n <= 128).  Features -> HBM (write-through).
 //   * fc.0 role, workgroups NC .. NC+127: 16 neurons each.  A wave holds ITS 18 or 19 granules of 32 k of the 16 rows in registers -- 152 VGPRs, the B
 //     operands of v_mfma_f32_16x16x4_f32 -- requested before any feature exists: the 38.8 MB weight stream runs under the conv role.  Then the features of
-//     all n windows stream past (A operands, 16 windows per MFMA row tile), the eight waves' partial sums meet in LDS in a fixed order, bias + ReLU -> h1.
-//   * fc.3, on the conv workgroups once their segment is done (a tile = 16 neurons x 16 windows on workgroup t, t + NC, ..): the same scheme over K = 2048,
-//     then the tile's share of fc.6 -- partial logits over its 16 neurons for its windows.
+//     16 windows stream past (A operands, one MFMA row tile), the eight waves' partial sums meet in LDS in a fixed order, bias + ReLU -> h1.
+//     17 .. 32 windows are two row tiles: the second one (windows 16 ..) of neuron tile j runs on the workgroup 128 blocks away (same XCD) -- a conv workgroup
+//     once its segment is stored, or an idle one -- which fetches the tile's 303 KB a second time, from L2 / the Infinity Cache (second_tile below).
+//   * fc.3 (a tile = 16 neurons x 16 windows): the same scheme over K = 2048, then the tile's share of fc.6 -- partial logits over its 16 neurons for its
+//     windows.  Up to 12 windows on idle CUs (weights requested at the start), up to 16 on the conv workgroups once their segment is done, from 17 on the
+//     first 64 workgroups of the fc.0 role (32 neuron tiles x 2 row tiles).
 //   * the last step on workgroup 0: the 32 partial logits per (window, class) added in order + bias, torch.max(output, 1), decimal2binary.
-// The features and h1 cross in the QUAD layout [k / 4][window (32)][4 k]: what an MFMA A operand wants lane by lane (see MbTile::run).
+// The features and h1 cross in the QUAD layout [k / 4][window (32)][4 k]: what an MFMA A operand wants lane by lane (see MbTile::run).  The features' k runs
+// position-major here (k' = 128 t + channel; fc.0's weight pack is in the same order): a conv lane's four channels are one quad, one 16-byte store.
 // Hand-overs: data (features, h1, partial logits) in ordinary device memory, written with agent-scope (write-through, sc1) stores and read with agent-scope
 // loads (served by L2, never by a CU's L1); behind them one 64-bit FLAG per producer in fine-grained memory that takes the request's number once the
 // producer's stores are acknowledged (s_waitcnt vmcnt(0) + workgroup barrier).  A consumer's first wave polls the flags it needs; every wait has a
@@ -192,6 +196,8 @@ void latency_mb_kernel(LatArgs a)
     unsigned long long* const fconv = a.mb_flags;                          // [128] conv workgroup b has stored its features
     unsigned long long* const ffc0 = a.mb_flags + 128;                     // [128] fc.0 tile j has stored its columns of h1
     unsigned long long* const ffc3 = a.mb_flags + 256;                     // [64]  fc.3 tile t has stored its partial logits
+    unsigned long long* const ffc0b = a.mb_flags + 576;                    // [128] 17 .. 32 windows: fc.0 tile j of the SECOND row tile (windows 16 ..) has stored its columns of h1
+    const bool two = n > 16;                                               // two row tiles of 16 windows
     int* const lflag = reinterpret_cast<int*>(lds + MB_LDS / 4 - 4);
     auto fail_out = [&]() { if (tid == 0) __hip_atomic_store(&a.mbox->error, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); };
 
@@ -199,14 +205,14 @@ void latency_mb_kernel(LatArgs a)
     const int ntile = MB_FC3 * (n > 16 ? 2 : 1);
     const bool dedicated = 256 - MB_FC0 - NC >= ntile;                     // enough idle CUs behind the fc.0 role: they take fc.3, with its weights requested at the start
     auto fc3_tiles = [&](int first, int stride) -> bool {
-        bool waited = false;
+        int waited = 0;
         for (int t3 = first; t3 < ntile; t3 += stride) {
             const int nt = t3 & (MB_FC3 - 1), mt0 = t3 >> 5;                    // neuron tile, row tile
             MbTile<MB_G3> t;
             t.load(a.mb_w2, FC1, nt, w, lane);
             const float w3v = a.w3[(size_t)(tid & 15) * FC2 + 16 * nt + ((tid >> 4) & 15)];      // thread (cls = tid & 15, i = (tid >> 4) & 15): W3[cls][16 nt + i]
-            if (!waited) { if (!mb_wait(ffc0, MB_FC0, seq, spin, lflag, tid)) { fail_out(); return false; } waited = true; }
-            if (t3 == 0) MB_TRACE(8);
+            if (!((waited >> mt0) & 1)) { if (!mb_wait(mt0 ? ffc0b : ffc0, MB_FC0, seq, spin, lflag, tid)) { fail_out(); return false; } waited |= 1 << mt0; }
+            if (t3 == (two ? MB_FC3 : 0)) MB_TRACE(8);                    // (17 .. 32 windows: the second row tile, whose fc.0 ran behind a conv segment)
             t.run<1>(a.mb_h1, FC1, n, a.b2, nt, w, lane, tid, lds, mt0);
             // lds[m * 16 + i] = ReLU(fc.3)[16 mt0 + m][16 nt + i].  Partial logits of the tile: thread (m, cls) walks its 16 neurons in order
             {
@@ -226,9 +232,30 @@ void latency_mb_kernel(LatArgs a)
         return true;
     };
 
+    // red[m * 16 + i] = h1[16 mt0 + m][16 j + i] -> the quad layout fc.3's tiles read
+    auto store_h1 = [&](int j, int mt0) {
+        const int m = 16 * mt0 + (tid >> 4), k = 16 * j + (tid & 15);
+        if (tid < 256 && m < n) mb_st(a.mb_h1 + ((size_t)(k >> 2) * LATMB_MAX_N + m) * 4 + (k & 3), lds[tid]);      // (one row tile: 256 values)
+    };
+    // 17 .. 32 windows: fc.0's SECOND row tile (windows 16 ..) of neuron tile j2 on the 128 workgroups outside the fc.0 role -- the conv workgroups once their
+    // segment is stored, and the idle ones.  The fc.0 role then multiplies 16 windows, not 32: at 32 windows its 2368 MFMAs per workgroup were 7.9 us of the fp32
+    // matrix pipe on half the chip while the other half waited for h1.  The tile's 303 KB of weights come a second time, from L2 / the Infinity Cache (the fc.0
+    // workgroup of the same tile sits 128 blocks away: the same XCD), requested before the wait for the other segments' features.
+    auto second_tile = [&]() -> bool {
+        const int j2 = (b - NC) & (MB_FC0 - 1);
+        MbTile<MB_G0> t;
+        t.load(a.mb_w1, FEAT, j2, w, lane);
+        if (!mb_wait(fconv, NC, seq, spin, lflag, tid)) { fail_out(); return false; }
+        t.run<1>(a.mb_feat, FEAT, n, a.b1, j2, w, lane, tid, lds, 1);
+        store_h1(j2, 1);
+        mb_post(&ffc0b[j2], seq, tid);
+        return true;
+    };
+
     if (b >= NC) {
-        if (b >= NC + MB_FC0) {                                            // idle CUs of a small batch: fc.3 if there are enough of them
+        if (b >= NC + MB_FC0) {                                            // idle CUs: fc.3 of a small batch if there are enough of them; a second row tile of fc.0 from 17 windows
             if (dedicated) (void)fc3_tiles(b - NC - MB_FC0, 256 - MB_FC0 - NC);
+            else if (two) (void)second_tile();
             return;
         }
         // ======================================================================== fc.0 role: tile j = 16 neurons
@@ -249,15 +276,11 @@ void latency_mb_kernel(LatArgs a)
         }
         if (!mb_wait(fconv, NC, seq, spin, lflag, tid)) { fail_out(); return; }
         if (j == 0) MB_TRACE(6);
-        if (n > 16) t.run<2>(a.mb_feat, FEAT, n, a.b1, j, w, lane, tid, lds);
-        else        t.run<1>(a.mb_feat, FEAT, n, a.b1, j, w, lane, tid, lds);
-        {
-            const int m = tid >> 4;                                        // red[m * 16 + i] = h1[m][16 j + i]
-            const int k = 16 * j + (tid & 15);                             // ... in the quad layout fc.3's tiles read
-            if (m < n) mb_st(a.mb_h1 + ((size_t)(k >> 2) * LATMB_MAX_N + m) * 4 + (k & 3), lds[tid]);
-        }
+        t.run<1>(a.mb_feat, FEAT, n, a.b1, j, w, lane, tid, lds);          // (17 .. 32 windows: the first row tile; the second one runs on the other 128 workgroups)
+        store_h1(j, 0);
         mb_post(&ffc0[j], seq, tid);
         if (j == 0) MB_TRACE(7);
+        if (two) (void)fc3_tiles(j, MB_FC0);                               // fc.3's 64 tiles on the first 64 of this role: done first, their fc.3 weights arrive under the wait for h1
         return;
     }
 
@@ -268,13 +291,15 @@ void latency_mb_kernel(LatArgs a)
         if (b == 0) MB_TRACE(1);
         conv_seg_body<ZS, 4, 2, 1, false, false, true, LATMB_MAX_N>(lds, a.src, win, sg, a.pk, a.mb_feat, LayerTaps{}, nullptr, chalf);
         if (b == 0) MB_TRACE(2);
+        if (a.trace && b == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MB_TRACE(14); __syncthreads(); MB_TRACE(15); }   // (traced runs: wave 0's stores acknowledged; every wave of the workgroup here)
         mb_post(&fconv[b], seq, tid);                                      // (with chalf the waves of the other channel half came back early and wait at its barrier)
         if (b == 0) MB_TRACE(3);
     }
     // ---- fc.3 on the conv workgroups (unless idle CUs took it: `dedicated`): a tile = 16 neurons x 16 windows (32 neuron tiles x one or two row tiles: with 17 .. 32 windows the two row tiles of
     //      a neuron tile go to two workgroups -- 1024 MFMAs each instead of 2048 on one), tile t3 on workgroup t3, t3 + NC, ..; then the tile's share
     //      of fc.6: partial logits over its 16 neurons for its windows
-    if (!dedicated && !fc3_tiles(b, NC < ntile ? NC : ntile)) return;
+    if (two) { if (!second_tile()) return; }
+    else if (!dedicated && !fc3_tiles(b, NC < ntile ? NC : ntile)) return;
 
     if (b != 0) return;
     // ============================================================================ workgroup 0: logits, torch.max(output, 1), decimal2binary
@@ -308,10 +333,12 @@ void latency_mb_kernel(LatArgs a)
     MB_TRACE(11);
 }
 
-// (rows, K) Linear weights -> the kernel's order: out[((((j * 8 + w) * NG + s) * 2 + h) * 64 + lane) * 4 + e] = W[16 j + (lane & 15)][32 (g0(w) + s) + 16 h + 4 (lane >> 4) + e]
-// for granule slot s < ng(w) of wave w (K / 32 granules dealt out over eight waves: the first K / 32 % 8 waves take one more); unused slots stay zero
+// (rows, K) Linear weights -> the kernel's order: out[((((j * 8 + w) * NG + s) * 2 + h) * 64 + lane) * 4 + e] = W[16 j + (lane & 15)][col(32 (g0(w) + s) + 16 h + 4 (lane >> 4) + e)]
+// for granule slot s < ng(w) of wave w (K / 32 granules dealt out over eight waves: the first K / 32 % 8 waves take one more); unused slots stay zero.
+// chan > 0 (fc.0): the kernel's k' runs position-major over the conv stack's output, k' = chan t + channel (conv_wino_dev.h XPOSE), torch's flatten
+// channel-major: col(k') = (k' % chan) (K / chan) + k' / chan; chan = 0: col(k') = k'
 size_t latmb_pack_floats(int rows, int K) { return (size_t)(rows / 16) * 8 * ((K / 32 + 7) / 8) * 512; }
-void latmb_pack_host(const float* W, int rows, int K, float* out)
+void latmb_pack_host(const float* W, int rows, int K, float* out, int chan)
 {
     const int total = K / 32, lo = total / 8, extra = total % 8, NG = (total + 7) / 8;
     memset(out, 0, latmb_pack_floats(rows, K) * sizeof(float));
@@ -321,9 +348,10 @@ void latmb_pack_host(const float* W, int rows, int K, float* out)
             for (int s = 0; s < ng; ++s)
                 for (int h = 0; h < 2; ++h)
                     for (int lane = 0; lane < 64; ++lane) {
-                        const float* src = W + (size_t)(16 * j + (lane & 15)) * K + 32 * (g0 + s) + 16 * h + 4 * (lane >> 4);
+                        const float* row = W + (size_t)(16 * j + (lane & 15)) * K;
+                        const int k0 = 32 * (g0 + s) + 16 * h + 4 * (lane >> 4);
                         float* dst = out + ((((size_t)(j * 8 + w) * NG + s) * 2 + h) * 64 + lane) * 4;
-                        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+                        for (int e = 0; e < 4; ++e) { const int k = k0 + e; dst[e] = row[chan > 0 ? (k % chan) * (K / chan) + k / chan : k]; }
                     }
         }
 }

@@ -42,7 +42,7 @@ for n in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,3,8,15,16,17
         m._lib.dce_debug_latency_trace(m._ctx, st)
         t0 = st[1]
         tr = {k: round((st[i] - t0) / 100.0, 2) for i, k in ((2, "conv_done"), (3, "conv_posted"), (4, "fc0_w_requested"), (5, "fc0_w_landed"), (6, "feat_seen"), (7, "h1_posted"),
-                                                            (8, "h1_seen"), (9, "fc3_posted"), (10, "partials_seen"), (11, "done"))}
+                                                            (8, "h1_seen"), (9, "fc3_posted"), (10, "partials_seen"), (11, "done"), (14, "conv_w0_stores_acked"), (15, "conv_all_waves"))}
     def dist(mod, k=200):
         ts = []
         for _ in range(k):
