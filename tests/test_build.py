@@ -35,8 +35,10 @@ def test_the_one_scratch_kernel_is_the_experiments_only_fc0_k_split():
 def test_no_compiler_instruction_reads_an_scc_written_by_inline_asm():
     r = _check()
     assert r.returncode == 0 and "\n0 reads of an SCC written inside an inline-asm statement" in r.stdout, r.stdout + r.stderr
-    r = _check("--only=fc_gemm_h2.hip", "--only=fc_gemm_x3.hip", "-DDCE_EXPERIMENTS=1")
+    assert "\n0 kernels in which compiler-generated code touches m0" in r.stdout, r.stdout       # (the LDS-DMA statements own m0 where they use it)
+    r = _check("--only=fc_gemm_h2.hip", "--only=fc_gemm_x3.hip", "--only=fc_gemm_phased.hip", "--only=conv_x3p.hip", "-DDCE_EXPERIMENTS=1")
     assert "\n0 reads of an SCC written inside an inline-asm statement" in r.stdout, r.stdout + r.stderr
+    assert "\n0 kernels in which compiler-generated code touches m0" in r.stdout, r.stdout
 
 
 def test_the_scan_sees_the_statement_that_caused_round_5s_fault():
