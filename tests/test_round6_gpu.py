@@ -77,6 +77,38 @@ def test_latency_micro_batch_vs_oracle(n, sd, orc):
     m.close()
 
 
+def test_latency_micro_batch_every_size_interleaved(sd, orc):
+    """Every size 2 .. 32 on ONE context, in an order that alternates between the role layouts (two conv workgroups per segment | one, fc.3 on idle CUs | on
+    the conv workgroups | on the fc.0 role, one | two row tiles with the second one behind a conv segment), pre-normalised windows and raw rows: each call
+    against the ORACLE, and equal -- bit for bit -- to the same windows' rows when they were part of another call's size (a window's logits depend on its
+    row tile's position only through the fixed order of the sums: rows are independent).  Flags of differently sized calls share one array: a stale flag
+    of an earlier, larger call must never satisfy a later wait (the request's number does that)."""
+    from deep_contact_estimator_amd import synth
+    m = _model(sd, tune={"latency": 1})
+    o = orc.Oracle(sd)
+    seq = synth.make_sequence(150 + 32 - 1, seed=77, kind="ar1").astype(np.float32)
+    zw = orc.zscore_windows(seq)
+    ref = o.forward_windows(zw)
+    sizes = [32, 2, 17, 16, 31, 3, 13, 30, 12, 24, 5, 18, 9, 29, 4, 20, 8, 27, 6, 22, 10, 25, 7, 19, 11, 28, 14, 21, 15, 26, 23]
+    assert sorted(sizes) == list(range(2, 33))
+    full = None
+    for n in sizes:
+        got = m.predict(zw[:n])
+        assert m.last_plan() == ["latency_mb"], (n, m.last_plan())
+        tol_ok(got["logits"], ref["logits"][:n], f"latency mode, {n} windows")
+        _argmax_contract(got["pred"], {"logits": ref["logits"][:n], "pred": ref["pred"][:n]})
+        assert np.array_equal(got["contacts"], orc.decimal2binary(got["pred"]))
+        gz = m.infer_sequence(seq[:149 + n])
+        assert m.last_plan() == ["latency_mb_zs"], (n, m.last_plan())
+        tol_ok(gz["logits"], ref["logits"][:n], f"latency mode, {n} raw windows")
+        if full is None:
+            full = got["logits"].copy()
+        else:                                                      # rows 0 .. 15 sit in the first row tile whatever n is: the same chains, the same bits
+            k = min(n, 16)
+            assert np.array_equal(got["logits"][:k], full[:k]), n
+    m.close()
+
+
 def test_latency_micro_batch_limits_and_switch(sd, orc):
     """33 windows and more take the batch path's kernels (bit-identical to a context without the option); latency_mb=0 keeps 2 .. 32 there too;
     one window stays on latency.hip's kernel; the micro-batch kernel and the one-window kernel alternate on one context without disturbing
