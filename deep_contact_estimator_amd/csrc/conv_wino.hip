@@ -743,13 +743,17 @@ void conv_wino1x8_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, 
 template <bool ZS, int NSEG, int NT1, int NT2, bool TAPS = false>
 __global__ __launch_bounds__(512)
 void conv_wino_seg_kernel(const float* __restrict__ src, int64_t n, ConvPack pk, float* __restrict__ feat,
-                          const long long* __restrict__ src_row, LayerTaps taps)
+                          const long long* __restrict__ src_row, LayerTaps taps, int chsplit = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float act[];
     if (src_row) src += *src_row * CH;                    // online graph: the window start lives in device memory
-    const int64_t win0 = blockIdx.x / NSEG;
+    // chsplit (quarter segments of up to 32 windows: 8 n <= 256 workgroups, one per CU): TWO workgroups per segment, each finishing one half of conv4's
+    // output channels (41 % of the stack's MFMAs) -- four waves instead of eight on an MFMA-bound layer, on CUs that would idle; conv1..3 are computed by
+    // both.  A channel's chain is the same instructions on the same wave either way: the same bits (as the latency mode's kernels, latency.hip)
+    const unsigned blk = chsplit ? blockIdx.x >> 1 : blockIdx.x;
+    const int64_t win0 = blk / NSEG;
     if (win0 >= n) return;
-    conv_seg_body<ZS, NSEG, NT1, NT2, TAPS>(act, src, win0, (int)(blockIdx.x % NSEG), pk, feat, taps);
+    conv_seg_body<ZS, NSEG, NT1, NT2, TAPS>(act, src, win0, (int)(blk % NSEG), pk, feat, taps, nullptr, chsplit ? (int)(blockIdx.x & 1) : -1);
 }
 
 
@@ -811,8 +815,8 @@ hipError_t launch_conv_wino_taps(int kernel, const float* src, int64_t n, const 
     switch (kernel) {
     case 0: hipLaunchKernelGGL((conv_wino_kernel<false, float, true>), dim3((unsigned)((n + NW - 1) / NW)), dim3(256), lds, st, src, n, pk, f, none, taps); break;
     case 1: hipLaunchKernelGGL((conv_wino1x8_kernel<false, true>), dim3((unsigned)n), dim3(512), lds, st, src, n, pk, f, none, taps); break;
-    case 2: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2, true>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, none, taps); break;
-    case 3: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1, true>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, none, taps); break;
+    case 2: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2, true>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, none, taps, 0); break;
+    case 3: hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1, true>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, none, taps, 0); break;
 #if DCE_EXPERIMENTS
     case 6: hipLaunchKernelGGL((conv_wino_rt4_kernel<false, float, true>), dim3((unsigned)((n + NW - 1) / NW)), dim3(256), lds, st, src, n, pk, f, none, taps); break;
     case 5: hipLaunchKernelGGL((conv_wino1_kernel<false, true>), dim3((unsigned)n), dim3(256), lds, st, src, n, pk, f, none, taps); break;
@@ -852,15 +856,17 @@ hipError_t launch_conv_wino(const float* src, int zscore, int64_t n, const ConvP
         const int64_t quarter_max = tu.winoq_max >= 0 ? tu.winoq_max : WINOQ_MAX_N;
         const size_t hl = HLDS_FLOATS * sizeof(float);
         if (n <= quarter_max) {
-            plan_note("conv_wino_quarter");
-            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 4, 2, 1>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{});
-            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1>), dim3((unsigned)(4 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{});
+            const int chs = n <= tu.winoq_chsplit_max ? 1 : 0;        // conv4's channel halves on two workgroups while every workgroup still has a CU of its own
+            plan_note(chs ? "conv_wino_quarter_ch2" : "conv_wino_quarter");
+            const dim3 g((unsigned)((chs ? 8 : 4) * n));
+            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 4, 2, 1>), g, dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{}, chs);
+            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 4, 2, 1>), g, dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{}, chs);
             return hipGetLastError();
         }
         if (n <= half_max) {
             plan_note("conv_wino_half");
-            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{});
-            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{});
+            if (zscore) hipLaunchKernelGGL((conv_wino_seg_kernel<true, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{}, 0);
+            else        hipLaunchKernelGGL((conv_wino_seg_kernel<false, 2, 3, 2>), dim3((unsigned)(2 * n)), dim3(512), hl, st, src, n, pk, f, src_row, LayerTaps{}, 0);
             return hipGetLastError();
         }
 #if DCE_EXPERIMENTS

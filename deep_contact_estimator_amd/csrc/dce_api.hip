@@ -64,7 +64,7 @@ const TuneKey kTuneKeys[] = {
     TK(gemm_tile, 'b'), TK(phased_min_tiles, 'i'), TK(phased_min_tiles1, 'i'), TK(phased_min, 'i'), TK(phased_cost, 'b'), TK(phased_sn, 'i'),
     TK(fc23, 'i'), TK(gemm_peel, 'b'), TK(conv_peel, 'b'), TK(gemm_small_deep, 'b'), TK(gemv, 'b'),
     TK(split_min, 'l'), TK(split_max, 'l'), TK(chain_min, 'l'), TK(chain_max, 'l'), TK(chain_max3, 'l'), TK(chain_bn16_max, 'l'),
-    TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TKX(wino1_w8, 'b'),
+    TK(wino1_max, 'l'), TK(winoh_max, 'l'), TK(winoq_max, 'l'), TK(winoq_chsplit_max, 'i'), TKX(wino1_w8, 'b'),
     TK(bf16_stream, 'b'), TK(x3_bf16_min, 'l'), TKX(x3_bf16_terms, 'i'), TK(bf16_conv_h2, 'b'), TK(bf16_conv_h2_min, 'l'),
     TK(online_graph, 'b'), TK(online_direct, 'b'), TK(latency, 'b'), TK(latency_mb, 'b'), TK(latency_mb_chalf, 'i'), TK(latency_idle_ms, 'i'), TK(latency_fc_delay, 'i'),
     TK(x3_conv, 'b'), TK(x3_conv_min, 'l'), TK(x3_min_tiles, 'i'), TKX(x3_unfused, 'b'), TK(x3_permk, 'b'), TKX(x3_fc3, 'b'), TKX(split_guard, 'b'), TK(h2_fc3, 'b'), TK(h2_min_tiles, 'i'), TK(guard_alloc, 'i'), TK(guard_mask, 'i'),

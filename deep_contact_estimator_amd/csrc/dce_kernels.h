@@ -37,6 +37,7 @@ struct Tuning {
     bool gemv = true;                                       // 0: no weight-streaming GEMV for <= 8 windows
     long long split_min = 9, split_max = 64;                // windows served by the four-range MFMA kernel (fc_gemm_split.hip)
     long long chain_min = 9, chain_max = 640, chain_max3 = 2048, chain_bn16_max = 64;   // ... by the MFMA chain kernel (fc.0 / fc.3; 32x16 blocks up to)
+    int winoq_chsplit_max = 32;                             // ... up to this many windows the quarter-segment conv kernel runs TWO workgroups per segment (one half of conv4's output channels each; 8 n <= 256 workgroups); 0: one
     long long wino1_max = -1, winoh_max = -1, winoq_max = -1;   // windows up to which the one-window / half-window / quarter-window conv kernels run (-1: kernel default 256 / 128 / 64)
     bool wino1_w8 = true;                                   // 0: the four-wave predecessor of the one-window kernel
     bool online_graph = false, online_direct = false;       // online pushes as ONE captured hipGraph launch / as plain launches with per-push parameters

@@ -318,8 +318,8 @@ def test_conv_rt4_equals_its_predecessor_bitwise(monkeypatch):
 def test_plan_by_batch_size(model_of):
     """The kernel families the dispatch picks at the batch sizes the other tests rely on."""
     m = model_of()
-    want = {1: ["conv_wino_quarter", "fc_gemv", "fc_gemv", "fc3_tail"],
-            30: ["conv_wino_quarter", "fc_split16x16", "fc_split16x16", "fc3_tail"],
+    want = {1: ["conv_wino_quarter_ch2", "fc_gemv", "fc_gemv", "fc3_tail"],
+            30: ["conv_wino_quarter_ch2", "fc_split16x16", "fc_split16x16", "fc3_tail"],
             100: ["conv_wino_half", "fc_chain32x32", "fc_chain32x32", "fc3_tail"],
             200: ["conv_wino1x8", "fc_chain32x32", "fc_chain32x32", "fc3_tail"]}
     rng = np.random.default_rng(2)

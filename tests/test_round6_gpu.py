@@ -198,7 +198,7 @@ def test_the_plan_table_is_what_runs(sd):
     from deep_contact_estimator_amd import contact_cnn
     if has_experiments():
         pytest.skip("the experiments build plans with round 5's predicate tree")
-    expect = {"fp32": {1: "conv_wino_quarter", 4096: "conv_wino2"},
+    expect = {"fp32": {1: "conv_wino_quarter_ch2", 4096: "conv_wino2"},
               "bf16_fc": {256: "conv_x2_bf16_permk", 257: "conv_h2_bf16_permk"},
               "fp32_f16x2": {127: "conv_wino_half", 128: "conv_h2_f32", 1280: "conv_h2_f32", 1281: "conv_h2", 12288: "conv_h2", 12289: "conv_h2"}}
     fcs = {("fp32_f16x2", 1280): "fc_phased128x64", ("fp32_f16x2", 1281): "fc_h2_256x128_out2", ("fp32_f16x2", 12288): "fc23_fused_h2_128x64",
